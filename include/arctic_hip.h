@@ -1,0 +1,250 @@
+/*
+ * arctic_hip.h -- C-ABI of the MI355X-native forward PBR shading path.
+ *
+ * This is the drop-in boundary for the per-pixel work of arctic-renderer's
+ * shaders/forward.hlsl + shaders/post_process.hlsl.  The reference has no FFI;
+ * the seam is the public surface of class Arctic::Renderer::Renderer
+ * (reference src/renderer/renderer.hpp:94-125), the only thing src/app.cpp
+ * calls.  Every entry point below names the reference call it replaces.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes only, no C++/torch types.
+ *   - every fallible call returns int: >= 0 ok (an index where one is
+ *     documented), < 0 an ARCTIC_E_* code.  The reference returns
+ *     [[nodiscard]] bool and logs (src/renderer/dxerr.hpp:5-10); here the
+ *     message is kept per handle and read with arctic_last_error().
+ *   - inputs are borrowed for the duration of the call and copied to device
+ *     memory synchronously (reference: blocking fence inside every upload,
+ *     src/renderer/rhi.cpp:480-519); the handle owns all device memory.
+ *   - a handle is not thread-safe (reference is single threaded).
+ *   - matrices are 16 floats in glm memory order (column major), the same
+ *     bytes the reference pushes as root constants
+ *     (src/renderer/forward_pass.hpp:16-34).
+ *   - there is NO CPU fallback: without a HIP device arctic_create() fails.
+ */
+#ifndef ARCTIC_HIP_H
+#define ARCTIC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes --------------------------------------------------------- */
+#define ARCTIC_OK            0
+#define ARCTIC_E_INVALID    -1 /* bad argument (null, zero size, index out of range) */
+#define ARCTIC_E_DEVICE     -2 /* a HIP runtime call failed (message has hipGetErrorString) */
+#define ARCTIC_E_NO_DEVICE  -3 /* no HIP device / device ordinal out of range */
+#define ARCTIC_E_STATE      -4 /* call order (e.g. shade before any G-buffer exists) */
+#define ARCTIC_E_CAPACITY   -5 /* more lights than max_lights, etc. */
+
+/* ---- POD scene types: byte-compatible with src/renderer/scene.hpp -------- */
+
+/* scene.hpp:20-38  Camera{vec3 eye; vec2 rotation; float aspect; float fov_y; array<float,2> z_near_far} */
+typedef struct ArcticCamera {
+    float eye[3];
+    float rotation[2];   /* degrees: x = pitch, y = yaw (scene.cpp:9-19) */
+    float aspect;
+    float fov_y;         /* degrees */
+    float z_near_far[2];
+} ArcticCamera;
+
+/* scene.hpp:40-47  Vertex, 14 floats = 56 B; input layout forward_pass.cpp:89-135 */
+typedef struct ArcticVertex {
+    float position[3];
+    float normal[3];
+    float tangent[3];
+    float bitangent[3];
+    float tex_coords[2];
+} ArcticVertex;
+
+/* scene.hpp:69-73  Object{mat4 trs; size_t mesh_idx} */
+typedef struct ArcticObject {
+    float    trs[16];    /* glm column-major */
+    uint64_t mesh_idx;
+} ArcticObject;
+
+/* scene.hpp:75-84  DirectionalLight{vec3 position; vec2 rotation; vec3 color} */
+typedef struct ArcticDirectionalLight {
+    float position[3];
+    float rotation[2];   /* degrees */
+    float color[3];
+} ArcticDirectionalLight;
+
+/* scene.hpp:88-94  PointLight, 32 B with pads (== HLSL cbuffer packing, forward.hlsl:20-24) */
+typedef struct ArcticPointLight {
+    float    position[3];
+    uint32_t padding0;
+    float    color[3];
+    uint32_t padding1;
+} ArcticPointLight;
+
+/* scene.hpp:96-103 Scene; std::vector members flattened to pointer + count.
+ * point_lights here is ignored by render_frame exactly as in the reference
+ * (renderer.cpp:285-407 uses the buffer last written by update_lights). */
+typedef struct ArcticScene {
+    ArcticCamera            camera;
+    float                   ambient;
+    ArcticDirectionalLight  sun;
+    const ArcticPointLight *point_lights;
+    uint64_t                n_point_lights;
+    const ArcticObject     *objects;
+    uint64_t                n_objects;
+} ArcticScene;
+
+/* scene.hpp:105-110 Settings{int tm_method=0; float gamma=2.2; float exposure=1} */
+typedef struct ArcticSettings {
+    int32_t tm_method;   /* 0 Reinhard (also any other value), 1 Exposure, 2 ACES: post_process.hlsl:76-89 */
+    float   gamma;
+    float   exposure;
+} ArcticSettings;
+
+#define ARCTIC_TM_REINHARD 0
+#define ARCTIC_TM_EXPOSURE 1
+#define ARCTIC_TM_ACES     2
+
+/* create-time parameters: every compile-time constant of the reference that
+ * BASELINE.json's configs vary becomes a field here. */
+typedef struct ArcticCreateInfo {
+    uint32_t width, height;  /* render-target size (renderer.hpp:94, App::WINDOW_WIDTH/HEIGHT app.hpp:20-21) */
+    uint32_t shadow_size;    /* ShadowMapPass::SIZE = 4000 (shadow_map_pass.hpp:23); 0 = no shadow map, shadow term 0 */
+    uint32_t max_lights;     /* Renderer::MAX_NUM_POINT_LIGHTS = 16 (renderer.hpp:22) */
+    int32_t  device;         /* HIP device ordinal */
+    uint32_t row_begin;      /* screen-space shard: this handle renders rows [row_begin,row_end) ... */
+    uint32_t row_end;        /* ... of the width x height frame; 0,0 = whole frame */
+} ArcticCreateInfo;
+
+typedef struct ArcticRenderer ArcticRenderer; /* opaque */
+
+/* ---- life cycle ---------------------------------------------------------- */
+
+/* replaces Renderer::Renderer(window,w,h) + bool Renderer::init()
+ * (renderer.hpp:94-100, renderer.cpp:22-231); no window.  On failure returns
+ * NULL and, if err/err_len given, writes the message there. */
+ArcticRenderer *arctic_create(const ArcticCreateInfo *info, char *err, uint64_t err_len);
+
+/* replaces Renderer::cleanup() + destructor (renderer.hpp:102) */
+void arctic_destroy(ArcticRenderer *r);
+
+/* last error message of this handle ("" if none); valid until the next call */
+const char *arctic_last_error(const ArcticRenderer *r);
+
+/* replaces bool Renderer::resize(uint32_t&,uint32_t&) (renderer.hpp:104).  Unlike
+ * the reference (which only resizes the swapchain, renderer.cpp:241-272) this
+ * really reallocates the targets; the row shard is reset to the whole frame. */
+int arctic_resize(ArcticRenderer *r, uint32_t width, uint32_t height);
+
+/* replaces bool Renderer::flush() (renderer.hpp:122-125): device idle */
+int arctic_flush(ArcticRenderer *r);
+
+/* ---- scene upload -------------------------------------------------------- */
+
+/* replaces bool Renderer::create_material(void*,w,h, void*,w,h, void*,w,h)
+ * (renderer.hpp:112-116, renderer.cpp:475-553): three tightly packed RGBA8
+ * images; diffuse is sRGB, the other two linear.  Returns the material index
+ * (= call order, like m_materials.emplace_back). */
+int arctic_create_material(ArcticRenderer *r,
+                           const void *diffuse, uint32_t diffuse_w, uint32_t diffuse_h,
+                           const void *normal, uint32_t normal_w, uint32_t normal_h,
+                           const void *metal_rough, uint32_t mr_w, uint32_t mr_h);
+
+/* replaces bool Renderer::create_mesh(span<Vertex>, span<uint32_t>, MaterialIdx)
+ * (renderer.hpp:109-110, renderer.cpp:417-473).  Returns the mesh index. */
+int arctic_create_mesh(ArcticRenderer *r,
+                       const ArcticVertex *vertices, uint64_t n_vertices,
+                       const uint32_t *indices, uint64_t n_indices,
+                       uint64_t material_idx);
+
+/* replaces void Renderer::update_lights(span<PointLight>) (renderer.hpp:120,
+ * renderer.cpp:585-603): clamps to max_lights like the reference clamps to 16. */
+int arctic_update_lights(ArcticRenderer *r, const ArcticPointLight *lights, uint64_t n);
+
+/* replaces bool Renderer::create_hdri(float*,w,h) (renderer.hpp:118).  The
+ * skybox is outside this path: accepted, validated, ignored. */
+int arctic_create_hdri(ArcticRenderer *r, const float *rgba32f, uint32_t w, uint32_t h);
+
+/* ---- frames -------------------------------------------------------------- */
+
+/* replaces bool Renderer::render_frame(const Scene&, const Settings&, build_ui)
+ * (renderer.hpp:106-107, renderer.cpp:274-415) minus skybox/ImGui/present:
+ * shadow-map raster -> visibility/G-buffer prepass -> shading (+fused tonemap)
+ * -> RGBA8.  out_rgba8 is a HOST buffer of (row_end-row_begin)*width*4 bytes,
+ * row-major, top-left origin; NULL = leave the frame on the device. */
+int arctic_render_frame(ArcticRenderer *r, const ArcticScene *scene,
+                        const ArcticSettings *settings, uint8_t *out_rgba8);
+
+/* same, but the RGBA8 shard is written to DEVICE memory the caller owns
+ * (e.g. a torch tensor that RCCL then gathers); stream-ordered on the
+ * handle's stream, call arctic_flush() before another stream reads it. */
+int arctic_render_frame_device(ArcticRenderer *r, const ArcticScene *scene,
+                               const ArcticSettings *settings, void *d_out_rgba8);
+
+/* ---- the passes one by one (bench + parity tests) ------------------------ */
+
+/* ShadowMapPass::run (shadow_map_pass.cpp:113-169, depth.hlsl): light-view
+ * depth-only raster, front faces culled, into the handle's shadow map. */
+int arctic_pass_shadow_map(ArcticRenderer *r, const ArcticScene *scene);
+
+/* ForwardPass::run's vertex + raster work (forward_pass.cpp:161-226,
+ * forward.hlsl:50-66): visibility + G-buffer (the interpolated VSOut). */
+int arctic_pass_gbuffer(ArcticRenderer *r, const ArcticScene *scene);
+
+/* ps_main (forward.hlsl:208-235) + post_process main (post_process.hlsl:59-93)
+ * over the resident G-buffer.  d_out_rgba8 may be NULL (handle's own buffer). */
+int arctic_pass_shade(ArcticRenderer *r, const ArcticScene *scene,
+                      const ArcticSettings *settings, void *d_out_rgba8);
+
+/* PostProcessPass::run alone (post_process_pass.cpp:73-95): tonemap + gamma of
+ * a float RGBA HDR image (host, w*h*4 floats) to RGBA8 (host). */
+int arctic_post_process(ArcticRenderer *r, const float *hdr_rgba32f, uint32_t w, uint32_t h,
+                        const ArcticSettings *settings, uint8_t *out_rgba8, float *out_ldr_rgb);
+
+/* time `iters` back-to-back arctic_pass_shade launches with HIP events on the
+ * handle's stream (after `warmup` untimed ones); ms_each gets iters floats. */
+int arctic_time_shade(ArcticRenderer *r, const ArcticScene *scene, const ArcticSettings *settings,
+                      uint32_t warmup, uint32_t iters, float *ms_each);
+
+/* ---- read-back / injection for tests ------------------------------------- */
+
+/* G-buffer of this shard, de-tiled to row-major: attrs = rows*width*18 floats
+ * in VSOut order (uv2, tbn9 = t,b,n, world3, light_space4; forward.hlsl:41-48),
+ * material = rows*width uint32 (0xFFFFFFFF = no geometry), depth = rows*width
+ * floats (1.0 = clear), tri = rows*width uint32 draw-order id.  Any may be NULL. */
+int arctic_read_gbuffer(ArcticRenderer *r, float *attrs, uint32_t *material, float *depth, uint32_t *tri);
+
+/* inject a G-buffer (same row-major layout) instead of rasterising one */
+int arctic_write_gbuffer(ArcticRenderer *r, const float *attrs, const uint32_t *material);
+
+/* shadow map: shadow_size^2 floats, row-major */
+int arctic_read_shadow_map(ArcticRenderer *r, float *depth);
+int arctic_write_shadow_map(ArcticRenderer *r, const float *depth);
+
+/* outputs of the last shade: float LDR (rows*width*3, after tonemap+gamma,
+ * before the UNORM8 quantisation), float HDR (rows*width*3, ps_main's colour),
+ * RGBA8 (rows*width*4).  Any may be NULL. */
+int arctic_read_output(ArcticRenderer *r, float *ldr_rgb, float *hdr_rgb, uint8_t *rgba8);
+
+/* the per-frame constants the host builds (forward_pass.cpp:166-177 via
+ * scene.cpp:41-70): proj_view[16], light_proj_view[16], sun_dir[3] */
+int arctic_frame_constants(const ArcticScene *scene, float *proj_view, float *light_proj_view, float *sun_dir);
+
+/* counters of the last frame: [0] setup triangles (forward), [1] raster work
+ * items (forward), [2] setup triangles (shadow), [3] raster work items
+ * (shadow), [4] shaded (covered) pixels, [5] point-light evaluations summed
+ * over pixels (only when stats were requested with arctic_set_option). */
+int arctic_stats(ArcticRenderer *r, uint64_t *out, uint32_t n);
+
+/* tuning / debug switches. */
+#define ARCTIC_OPT_KEEP_FLOAT_OUTPUT 1 /* 1 = shade also stores float LDR+HDR planes (tests); 0 = RGBA8 only (bench) */
+#define ARCTIC_OPT_COUNT_LIGHT_EVALS 2 /* 1 = shade counts evaluated lights per pixel (slower) */
+#define ARCTIC_OPT_CULLING           3 /* 0 = evaluate every light for every pixel; 1 = exact wave-level culling (default) */
+int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value);
+
+/* library/ABI version: major*10000 + minor*100 + patch */
+int arctic_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARCTIC_HIP_H */
