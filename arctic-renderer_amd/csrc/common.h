@@ -1,0 +1,137 @@
+// common.h -- internal types shared by the host side (renderer.cpp) and the HIP kernels.
+// Not part of the C-ABI (that is include/arctic_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace arctic {
+
+// ---- data layout in HBM ----------------------------------------------------------------------
+// Screen: tiles of 8x8 pixels, one tile = one wavefront (64 lanes); lane l <-> pixel (l & 7, l >> 3).
+// Every per-pixel plane (visibility, G-buffer) is TILE-MAJOR: element (tile, lane) at tile*64 + lane,
+// tile = ty * tiles_x + tx (ty counted from the first tile row of the row shard), so a wave-wide
+// load of a float4 plane is one contiguous 1 KiB run.  The RGBA8 frame handed to the caller is
+// row-major.
+constexpr int TILE = 8;
+constexpr int TILE_PIXELS = 64;
+constexpr uint32_t NO_MATERIAL = 0xFFFFFFFFu;
+
+// G-buffer = the interpolated VSOut (forward.hlsl:41-48) minus SV_POSITION, 76 B / pixel:
+//   p0 float4  world.xyz, material id (bits)
+//   p1 float4  light_space_position.xyzw
+//   p2 float4  uv.xy, t.xy
+//   p3 float4  t.z, b.xyz
+//   p4 float3  n.xyz            (12-byte stride)
+struct GBuffer {
+    float4 *p0, *p1, *p2, *p3;
+    float *p4;
+};
+
+// transformed vertex (the reference's VSOut), 96 B
+struct XVert {
+    float clip[4];
+    float attr[18];  // uv2, t3, b3, n3, world3, light4
+    float pad[2];
+};
+
+// per-object record uploaded every frame (Scene.objects flattened, scene.hpp:69-73 + the mesh it points to)
+struct ObjectRec {
+    float trs[16];            // model matrix, glm column-major
+    const float *vertices;    // ArcticVertex[] as 14 floats each
+    const uint32_t *indices;
+    uint32_t n_vertices, n_triangles;
+    uint32_t first_xvert;     // offset of this object's vertices in the transformed-vertex buffer
+    uint32_t first_triangle;  // draw-order id of this object's first triangle
+    uint32_t material;
+    uint32_t pad;
+};
+
+// one rasterisable (clipped, culled, oriented) triangle, 128 B
+struct SetupRec {
+    int32_t X[3], Y[3];   // 24.8 fixed point, oriented so area2 > 0
+    float z[3], iw[3];    // z/w, 1/w
+    float bary[3][3];     // vertex k of this triangle as a combination of the source triangle's vertices
+    int64_t area2;
+    int32_t px0, py0, px1, py1;  // inclusive pixel bounds (scissored)
+    uint32_t src_tri, object;
+    uint32_t pad[2];
+};
+static_assert(sizeof(SetupRec) == 128, "SetupRec layout");
+
+// frame constants for the geometry kernels
+struct GeomParams {
+    float clip_from_world[16];   // proj_view (forward) or light_proj_view (shadow)
+    float light_from_world[16];  // light_proj_view
+    float vp_w, vp_h;            // viewport size in pixels
+    int32_t sc_x0, sc_y0, sc_x1, sc_y1;  // scissor (exclusive upper)
+    int32_t cull_front;          // 0: cull back faces (forward pass), 1: cull front faces (shadow pass)
+    int32_t tiles_x;             // tile columns of the target
+    int32_t tile_y0;             // first tile row stored (row shard); 0 for the shadow map
+    int32_t pitch;               // shadow pass: row pitch of the row-major depth map (= S)
+};
+
+// texture descriptor, 16 B; three consecutive per material: diffuse (sRGB), normal, metal-rough
+struct TexDesc {
+    const uint32_t *texels;  // RGBA8 little endian (r = low byte), row-major, tightly packed
+    uint32_t w, h;
+};
+
+// point light as uploaded (scene.hpp:88-94): float3 pos, pad, float3 color, pad = 2 x float4
+struct ShadeParams {
+    GBuffer g;
+    const TexDesc *tex;          // 3 * n_materials
+    uint32_t n_materials;
+    const float *srgb_lut;       // 256 floats, sRGB8 -> linear
+    const float *shadow_map;     // S*S floats row-major, or null
+    uint32_t shadow_size;
+    const float4 *lights;        // 2 float4 per light
+    uint32_t n_lights;
+    float eye[3];
+    float sun_dir[3];
+    float sun_color[3];
+    float ambient;
+    int32_t tm_method;
+    float inv_gamma;
+    float exposure;
+    uint32_t width;              // frame width in pixels
+    uint32_t rows;               // rows of this shard
+    uint32_t row0_in_tile;       // row_begin - tile_y0*8: offset of the shard's first row inside its first tile row
+    uint32_t tiles_x, tiles_y;   // tile grid of the shard
+    uint8_t *out_rgba8;          // rows*width*4, row-major
+    float *out_ldr;              // optional rows*width*3
+    float *out_hdr;              // optional rows*width*3
+    unsigned long long *light_evals;  // optional counter
+    int32_t culling;
+};
+
+// ---- kernel launchers (geometry.hip, shade.hip) ---------------------------------------------
+// every launcher enqueues on `s` and returns the launch error, never synchronises.
+hipError_t launch_vertex(const ObjectRec *objs, const uint32_t *block_obj, const uint32_t *block_first,
+                         uint32_t n_blocks, const GeomParams *gp, XVert *xv, int clip_only, hipStream_t s);
+hipError_t launch_setup(const ObjectRec *objs, const uint32_t *block_obj, const uint32_t *block_first,
+                        uint32_t n_blocks, const GeomParams *gp, const XVert *xv,
+                        const uint32_t *sub_offset /*null: count pass*/, uint32_t *sub_count,
+                        SetupRec *recs, uint32_t *tile_count, hipStream_t s);
+hipError_t launch_scan(const uint32_t *in, uint32_t *out /*n+1, exclusive*/, uint32_t n, uint32_t *scratch, hipStream_t s);
+uint32_t scan_scratch_elems(uint32_t n);
+hipError_t launch_raster_vis(const SetupRec *recs, const uint32_t *tile_offset, uint32_t n_recs, uint32_t n_items,
+                             const GeomParams *gp, unsigned long long *vis, hipStream_t s);
+hipError_t launch_raster_depth(const SetupRec *recs, const uint32_t *tile_offset, uint32_t n_recs, uint32_t n_items,
+                               const GeomParams *gp, uint32_t *depth_bits, hipStream_t s);
+hipError_t launch_resolve(const unsigned long long *vis, const SetupRec *recs, const ObjectRec *objs, const XVert *xv,
+                          const GeomParams *gp, uint32_t n_tiles, GBuffer g, float *depth_out, uint32_t *src_out, hipStream_t s);
+hipError_t launch_fill_u64(unsigned long long *p, unsigned long long v, size_t n, hipStream_t s);
+hipError_t launch_fill_u32(uint32_t *p, uint32_t v, size_t n, hipStream_t s);
+hipError_t launch_shade(const ShadeParams &sp, hipStream_t s);
+hipError_t launch_post_process(const float4 *hdr, uint32_t w, uint32_t h, int32_t tm, float inv_gamma, float exposure,
+                               uint8_t *rgba8, float *ldr, hipStream_t s);
+hipError_t launch_gbuffer_tile(GBuffer g, float *attrs, uint32_t *mat, uint32_t width, uint32_t rows,
+                               uint32_t row0_in_tile, uint32_t tiles_x, uint32_t tiles_y, int to_tiled, hipStream_t s);
+
+// ---- host math (host_math.cpp): glm-equivalent builders, scene.cpp:9-19,41-70 ----------------
+void dir_from_rot(const float rot_deg[2], float out[3]);
+void camera_proj_view(const float eye[3], const float rot_deg[2], float aspect, float fov_y_deg, float zn, float zf, float out[16]);
+void sun_proj_view(const float pos[3], const float rot_deg[2], float out[16]);
+float srgb8_to_linear(int c);
+
+}  // namespace arctic

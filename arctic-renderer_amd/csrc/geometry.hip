@@ -1,0 +1,515 @@
+// geometry.hip -- visibility / G-buffer prepass and shadow-map raster for gfx950.
+//
+// Replaces what D3D12's fixed-function pipeline does for the reference around
+// shaders/forward.hlsl:50-66 (vs_main) and shaders/depth.hlsl:7-10: vertex
+// transform, clipping, back/front-face culling, rasterisation with the D3D
+// rules (pixel centres at +0.5, 8 sub-pixel bits, top-left fill rule, depth
+// LESS with first-drawn-wins ties: forward_pass.cpp:137-151,
+// shadow_map_pass.cpp:96-97) and perspective-correct interpolation of the 18
+// VSOut floats -- written out as the G-buffer instead of feeding a pixel shader.
+//
+// MI355X design: one launch per stage over ALL objects (no per-draw loop);
+//   vertex  : 1 thread / vertex                         -> XVert[]            (coalesced 96 B records)
+//   setup   : 1 thread / triangle, count then emit      -> SetupRec[] compacted in draw order
+//   raster  : 1 wavefront / (triangle, 8x8 tile), 1 lane / pixel, 64-bit atomicMin of
+//             (depth bits << 32 | draw-order id) into a tile-major visibility plane:
+//             order-independent, so no sorting and no per-pixel locks
+//   resolve : 1 lane / pixel: fetch the winner, re-derive its barycentrics from the same integer
+//             edge functions, interpolate, write the tile-major G-buffer planes (1 KiB / wave-store)
+// The shadow map uses the same stages with a 32-bit atomicMin on the depth bits.
+//
+// This translation unit is compiled with -ffp-contract=off: coverage is integer and every fp32
+// operation rounds once, in a fixed order, so visibility and G-buffer are bit-reproducible
+// (the parity tests require bit equality with the CPU oracle).  fmaf() only where written.
+#include "common.h"
+
+namespace arctic {
+
+namespace {
+
+constexpr float GUARD = 64.0f;  // guard band |x|,|y| <= GUARD*w keeps 24.8 coordinates inside int32
+constexpr int MAX_POLY = 10;
+
+struct CV {  // clip-space vertex carried through the clipper
+    float x, y, z, w;
+    float b0, b1, b2;  // barycentrics w.r.t. the source triangle
+};
+
+__device__ __forceinline__ float plane_dist(const CV &v, int plane) {
+    switch (plane) {
+    case 0: return v.z;
+    case 1: return v.w - v.z;
+    case 2: return v.x + GUARD * v.w;
+    case 3: return GUARD * v.w - v.x;
+    case 4: return v.y + GUARD * v.w;
+    default: return GUARD * v.w - v.y;
+    }
+}
+
+// intersection from the inside vertex towards the outside vertex
+__device__ __forceinline__ CV clip_lerp(const CV &in, const CV &out, float din, float dout) {
+    float t = din / (din - dout);
+    CV r;
+    r.x = fmaf(t, out.x - in.x, in.x);
+    r.y = fmaf(t, out.y - in.y, in.y);
+    r.z = fmaf(t, out.z - in.z, in.z);
+    r.w = fmaf(t, out.w - in.w, in.w);
+    r.b0 = fmaf(t, out.b0 - in.b0, in.b0);
+    r.b1 = fmaf(t, out.b1 - in.b1, in.b1);
+    r.b2 = fmaf(t, out.b2 - in.b2, in.b2);
+    return r;
+}
+
+// Sutherland-Hodgman against near, far and the four guard-band planes
+__device__ int clip_polygon(CV *poly, int n) {
+    CV tmp[MAX_POLY];
+    for (int plane = 0; plane < 6; ++plane) {
+        float d[MAX_POLY];
+        bool all_in = true, any_in = false;
+        for (int i = 0; i < n; ++i) {
+            d[i] = plane_dist(poly[i], plane);
+            if (d[i] >= 0.0f) any_in = true; else all_in = false;
+        }
+        if (all_in) continue;
+        if (!any_in) return 0;
+        int m = 0;
+        for (int i = 0; i < n; ++i) {
+            int j = (i + 1 == n) ? 0 : i + 1;
+            bool in_i = d[i] >= 0.0f, in_j = d[j] >= 0.0f;
+            if (in_i) tmp[m++] = poly[i];
+            if (in_i != in_j) tmp[m++] = in_i ? clip_lerp(poly[i], poly[j], d[i], d[j]) : clip_lerp(poly[j], poly[i], d[j], d[i]);
+        }
+        n = m;
+        for (int i = 0; i < n; ++i) poly[i] = tmp[i];
+        if (n < 3) return 0;
+    }
+    return n;
+}
+
+__device__ __forceinline__ int32_t snap(float s) { return (int32_t)floorf(s * 256.0f + 0.5f); }
+
+// viewport transform, snapping, culling, orientation, pixel bounds.  false = nothing to rasterise.
+__device__ bool setup_triangle(const CV &a, const CV &b, const CV &c, const GeomParams &gp, SetupRec &t) {
+    const CV *v[3] = {&a, &b, &c};
+    float hx = 0.5f * gp.vp_w, hy = 0.5f * gp.vp_h;
+    int32_t X[3], Y[3];
+    float z[3], iw[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (!(v[i]->w > 0.0f)) return false;
+        iw[i] = 1.0f / v[i]->w;
+        float nx = v[i]->x * iw[i], ny = v[i]->y * iw[i];
+        z[i] = v[i]->z * iw[i];
+        X[i] = snap((nx + 1.0f) * hx);   // D3D viewport: X = (x+1) * W/2
+        Y[i] = snap((1.0f - ny) * hy);   //               Y = (1-y) * H/2
+    }
+    int64_t area2 = (int64_t)(X[1] - X[0]) * (int64_t)(Y[2] - Y[0]) - (int64_t)(X[2] - X[0]) * (int64_t)(Y[1] - Y[0]);
+    if (area2 == 0) return false;
+    // y-down: area2 > 0 <=> clockwise as seen; front = counter-clockwise (FrontCounterClockwise = TRUE)
+    bool front = area2 < 0;
+    if (gp.cull_front ? front : !front) return false;
+    int i1 = 1, i2 = 2;
+    if (area2 < 0) { i1 = 2; i2 = 1; area2 = -area2; }
+    const int o[3] = {0, i1, i2};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        int k = o[i];
+        t.X[i] = X[k]; t.Y[i] = Y[k]; t.z[i] = z[k]; t.iw[i] = iw[k];
+        t.bary[i][0] = v[k]->b0; t.bary[i][1] = v[k]->b1; t.bary[i][2] = v[k]->b2;
+    }
+    t.area2 = area2;
+    int32_t xmin = min(X[0], min(X[1], X[2])), xmax = max(X[0], max(X[1], X[2]));
+    int32_t ymin = min(Y[0], min(Y[1], Y[2])), ymax = max(Y[0], max(Y[1], Y[2]));
+    t.px0 = max((xmin - 128 + 255) >> 8, gp.sc_x0);
+    t.px1 = min((xmax - 128) >> 8, gp.sc_x1 - 1);
+    t.py0 = max((ymin - 128 + 255) >> 8, gp.sc_y0);
+    t.py1 = min((ymax - 128) >> 8, gp.sc_y1 - 1);
+    return t.px0 <= t.px1 && t.py0 <= t.py1;
+}
+
+__device__ __forceinline__ uint32_t tiles_of(const SetupRec &t) {
+    return (uint32_t)((t.px1 >> 3) - (t.px0 >> 3) + 1) * (uint32_t)((t.py1 >> 3) - (t.py0 >> 3) + 1);
+}
+
+// edge i: vertex i -> vertex (i+1)%3, inside-positive; bias implements the top-left rule
+struct Edges {
+    int64_t dx[3], dy[3];
+    int32_t x0[3], y0[3];
+    int64_t bias[3];
+};
+__device__ __forceinline__ void make_edges(const SetupRec &t, Edges &e) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        int j = (i + 1) % 3;
+        e.dx[i] = (int64_t)t.X[j] - t.X[i];
+        e.dy[i] = (int64_t)t.Y[j] - t.Y[i];
+        e.x0[i] = t.X[i]; e.y0[i] = t.Y[i];
+        bool top_left = (e.dy[i] == 0 && e.dx[i] > 0) || (e.dy[i] < 0);
+        e.bias[i] = top_left ? 0 : -1;
+    }
+}
+__device__ __forceinline__ int64_t edge_eval(const Edges &e, int i, int32_t px, int32_t py) {
+    int64_t Px = (int64_t)px * 256 + 128, Py = (int64_t)py * 256 + 128;
+    return e.dx[i] * (Py - e.y0[i]) - e.dy[i] * (Px - e.x0[i]);
+}
+// coverage + barycentrics (l1, l2) + clamped depth
+__device__ __forceinline__ bool fragment(const SetupRec &t, const Edges &e, float inv_area, int32_t px, int32_t py,
+                                         float &l1, float &l2, float &z) {
+    int64_t e0 = edge_eval(e, 0, px, py), e1 = edge_eval(e, 1, px, py), e2 = edge_eval(e, 2, px, py);
+    if ((e0 + e.bias[0]) < 0 || (e1 + e.bias[1]) < 0 || (e2 + e.bias[2]) < 0) return false;
+    l1 = (float)e2 * inv_area;
+    l2 = (float)e0 * inv_area;
+    z = fmaf(l2, t.z[2] - t.z[0], fmaf(l1, t.z[1] - t.z[0], t.z[0]));
+    z = fminf(fmaxf(z, 0.0f), 1.0f);
+    return true;
+}
+
+// HLSL mul(M, v) with M column-major: row i = ((m0i*x + m1i*y) + m2i*z) + m3i*w
+__device__ __forceinline__ void mat_vec(const float *m, float x, float y, float z, float w, float *o) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = ((m[i] * x + m[4 + i] * y) + m[8 + i] * z) + m[12 + i] * w;
+}
+__device__ __forceinline__ void normalize3(const float *v, float *o) {
+    float inv = 1.0f / sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+    o[0] = v[0] * inv; o[1] = v[1] * inv; o[2] = v[2] * inv;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward.hlsl:50-66 vs_main for every vertex of every object in one launch
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_vertex(const ObjectRec *__restrict__ objs, const uint32_t *__restrict__ block_obj,
+                                                const uint32_t *__restrict__ block_first, const GeomParams *__restrict__ gpp,
+                                                XVert *__restrict__ xv, int clip_only) {
+    const ObjectRec &ob = objs[block_obj[blockIdx.x]];
+    uint32_t vi = block_first[blockIdx.x] + threadIdx.x;
+    if (vi >= ob.n_vertices) return;
+    const float *src = ob.vertices + (size_t)vi * 14;
+    float world[4];
+    mat_vec(ob.trs, src[0], src[1], src[2], 1.0f, world);
+    XVert &o = xv[ob.first_xvert + vi];
+    float clip[4];
+    mat_vec(gpp->clip_from_world, world[0], world[1], world[2], world[3], clip);
+    o.clip[0] = clip[0]; o.clip[1] = clip[1]; o.clip[2] = clip[2]; o.clip[3] = clip[3];
+    if (clip_only) return;   // depth.hlsl:7-10
+    float t[3], b[3], n[3], ls[4];
+    normalize3(src + 6, t);
+    normalize3(src + 3, n);
+    normalize3(src + 9, b);
+    mat_vec(gpp->light_from_world, world[0], world[1], world[2], world[3], ls);
+    o.attr[0] = src[12]; o.attr[1] = src[13];
+    o.attr[2] = t[0]; o.attr[3] = t[1]; o.attr[4] = t[2];
+    o.attr[5] = b[0]; o.attr[6] = b[1]; o.attr[7] = b[2];
+    o.attr[8] = n[0]; o.attr[9] = n[1]; o.attr[10] = n[2];
+    o.attr[11] = world[0]; o.attr[12] = world[1]; o.attr[13] = world[2];
+    o.attr[14] = ls[0]; o.attr[15] = ls[1]; o.attr[16] = ls[2]; o.attr[17] = ls[3];
+}
+
+// ---------------------------------------------------------------------------------------------
+// clip + setup, one thread per source triangle.  Pass 1 (sub_offset == null) counts the triangles
+// each source triangle produces; after an exclusive scan pass 2 writes them compacted, in draw
+// order, together with the number of 8x8 tiles each one touches.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_setup(const ObjectRec *__restrict__ objs, const uint32_t *__restrict__ block_obj,
+                                               const uint32_t *__restrict__ block_first, const GeomParams *__restrict__ gpp,
+                                               const XVert *__restrict__ xv, const uint32_t *__restrict__ sub_offset,
+                                               uint32_t *__restrict__ sub_count, SetupRec *__restrict__ recs,
+                                               uint32_t *__restrict__ tile_count) {
+    uint32_t oi = block_obj[blockIdx.x];
+    const ObjectRec &ob = objs[oi];
+    uint32_t ti = block_first[blockIdx.x] + threadIdx.x;
+    if (ti >= ob.n_triangles) return;
+    const GeomParams gp = *gpp;
+    uint32_t src = ob.first_triangle + ti;
+    uint32_t idx[3] = {ob.indices[3 * ti], ob.indices[3 * ti + 1], ob.indices[3 * ti + 2]};
+    uint32_t produced = 0;
+    uint32_t out = sub_offset ? sub_offset[src] : 0;
+    if (idx[0] < ob.n_vertices && idx[1] < ob.n_vertices && idx[2] < ob.n_vertices) {
+        CV poly[MAX_POLY];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float *c = xv[ob.first_xvert + idx[k]].clip;
+            poly[k].x = c[0]; poly[k].y = c[1]; poly[k].z = c[2]; poly[k].w = c[3];
+            poly[k].b0 = k == 0 ? 1.0f : 0.0f; poly[k].b1 = k == 1 ? 1.0f : 0.0f; poly[k].b2 = k == 2 ? 1.0f : 0.0f;
+        }
+        bool inside = true;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int p = 0; p < 6; ++p) inside = inside && (plane_dist(poly[k], p) >= 0.0f);
+        int n = inside ? 3 : clip_polygon(poly, 3);
+        for (int f = 1; f + 1 < n; ++f) {
+            SetupRec t;
+            if (!setup_triangle(poly[0], poly[f], poly[f + 1], gp, t)) continue;
+            if (sub_offset) {
+                t.src_tri = src; t.object = oi; t.pad[0] = 0; t.pad[1] = 0;
+                recs[out + produced] = t;
+                tile_count[out + produced] = tiles_of(t);
+            }
+            ++produced;
+        }
+    }
+    if (!sub_offset) sub_count[src] = produced;
+}
+
+// ---------------------------------------------------------------------------------------------
+// exclusive prefix sum (out has n+1 entries; out[n] = total): 1024 elements per block
+// ---------------------------------------------------------------------------------------------
+constexpr int SCAN_BLOCK = 256, SCAN_PER_THREAD = 4, SCAN_ELEMS = SCAN_BLOCK * SCAN_PER_THREAD;
+
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_block(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+                                                           uint32_t n, uint32_t *__restrict__ block_sums) {
+    __shared__ uint32_t wave_sums[SCAN_BLOCK / 64];
+    uint32_t base = blockIdx.x * SCAN_ELEMS + threadIdx.x * SCAN_PER_THREAD;
+    uint32_t v[SCAN_PER_THREAD], sum = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; ++k) { v[k] = (base + k < n) ? in[base + k] : 0; sum += v[k]; }
+    uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(incl, d); if (lane >= (uint32_t)d) incl += y; }
+    if (lane == 63) wave_sums[wave] = incl;
+    __syncthreads();
+    uint32_t wave_base = 0;
+    for (uint32_t w = 0; w < wave; ++w) wave_base += wave_sums[w];
+    uint32_t run = wave_base + incl - sum;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; ++k) { if (base + k < n) out[base + k] = run; run += v[k]; }
+    if (threadIdx.x == SCAN_BLOCK - 1) block_sums[blockIdx.x] = wave_base + incl;
+}
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_add(uint32_t *__restrict__ out, uint32_t n, const uint32_t *__restrict__ block_offsets,
+                                                         uint32_t n_blocks) {
+    uint32_t add = block_offsets[blockIdx.x];
+    uint32_t base = blockIdx.x * SCAN_ELEMS + threadIdx.x * SCAN_PER_THREAD;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; ++k) if (base + k < n) out[base + k] += add;
+    if (blockIdx.x == n_blocks - 1 && threadIdx.x == 0) out[n] = block_offsets[n_blocks];   // grand total
+}
+__global__ void k_scan_total1(uint32_t *out, uint32_t n, const uint32_t *block_sums) { out[n] = block_sums[0]; }
+
+// ---------------------------------------------------------------------------------------------
+// raster: one wavefront per (triangle, 8x8 tile) work item, one lane per pixel
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t find_record(const uint32_t *__restrict__ tile_offset, uint32_t n_recs, uint32_t item) {
+    uint32_t lo = 0, hi = n_recs;   // invariant: tile_offset[lo] <= item < tile_offset[hi]
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (tile_offset[mid] <= item) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+template <bool DEPTH_ONLY>
+__global__ __launch_bounds__(256) void k_raster(const SetupRec *__restrict__ recs, const uint32_t *__restrict__ tile_offset,
+                                                uint32_t n_recs, uint32_t n_items, const GeomParams *__restrict__ gpp,
+                                                unsigned long long *__restrict__ vis, uint32_t *__restrict__ depth_bits) {
+    uint32_t item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= n_items) return;
+    uint32_t lane = threadIdx.x & 63;
+    uint32_t r = find_record(tile_offset, n_recs, item);
+    r = __builtin_amdgcn_readfirstlane(r);
+    const SetupRec &t = recs[r];
+    uint32_t local = item - tile_offset[r];
+    int32_t tx0 = t.px0 >> 3, ty0 = t.py0 >> 3;
+    uint32_t ntx = (uint32_t)((t.px1 >> 3) - tx0 + 1);
+    int32_t tx = tx0 + (int32_t)(local % ntx), ty = ty0 + (int32_t)(local / ntx);
+    int32_t px = tx * 8 + (int32_t)(lane & 7), py = ty * 8 + (int32_t)(lane >> 3);
+    if (px < t.px0 || px > t.px1 || py < t.py0 || py > t.py1) return;
+    Edges e;
+    make_edges(t, e);
+    float inv_area = 1.0f / (float)t.area2;
+    float l1, l2, z;
+    if (!fragment(t, e, inv_area, px, py, l1, l2, z)) return;
+    if (!(z < 1.0f)) return;   // depth LESS against the 1.0 clear
+    if (DEPTH_ONLY) {
+        uint32_t *p = depth_bits + (size_t)py * gpp->pitch + px;
+        uint32_t zb = __float_as_uint(z);
+        if (zb < *p) atomicMin(p, zb);
+    } else {
+        size_t idx = ((size_t)(ty - gpp->tile_y0) * gpp->tiles_x + tx) * 64 + lane;
+        unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | r;   // ties: first drawn (smallest id) wins
+        if (key < vis[idx]) atomicMin(&vis[idx], key);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// resolve: visibility -> interpolated attributes, tile-major G-buffer
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resolve(const unsigned long long *__restrict__ vis, const SetupRec *__restrict__ recs,
+                                                 const ObjectRec *__restrict__ objs, const XVert *__restrict__ xv,
+                                                 const GeomParams *__restrict__ gpp, uint32_t n_tiles, GBuffer g,
+                                                 float *__restrict__ depth_out, uint32_t *__restrict__ src_out) {
+    uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= n_tiles) return;
+    uint32_t lane = threadIdx.x & 63;
+    size_t idx = (size_t)tile * 64 + lane;
+    unsigned long long key = vis[idx];
+    float a[18];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) a[k] = 0.0f;
+    uint32_t mat = NO_MATERIAL, src = 0xFFFFFFFFu;
+    float depth = 1.0f;
+    if (key != ~0ull) {
+        const SetupRec &t = recs[(uint32_t)key];
+        depth = __uint_as_float((uint32_t)(key >> 32));
+        int32_t tx = (int32_t)(tile % (uint32_t)gpp->tiles_x), ty = (int32_t)(tile / (uint32_t)gpp->tiles_x) + gpp->tile_y0;
+        int32_t px = tx * 8 + (int32_t)(lane & 7), py = ty * 8 + (int32_t)(lane >> 3);
+        Edges e;
+        make_edges(t, e);
+        float inv_area = 1.0f / (float)t.area2;
+        float l1 = (float)edge_eval(e, 2, px, py) * inv_area;
+        float l2 = (float)edge_eval(e, 0, px, py) * inv_area;
+        float l0 = (1.0f - l1) - l2;
+        float pw0 = l0 * t.iw[0], pw1 = l1 * t.iw[1], pw2 = l2 * t.iw[2];
+        float rr = 1.0f / ((pw0 + pw1) + pw2);
+        float b0 = pw0 * rr, b1 = pw1 * rr, b2 = pw2 * rr;
+        float B[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) B[k] = (b0 * t.bary[0][k] + b1 * t.bary[1][k]) + b2 * t.bary[2][k];
+        const ObjectRec &ob = objs[t.object];
+        uint32_t lt = t.src_tri - ob.first_triangle;
+        const float *A0 = xv[ob.first_xvert + ob.indices[3 * lt]].attr;
+        const float *A1 = xv[ob.first_xvert + ob.indices[3 * lt + 1]].attr;
+        const float *A2 = xv[ob.first_xvert + ob.indices[3 * lt + 2]].attr;
+#pragma unroll
+        for (int k = 0; k < 18; ++k) a[k] = (B[0] * A0[k] + B[1] * A1[k]) + B[2] * A2[k];
+        mat = ob.material;
+        src = t.src_tri;
+    }
+    g.p0[idx] = make_float4(a[11], a[12], a[13], __uint_as_float(mat));
+    g.p1[idx] = make_float4(a[14], a[15], a[16], a[17]);
+    g.p2[idx] = make_float4(a[0], a[1], a[2], a[3]);
+    g.p3[idx] = make_float4(a[4], a[5], a[6], a[7]);
+    g.p4[idx * 3] = a[8]; g.p4[idx * 3 + 1] = a[9]; g.p4[idx * 3 + 2] = a[10];
+    if (depth_out) depth_out[idx] = depth;
+    if (src_out) src_out[idx] = src;
+}
+
+// ---------------------------------------------------------------------------------------------
+// helpers: fills; row-major <-> tile-major G-buffer conversion for the read/write test entry points
+// ---------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void k_fill(T *p, T v, size_t n) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+    for (; i < n; i += stride) p[i] = v;
+}
+
+__global__ __launch_bounds__(256) void k_gbuffer_tile(GBuffer g, float *attrs, uint32_t *mat, uint32_t width, uint32_t rows,
+                                                      uint32_t row0_in_tile, uint32_t tiles_x, uint32_t tiles_y, int to_tiled) {
+    uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= tiles_x * tiles_y) return;
+    uint32_t lane = threadIdx.x & 63;
+    uint32_t x = (tile % tiles_x) * 8 + (lane & 7);
+    int32_t y = (int32_t)((tile / tiles_x) * 8 + (lane >> 3)) - (int32_t)row0_in_tile;   // row inside the shard
+    size_t idx = (size_t)tile * 64 + lane;
+    bool in = x < width && y >= 0 && y < (int32_t)rows;
+    if (to_tiled) {
+        float a[18];
+        uint32_t m = NO_MATERIAL;
+#pragma unroll
+        for (int k = 0; k < 18; ++k) a[k] = 0.0f;
+        if (in) {
+            size_t p = (size_t)y * width + x;
+#pragma unroll
+            for (int k = 0; k < 18; ++k) a[k] = attrs[p * 18 + k];
+            m = mat[p];
+        }
+        g.p0[idx] = make_float4(a[11], a[12], a[13], __uint_as_float(m));
+        g.p1[idx] = make_float4(a[14], a[15], a[16], a[17]);
+        g.p2[idx] = make_float4(a[0], a[1], a[2], a[3]);
+        g.p3[idx] = make_float4(a[4], a[5], a[6], a[7]);
+        g.p4[idx * 3] = a[8]; g.p4[idx * 3 + 1] = a[9]; g.p4[idx * 3 + 2] = a[10];
+    } else if (in) {
+        size_t p = (size_t)y * width + x;
+        float4 q0 = g.p0[idx], q1 = g.p1[idx], q2 = g.p2[idx], q3 = g.p3[idx];
+        if (attrs) {
+            float *a = attrs + p * 18;
+            a[0] = q2.x; a[1] = q2.y; a[2] = q2.z; a[3] = q2.w;
+            a[4] = q3.x; a[5] = q3.y; a[6] = q3.z; a[7] = q3.w;
+            a[8] = g.p4[idx * 3]; a[9] = g.p4[idx * 3 + 1]; a[10] = g.p4[idx * 3 + 2];
+            a[11] = q0.x; a[12] = q0.y; a[13] = q0.z;
+            a[14] = q1.x; a[15] = q1.y; a[16] = q1.z; a[17] = q1.w;
+        }
+        if (mat) mat[p] = __float_as_uint(q0.w);
+    }
+}
+
+inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+}  // namespace
+
+hipError_t launch_vertex(const ObjectRec *objs, const uint32_t *block_obj, const uint32_t *block_first, uint32_t n_blocks,
+                         const GeomParams *gp, XVert *xv, int clip_only, hipStream_t s) {
+    if (n_blocks == 0) return hipSuccess;
+    k_vertex<<<n_blocks, 256, 0, s>>>(objs, block_obj, block_first, gp, xv, clip_only);
+    return hipGetLastError();
+}
+
+hipError_t launch_setup(const ObjectRec *objs, const uint32_t *block_obj, const uint32_t *block_first, uint32_t n_blocks,
+                        const GeomParams *gp, const XVert *xv, const uint32_t *sub_offset, uint32_t *sub_count,
+                        SetupRec *recs, uint32_t *tile_count, hipStream_t s) {
+    if (n_blocks == 0) return hipSuccess;
+    k_setup<<<n_blocks, 256, 0, s>>>(objs, block_obj, block_first, gp, xv, sub_offset, sub_count, recs, tile_count);
+    return hipGetLastError();
+}
+
+uint32_t scan_scratch_elems(uint32_t n) {
+    // block sums of every level, each level followed by its own scanned copy (+1 for the total)
+    uint32_t total = 0;
+    while (n > 1) { n = div_up(n, SCAN_ELEMS); total += 2 * n + 2; if (n == 1) break; }
+    return total + 4;
+}
+
+hipError_t launch_scan(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *scratch, hipStream_t s) {
+    if (n == 0) return hipMemsetAsync(out, 0, sizeof(uint32_t), s);
+    uint32_t nb = div_up(n, SCAN_ELEMS);
+    uint32_t *sums = scratch, *sums_scanned = scratch + nb;   // sums_scanned has nb+1 entries
+    k_scan_block<<<nb, SCAN_BLOCK, 0, s>>>(in, out, n, sums);
+    if (nb == 1) {
+        k_scan_total1<<<1, 1, 0, s>>>(out, n, sums);
+        return hipGetLastError();
+    }
+    hipError_t e = launch_scan(sums, sums_scanned, nb, scratch + 2 * nb + 1, s);
+    if (e != hipSuccess) return e;
+    k_scan_add<<<nb, SCAN_BLOCK, 0, s>>>(out, n, sums_scanned, nb);
+    return hipGetLastError();
+}
+
+hipError_t launch_raster_vis(const SetupRec *recs, const uint32_t *tile_offset, uint32_t n_recs, uint32_t n_items,
+                             const GeomParams *gp, unsigned long long *vis, hipStream_t s) {
+    if (n_items == 0) return hipSuccess;
+    k_raster<false><<<div_up(n_items, 4), 256, 0, s>>>(recs, tile_offset, n_recs, n_items, gp, vis, nullptr);
+    return hipGetLastError();
+}
+
+hipError_t launch_raster_depth(const SetupRec *recs, const uint32_t *tile_offset, uint32_t n_recs, uint32_t n_items,
+                               const GeomParams *gp, uint32_t *depth_bits, hipStream_t s) {
+    if (n_items == 0) return hipSuccess;
+    k_raster<true><<<div_up(n_items, 4), 256, 0, s>>>(recs, tile_offset, n_recs, n_items, gp, nullptr, depth_bits);
+    return hipGetLastError();
+}
+
+hipError_t launch_resolve(const unsigned long long *vis, const SetupRec *recs, const ObjectRec *objs, const XVert *xv,
+                          const GeomParams *gp, uint32_t n_tiles, GBuffer g, float *depth_out, uint32_t *src_out, hipStream_t s) {
+    if (n_tiles == 0) return hipSuccess;
+    k_resolve<<<div_up(n_tiles, 4), 256, 0, s>>>(vis, recs, objs, xv, gp, n_tiles, g, depth_out, src_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_u64(unsigned long long *p, unsigned long long v, size_t n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    k_fill<unsigned long long><<<(unsigned)std::min<size_t>((n + 255) / 256, 2048), 256, 0, s>>>(p, v, n);
+    return hipGetLastError();
+}
+hipError_t launch_fill_u32(uint32_t *p, uint32_t v, size_t n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    k_fill<uint32_t><<<(unsigned)std::min<size_t>((n + 255) / 256, 2048), 256, 0, s>>>(p, v, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_gbuffer_tile(GBuffer g, float *attrs, uint32_t *mat, uint32_t width, uint32_t rows, uint32_t row0_in_tile,
+                               uint32_t tiles_x, uint32_t tiles_y, int to_tiled, hipStream_t s) {
+    k_gbuffer_tile<<<div_up(tiles_x * tiles_y, 4), 256, 0, s>>>(g, attrs, mat, width, rows, row0_in_tile, tiles_x, tiles_y, to_tiled);
+    return hipGetLastError();
+}
+
+}  // namespace arctic

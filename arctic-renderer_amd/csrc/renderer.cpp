@@ -1,0 +1,627 @@
+// renderer.cpp -- the C-ABI of include/arctic_hip.h: resource ownership + frame graph on one HIP stream.
+//
+// Plays the role of Arctic::Renderer::Renderer (reference src/renderer/renderer.{hpp,cpp}) for
+// the hot path only: create_material/create_mesh/update_lights upload resources
+// (renderer.cpp:417-603), render_frame runs shadow-map raster -> visibility/G-buffer prepass ->
+// shading+tonemap (renderer.cpp:285-357 minus skybox, ImGui and present).  Everything D3D12
+// (RHI, descriptor heaps, barriers, swapchain) is replaced by plain device allocations and
+// stream order.  No CPU fallback: every entry point needs a HIP device.
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/arctic_hip.h"
+#include "common.h"
+
+using namespace arctic;
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+struct Mesh {
+    float *d_vertices = nullptr;
+    uint32_t *d_indices = nullptr;
+    uint32_t n_vertices = 0, n_indices = 0;
+    uint64_t material = 0;
+};
+
+}  // namespace
+
+struct ArcticRenderer {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint32_t width = 0, height = 0, shadow_size = 0, max_lights = 0, row_begin = 0, row_end = 0;
+    uint32_t tiles_x = 0, tiles_y = 0, tile_y0 = 0, row0_in_tile = 0;
+    std::vector<Mesh> meshes;
+    std::vector<TexDesc> tex;        // 3 per material (device pointers)
+    std::vector<void *> tex_allocs;
+    DevBuf d_tex, d_lut, d_lights, d_shadow;
+    uint32_t n_lights = 0;
+    // frame targets
+    DevBuf d_vis, d_p0, d_p1, d_p2, d_p3, d_p4, d_depth, d_src, d_rgba8, d_ldr, d_hdr, d_counter;
+    bool have_gbuffer = false, have_output = false;
+    // per-frame geometry scratch
+    DevBuf d_objs, d_vblock_obj, d_vblock_first, d_tblock_obj, d_tblock_first, d_xverts, d_sub_count, d_sub_offset,
+        d_recs, d_tile_count, d_tile_offset, d_scan, d_gp, d_stage;
+    uint64_t stats[6] = {0, 0, 0, 0, 0, 0};
+    int keep_float = 0, count_evals = 0, culling = 1;
+    std::string err;
+
+    int fail(int code, const char *fmt, ...) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        err = buf;
+        return code;
+    }
+    uint32_t rows() const { return row_end - row_begin; }
+    size_t n_tiles() const { return (size_t)tiles_x * tiles_y; }
+    GBuffer gbuffer() const { return GBuffer{d_p0.as<float4>(), d_p1.as<float4>(), d_p2.as<float4>(), d_p3.as<float4>(), d_p4.as<float>()}; }
+};
+
+#define HIPCHECK(r, expr)                                                                            \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess) return (r)->fail(ARCTIC_E_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+namespace {
+
+int select_device(ArcticRenderer *r) {
+    HIPCHECK(r, hipSetDevice(r->device));
+    return ARCTIC_OK;
+}
+
+int alloc_targets(ArcticRenderer *r) {
+    r->tile_y0 = r->row_begin / TILE;
+    r->row0_in_tile = r->row_begin - r->tile_y0 * TILE;
+    r->tiles_x = (r->width + TILE - 1) / TILE;
+    r->tiles_y = (r->row_end + TILE - 1) / TILE - r->tile_y0;
+    size_t px = r->n_tiles() * TILE_PIXELS, out_px = (size_t)r->rows() * r->width;
+    HIPCHECK(r, r->d_vis.ensure(px * 8));
+    HIPCHECK(r, r->d_p0.ensure(px * 16));
+    HIPCHECK(r, r->d_p1.ensure(px * 16));
+    HIPCHECK(r, r->d_p2.ensure(px * 16));
+    HIPCHECK(r, r->d_p3.ensure(px * 16));
+    HIPCHECK(r, r->d_p4.ensure(px * 12));
+    HIPCHECK(r, r->d_depth.ensure(px * 4));
+    HIPCHECK(r, r->d_src.ensure(px * 4));
+    HIPCHECK(r, r->d_rgba8.ensure(out_px * 4));
+    HIPCHECK(r, r->d_counter.ensure(64));
+    r->have_gbuffer = r->have_output = false;
+    return ARCTIC_OK;
+}
+
+// Scene.objects -> ObjectRec[] + block tables; returns counts through the out params
+int upload_objects(ArcticRenderer *r, const ArcticScene *sc, uint32_t &n_objs, uint32_t &n_xverts, uint32_t &n_src_tris,
+                   uint32_t &n_vblocks, uint32_t &n_tblocks) {
+    std::vector<ObjectRec> objs;
+    std::vector<uint32_t> vb_obj, vb_first, tb_obj, tb_first;
+    uint64_t xv = 0, tri = 0;
+    for (uint64_t i = 0; i < sc->n_objects; ++i) {
+        const ArcticObject &o = sc->objects[i];
+        if (o.mesh_idx >= r->meshes.size()) continue;   // the reference would index out of bounds; skipped here
+        const Mesh &m = r->meshes[o.mesh_idx];
+        ObjectRec rec;
+        std::memcpy(rec.trs, o.trs, sizeof rec.trs);
+        rec.vertices = m.d_vertices;
+        rec.indices = m.d_indices;
+        rec.n_vertices = m.n_vertices;
+        rec.n_triangles = m.n_indices / 3;
+        rec.first_xvert = (uint32_t)xv;
+        rec.first_triangle = (uint32_t)tri;
+        rec.material = (uint32_t)m.material;
+        rec.pad = 0;
+        uint32_t oi = (uint32_t)objs.size();
+        for (uint32_t b = 0; b < rec.n_vertices; b += 256) { vb_obj.push_back(oi); vb_first.push_back(b); }
+        for (uint32_t b = 0; b < rec.n_triangles; b += 256) { tb_obj.push_back(oi); tb_first.push_back(b); }
+        xv += rec.n_vertices;
+        tri += rec.n_triangles;
+        objs.push_back(rec);
+    }
+    if (xv > 0xFFFFFFF0ull || tri > 0xFFFFFFF0ull) return r->fail(ARCTIC_E_CAPACITY, "scene too large: %llu vertices, %llu triangles", (unsigned long long)xv, (unsigned long long)tri);
+    n_objs = (uint32_t)objs.size(); n_xverts = (uint32_t)xv; n_src_tris = (uint32_t)tri;
+    n_vblocks = (uint32_t)vb_obj.size(); n_tblocks = (uint32_t)tb_obj.size();
+    if (n_objs == 0) return ARCTIC_OK;
+    auto up = [&](DevBuf &b, const void *src, size_t bytes) -> hipError_t {
+        hipError_t e = b.ensure(bytes);
+        if (e != hipSuccess) return e;
+        return hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, r->stream);
+    };
+    HIPCHECK(r, up(r->d_objs, objs.data(), objs.size() * sizeof(ObjectRec)));
+    HIPCHECK(r, up(r->d_vblock_obj, vb_obj.data(), vb_obj.size() * 4));
+    HIPCHECK(r, up(r->d_vblock_first, vb_first.data(), vb_first.size() * 4));
+    HIPCHECK(r, up(r->d_tblock_obj, tb_obj.data(), tb_obj.size() * 4));
+    HIPCHECK(r, up(r->d_tblock_first, tb_first.data(), tb_first.size() * 4));
+    HIPCHECK(r, hipStreamSynchronize(r->stream));   // the host vectors die at return
+    HIPCHECK(r, r->d_xverts.ensure((size_t)n_xverts * sizeof(XVert)));
+    HIPCHECK(r, r->d_sub_count.ensure((size_t)n_src_tris * 4 + 4));
+    HIPCHECK(r, r->d_sub_offset.ensure((size_t)n_src_tris * 4 + 8));
+    return ARCTIC_OK;
+}
+
+// vertex -> clip/setup -> raster, shared by the forward prepass and the shadow pass
+int run_geometry(ArcticRenderer *r, const ArcticScene *sc, bool shadow_pass, uint64_t &n_recs_out, uint64_t &n_items_out) {
+    GeomParams gp;
+    std::memset(&gp, 0, sizeof gp);
+    sun_proj_view(sc->sun.position, sc->sun.rotation, gp.light_from_world);
+    if (shadow_pass) {
+        std::memcpy(gp.clip_from_world, gp.light_from_world, sizeof gp.clip_from_world);
+        gp.vp_w = gp.vp_h = (float)r->shadow_size;
+        gp.sc_x0 = gp.sc_y0 = 0; gp.sc_x1 = gp.sc_y1 = (int32_t)r->shadow_size;
+        gp.cull_front = 1;                                       // shadow_map_pass.cpp:96-97
+        gp.tiles_x = (int32_t)((r->shadow_size + 7) / 8); gp.tile_y0 = 0; gp.pitch = (int32_t)r->shadow_size;
+    } else {
+        const ArcticCamera &c = sc->camera;
+        camera_proj_view(c.eye, c.rotation, c.aspect, c.fov_y, c.z_near_far[0], c.z_near_far[1], gp.clip_from_world);
+        gp.vp_w = (float)r->width; gp.vp_h = (float)r->height;
+        gp.sc_x0 = 0; gp.sc_x1 = (int32_t)r->width; gp.sc_y0 = (int32_t)r->row_begin; gp.sc_y1 = (int32_t)r->row_end;
+        gp.cull_front = 0;                                       // forward_pass.cpp:143-144
+        gp.tiles_x = (int32_t)r->tiles_x; gp.tile_y0 = (int32_t)r->tile_y0; gp.pitch = 0;
+    }
+    HIPCHECK(r, r->d_gp.ensure(sizeof gp));
+    HIPCHECK(r, hipMemcpyAsync(r->d_gp.p, &gp, sizeof gp, hipMemcpyHostToDevice, r->stream));
+    HIPCHECK(r, hipStreamSynchronize(r->stream));
+    const GeomParams *d_gp = r->d_gp.as<GeomParams>();
+
+    uint32_t n_objs, n_xverts, n_src, n_vblocks, n_tblocks;
+    int rc = upload_objects(r, sc, n_objs, n_xverts, n_src, n_vblocks, n_tblocks);
+    if (rc != ARCTIC_OK) return rc;
+    n_recs_out = n_items_out = 0;
+    if (n_objs == 0 || n_src == 0) return ARCTIC_OK;
+    const ObjectRec *objs = r->d_objs.as<ObjectRec>();
+    HIPCHECK(r, launch_vertex(objs, r->d_vblock_obj.as<uint32_t>(), r->d_vblock_first.as<uint32_t>(), n_vblocks, d_gp,
+                              r->d_xverts.as<XVert>(), shadow_pass ? 1 : 0, r->stream));
+    // pass 1: count, scan
+    HIPCHECK(r, launch_setup(objs, r->d_tblock_obj.as<uint32_t>(), r->d_tblock_first.as<uint32_t>(), n_tblocks, d_gp,
+                             r->d_xverts.as<XVert>(), nullptr, r->d_sub_count.as<uint32_t>(), nullptr, nullptr, r->stream));
+    HIPCHECK(r, r->d_scan.ensure(((size_t)scan_scratch_elems(n_src) + scan_scratch_elems(7 * (size_t)n_src > 0xFFFFFFF0ull ? 0xFFFFFFF0u : 7 * n_src)) * 4 + 4096));
+    HIPCHECK(r, launch_scan(r->d_sub_count.as<uint32_t>(), r->d_sub_offset.as<uint32_t>(), n_src, r->d_scan.as<uint32_t>(), r->stream));
+    uint32_t n_recs = 0;
+    HIPCHECK(r, hipMemcpyAsync(&n_recs, r->d_sub_offset.as<uint32_t>() + n_src, 4, hipMemcpyDeviceToHost, r->stream));
+    HIPCHECK(r, hipStreamSynchronize(r->stream));
+    n_recs_out = n_recs;
+    if (n_recs == 0) return ARCTIC_OK;
+    // pass 2: emit compacted records + tiles per record, scan
+    HIPCHECK(r, r->d_recs.ensure((size_t)n_recs * sizeof(SetupRec)));
+    HIPCHECK(r, r->d_tile_count.ensure((size_t)n_recs * 4 + 4));
+    HIPCHECK(r, r->d_tile_offset.ensure((size_t)n_recs * 4 + 8));
+    HIPCHECK(r, launch_setup(objs, r->d_tblock_obj.as<uint32_t>(), r->d_tblock_first.as<uint32_t>(), n_tblocks, d_gp,
+                             r->d_xverts.as<XVert>(), r->d_sub_offset.as<uint32_t>(), nullptr, r->d_recs.as<SetupRec>(),
+                             r->d_tile_count.as<uint32_t>(), r->stream));
+    HIPCHECK(r, launch_scan(r->d_tile_count.as<uint32_t>(), r->d_tile_offset.as<uint32_t>(), n_recs, r->d_scan.as<uint32_t>(), r->stream));
+    uint32_t n_items = 0;
+    HIPCHECK(r, hipMemcpyAsync(&n_items, r->d_tile_offset.as<uint32_t>() + n_recs, 4, hipMemcpyDeviceToHost, r->stream));
+    HIPCHECK(r, hipStreamSynchronize(r->stream));
+    n_items_out = n_items;
+    if (shadow_pass)
+        HIPCHECK(r, launch_raster_depth(r->d_recs.as<SetupRec>(), r->d_tile_offset.as<uint32_t>(), n_recs, n_items, d_gp,
+                                        r->d_shadow.as<uint32_t>(), r->stream));
+    else
+        HIPCHECK(r, launch_raster_vis(r->d_recs.as<SetupRec>(), r->d_tile_offset.as<uint32_t>(), n_recs, n_items, d_gp,
+                                      r->d_vis.as<unsigned long long>(), r->stream));
+    return ARCTIC_OK;
+}
+
+int pass_shadow_map(ArcticRenderer *r, const ArcticScene *sc) {
+    if (r->shadow_size == 0) return ARCTIC_OK;
+    size_t n = (size_t)r->shadow_size * r->shadow_size;
+    HIPCHECK(r, launch_fill_u32(r->d_shadow.as<uint32_t>(), 0x3F800000u, n, r->stream));   // clear to 1.0 (shadow_map_pass.cpp:124-131)
+    return run_geometry(r, sc, true, r->stats[2], r->stats[3]);
+}
+
+int pass_gbuffer(ArcticRenderer *r, const ArcticScene *sc) {
+    HIPCHECK(r, launch_fill_u64(r->d_vis.as<unsigned long long>(), ~0ull, r->n_tiles() * TILE_PIXELS, r->stream));
+    int rc = run_geometry(r, sc, false, r->stats[0], r->stats[1]);
+    if (rc != ARCTIC_OK) return rc;
+    HIPCHECK(r, launch_resolve(r->d_vis.as<unsigned long long>(), r->d_recs.as<SetupRec>(), r->d_objs.as<ObjectRec>(),
+                               r->d_xverts.as<XVert>(), r->d_gp.as<GeomParams>(), (uint32_t)r->n_tiles(), r->gbuffer(),
+                               r->d_depth.as<float>(), r->d_src.as<uint32_t>(), r->stream));
+    r->have_gbuffer = true;
+    return ARCTIC_OK;
+}
+
+int fill_shade_params(ArcticRenderer *r, const ArcticScene *sc, const ArcticSettings *st, void *d_out, ShadeParams &sp) {
+    if (!r->have_gbuffer) return r->fail(ARCTIC_E_STATE, "shade: no G-buffer (run arctic_pass_gbuffer or arctic_write_gbuffer first)");
+    std::memset(&sp, 0, sizeof sp);
+    sp.g = r->gbuffer();
+    sp.tex = r->d_tex.as<TexDesc>();
+    sp.n_materials = (uint32_t)(r->tex.size() / 3);
+    sp.srgb_lut = r->d_lut.as<float>();
+    sp.shadow_map = r->shadow_size ? r->d_shadow.as<float>() : nullptr;
+    sp.shadow_size = r->shadow_size;
+    sp.lights = r->d_lights.as<float4>();
+    sp.n_lights = r->n_lights;
+    std::memcpy(sp.eye, sc->camera.eye, 12);
+    dir_from_rot(sc->sun.rotation, sp.sun_dir);     // DirectionalLight::direction(), scene.cpp:56-59
+    std::memcpy(sp.sun_color, sc->sun.color, 12);
+    sp.ambient = sc->ambient;
+    sp.tm_method = st->tm_method;
+    sp.inv_gamma = 1.0f / st->gamma;
+    sp.exposure = st->exposure;
+    sp.width = r->width; sp.rows = r->rows(); sp.row0_in_tile = r->row0_in_tile;
+    sp.tiles_x = r->tiles_x; sp.tiles_y = r->tiles_y;
+    sp.out_rgba8 = static_cast<uint8_t *>(d_out ? d_out : r->d_rgba8.p);
+    size_t out_px = (size_t)r->rows() * r->width;
+    if (r->keep_float) {
+        HIPCHECK(r, r->d_ldr.ensure(out_px * 12));
+        HIPCHECK(r, r->d_hdr.ensure(out_px * 12));
+        sp.out_ldr = r->d_ldr.as<float>(); sp.out_hdr = r->d_hdr.as<float>();
+    }
+    sp.light_evals = r->count_evals ? r->d_counter.as<unsigned long long>() : nullptr;
+    sp.culling = r->culling;
+    return ARCTIC_OK;
+}
+
+int pass_shade(ArcticRenderer *r, const ArcticScene *sc, const ArcticSettings *st, void *d_out) {
+    ShadeParams sp;
+    int rc = fill_shade_params(r, sc, st, d_out, sp);
+    if (rc != ARCTIC_OK) return rc;
+    if (sp.light_evals) HIPCHECK(r, hipMemsetAsync(r->d_counter.p, 0, 8, r->stream));
+    HIPCHECK(r, launch_shade(sp, r->stream));
+    if (sp.light_evals) {
+        unsigned long long n = 0;
+        HIPCHECK(r, hipMemcpyAsync(&n, r->d_counter.p, 8, hipMemcpyDeviceToHost, r->stream));
+        HIPCHECK(r, hipStreamSynchronize(r->stream));
+        r->stats[5] = n;
+    }
+    r->have_output = (d_out == nullptr);
+    return ARCTIC_OK;
+}
+
+bool valid_scene(const ArcticScene *sc) { return sc && (sc->n_objects == 0 || sc->objects); }
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int arctic_version(void) { return 100; }
+
+ArcticRenderer *arctic_create(const ArcticCreateInfo *info, char *err, uint64_t err_len) {
+    auto say = [&](const char *m) { if (err && err_len) { std::snprintf(err, (size_t)err_len, "%s", m); } };
+    if (!info || info->width == 0 || info->height == 0) { say("arctic_create: width/height must be > 0"); return nullptr; }
+    uint32_t rb = info->row_begin, re = info->row_end;
+    if (rb == 0 && re == 0) re = info->height;
+    if (re > info->height || rb >= re) { say("arctic_create: bad row shard"); return nullptr; }
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) { say("arctic_create: no HIP device (this library has no CPU path)"); return nullptr; }
+    if (info->device < 0 || info->device >= n_dev) { say("arctic_create: device ordinal out of range"); return nullptr; }
+    ArcticRenderer *r = new ArcticRenderer();
+    r->device = info->device;
+    r->width = info->width; r->height = info->height; r->shadow_size = info->shadow_size; r->max_lights = info->max_lights;
+    r->row_begin = rb; r->row_end = re;
+    auto bail = [&](const char *what, hipError_t e) {
+        char buf[256];
+        std::snprintf(buf, sizeof buf, "arctic_create: %s: %s", what, hipGetErrorString(e));
+        say(buf);
+        arctic_destroy(r);
+        return (ArcticRenderer *)nullptr;
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(r->device)) != hipSuccess) return bail("hipSetDevice", e);
+    if ((e = hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    float lut[256];
+    for (int i = 0; i < 256; ++i) lut[i] = srgb8_to_linear(i);
+    if ((e = r->d_lut.ensure(sizeof lut)) != hipSuccess) return bail("hipMalloc lut", e);
+    if ((e = hipMemcpy(r->d_lut.p, lut, sizeof lut, hipMemcpyHostToDevice)) != hipSuccess) return bail("upload lut", e);
+    if ((e = r->d_lights.ensure(std::max<size_t>(32, (size_t)r->max_lights * 32))) != hipSuccess) return bail("hipMalloc lights", e);
+    if ((e = r->d_tex.ensure(48)) != hipSuccess) return bail("hipMalloc tex table", e);
+    if (r->shadow_size) {
+        size_t n = (size_t)r->shadow_size * r->shadow_size;
+        if ((e = r->d_shadow.ensure(n * 4)) != hipSuccess) return bail("hipMalloc shadow map", e);
+        if ((e = launch_fill_u32(r->d_shadow.as<uint32_t>(), 0x3F800000u, n, r->stream)) != hipSuccess) return bail("clear shadow map", e);
+    }
+    if (alloc_targets(r) != ARCTIC_OK) { say(r->err.c_str()); arctic_destroy(r); return nullptr; }
+    if ((e = hipStreamSynchronize(r->stream)) != hipSuccess) return bail("sync", e);
+    return r;
+}
+
+void arctic_destroy(ArcticRenderer *r) {
+    if (!r) return;
+    (void)hipSetDevice(r->device);
+    if (r->stream) { (void)hipStreamSynchronize(r->stream); (void)hipStreamDestroy(r->stream); }
+    for (Mesh &m : r->meshes) { if (m.d_vertices) (void)hipFree(m.d_vertices); if (m.d_indices) (void)hipFree(m.d_indices); }
+    for (void *p : r->tex_allocs) (void)hipFree(p);
+    DevBuf *bufs[] = {&r->d_tex, &r->d_lut, &r->d_lights, &r->d_shadow, &r->d_vis, &r->d_p0, &r->d_p1, &r->d_p2, &r->d_p3, &r->d_p4,
+                      &r->d_depth, &r->d_src, &r->d_rgba8, &r->d_ldr, &r->d_hdr, &r->d_counter, &r->d_objs, &r->d_vblock_obj,
+                      &r->d_vblock_first, &r->d_tblock_obj, &r->d_tblock_first, &r->d_xverts, &r->d_sub_count, &r->d_sub_offset,
+                      &r->d_recs, &r->d_tile_count, &r->d_tile_offset, &r->d_scan, &r->d_gp, &r->d_stage};
+    for (DevBuf *b : bufs) b->release();
+    delete r;
+}
+
+const char *arctic_last_error(const ArcticRenderer *r) { return r ? r->err.c_str() : "null handle"; }
+
+int arctic_resize(ArcticRenderer *r, uint32_t width, uint32_t height) {
+    if (!r) return ARCTIC_E_INVALID;
+    if (width == 0 || height == 0) return r->fail(ARCTIC_E_INVALID, "resize: zero size");
+    int rc = select_device(r);
+    if (rc) return rc;
+    HIPCHECK(r, hipStreamSynchronize(r->stream));
+    r->width = width; r->height = height; r->row_begin = 0; r->row_end = height;
+    return alloc_targets(r);
+}
+
+int arctic_flush(ArcticRenderer *r) {
+    if (!r) return ARCTIC_E_INVALID;
+    int rc = select_device(r);
+    if (rc) return rc;
+    HIPCHECK(r, hipStreamSynchronize(r->stream));
+    return ARCTIC_OK;
+}
+
+int arctic_create_material(ArcticRenderer *r, const void *diffuse, uint32_t dw, uint32_t dh, const void *normal, uint32_t nw,
+                           uint32_t nh, const void *mr, uint32_t mw, uint32_t mh) {
+    if (!r) return ARCTIC_E_INVALID;
+    if (!diffuse || !normal || !mr || !dw || !dh || !nw || !nh || !mw || !mh) return r->fail(ARCTIC_E_INVALID, "create_material: null image or zero size");
+    int rc = select_device(r);
+    if (rc) return rc;
+    const void *src[3] = {diffuse, normal, mr};
+    const uint32_t w[3] = {dw, nw, mw}, h[3] = {dh, nh, mh};
+    TexDesc td[3];
+    for (int i = 0; i < 3; ++i) {
+        void *p = nullptr;
+        size_t bytes = (size_t)w[i] * h[i] * 4;
+        HIPCHECK(r, hipMalloc(&p, bytes));
+        r->tex_allocs.push_back(p);
+        HIPCHECK(r, hipMemcpy(p, src[i], bytes, hipMemcpyHostToDevice));   // synchronous like rhi.cpp:480-519
+        td[i].texels = static_cast<const uint32_t *>(p); td[i].w = w[i]; td[i].h = h[i];
+    }
+    r->tex.insert(r->tex.end(), td, td + 3);
+    HIPCHECK(r, hipStreamSynchronize(r->stream));
+    HIPCHECK(r, r->d_tex.ensure(r->tex.size() * sizeof(TexDesc)));
+    HIPCHECK(r, hipMemcpy(r->d_tex.p, r->tex.data(), r->tex.size() * sizeof(TexDesc), hipMemcpyHostToDevice));
+    return (int)(r->tex.size() / 3) - 1;
+}
+
+int arctic_create_mesh(ArcticRenderer *r, const ArcticVertex *vertices, uint64_t n_vertices, const uint32_t *indices,
+                       uint64_t n_indices, uint64_t material_idx) {
+    if (!r) return ARCTIC_E_INVALID;
+    if (!vertices || !indices || n_vertices == 0 || n_indices == 0) return r->fail(ARCTIC_E_INVALID, "create_mesh: empty mesh");
+    if (n_indices % 3 != 0) return r->fail(ARCTIC_E_INVALID, "create_mesh: index count %llu is not a multiple of 3 (triangle list)", (unsigned long long)n_indices);
+    if (material_idx >= r->tex.size() / 3) return r->fail(ARCTIC_E_INVALID, "create_mesh: material %llu does not exist", (unsigned long long)material_idx);
+    if (n_vertices > 0x7FFFFFFFull || n_indices > 0xFFFFFFF0ull) return r->fail(ARCTIC_E_CAPACITY, "create_mesh: mesh too large");
+    int rc = select_device(r);
+    if (rc) return rc;
+    Mesh m;
+    HIPCHECK(r, hipMalloc((void **)&m.d_vertices, n_vertices * sizeof(ArcticVertex)));
+    if (hipMalloc((void **)&m.d_indices, n_indices * 4) != hipSuccess) { (void)hipFree(m.d_vertices); return r->fail(ARCTIC_E_DEVICE, "create_mesh: hipMalloc indices"); }
+    m.n_vertices = (uint32_t)n_vertices; m.n_indices = (uint32_t)n_indices; m.material = material_idx;
+    r->meshes.push_back(m);
+    HIPCHECK(r, hipMemcpy(m.d_vertices, vertices, n_vertices * sizeof(ArcticVertex), hipMemcpyHostToDevice));
+    HIPCHECK(r, hipMemcpy(m.d_indices, indices, n_indices * 4, hipMemcpyHostToDevice));
+    return (int)r->meshes.size() - 1;
+}
+
+int arctic_update_lights(ArcticRenderer *r, const ArcticPointLight *lights, uint64_t n) {
+    if (!r) return ARCTIC_E_INVALID;
+    if (n && !lights) return r->fail(ARCTIC_E_INVALID, "update_lights: null");
+    int rc = select_device(r);
+    if (rc) return rc;
+    uint32_t k = (uint32_t)std::min<uint64_t>(n, r->max_lights);   // renderer.cpp:587-588
+    HIPCHECK(r, hipStreamSynchronize(r->stream));
+    if (k) HIPCHECK(r, hipMemcpy(r->d_lights.p, lights, (size_t)k * sizeof(ArcticPointLight), hipMemcpyHostToDevice));
+    r->n_lights = k;
+    return ARCTIC_OK;
+}
+
+int arctic_create_hdri(ArcticRenderer *r, const float *rgba32f, uint32_t w, uint32_t h) {
+    if (!r) return ARCTIC_E_INVALID;
+    if (!rgba32f || !w || !h) return r->fail(ARCTIC_E_INVALID, "create_hdri: null image or zero size");
+    return ARCTIC_OK;   // skybox is outside this path
+}
+
+int arctic_pass_shadow_map(ArcticRenderer *r, const ArcticScene *scene) {
+    if (!r) return ARCTIC_E_INVALID;
+    if (!valid_scene(scene)) return r->fail(ARCTIC_E_INVALID, "pass_shadow_map: bad scene");
+    int rc = select_device(r);
+    return rc ? rc : pass_shadow_map(r, scene);
+}
+
+int arctic_pass_gbuffer(ArcticRenderer *r, const ArcticScene *scene) {
+    if (!r) return ARCTIC_E_INVALID;
+    if (!valid_scene(scene)) return r->fail(ARCTIC_E_INVALID, "pass_gbuffer: bad scene");
+    int rc = select_device(r);
+    return rc ? rc : pass_gbuffer(r, scene);
+}
+
+int arctic_pass_shade(ArcticRenderer *r, const ArcticScene *scene, const ArcticSettings *settings, void *d_out) {
+    if (!r) return ARCTIC_E_INVALID;
+    if (!scene || !settings) return r->fail(ARCTIC_E_INVALID, "pass_shade: null scene/settings");
+    int rc = select_device(r);
+    return rc ? rc : pass_shade(r, scene, settings, d_out);
+}
+
+int arctic_render_frame_device(ArcticRenderer *r, const ArcticScene *scene, const ArcticSettings *settings, void *d_out) {
+    if (!r) return ARCTIC_E_INVALID;
+    if (!valid_scene(scene) || !settings) return r->fail(ARCTIC_E_INVALID, "render_frame: bad scene/settings");
+    int rc = select_device(r);
+    if (rc) return rc;
+    if ((rc = pass_shadow_map(r, scene)) != ARCTIC_OK) return rc;
+    if ((rc = pass_gbuffer(r, scene)) != ARCTIC_OK) return rc;
+    return pass_shade(r, scene, settings, d_out);
+}
+
+int arctic_render_frame(ArcticRenderer *r, const ArcticScene *scene, const ArcticSettings *settings, uint8_t *out_rgba8) {
+    int rc = arctic_render_frame_device(r, scene, settings, nullptr);
+    if (rc != ARCTIC_OK) return rc;
+    if (out_rgba8) HIPCHECK(r, hipMemcpyAsync(out_rgba8, r->d_rgba8.p, (size_t)r->rows() * r->width * 4, hipMemcpyDeviceToHost, r->stream));
+    HIPCHECK(r, hipStreamSynchronize(r->stream));
+    return ARCTIC_OK;
+}
+
+int arctic_post_process(ArcticRenderer *r, const float *hdr, uint32_t w, uint32_t h, const ArcticSettings *st, uint8_t *out_rgba8,
+                        float *out_ldr) {
+    if (!r) return ARCTIC_E_INVALID;
+    if (!hdr || !w || !h || !st || !out_rgba8) return r->fail(ARCTIC_E_INVALID, "post_process: null argument or zero size");
+    int rc = select_device(r);
+    if (rc) return rc;
+    size_t n = (size_t)w * h;
+    HIPCHECK(r, r->d_stage.ensure(n * 16 + n * 4 + n * 12));
+    char *base = r->d_stage.as<char>();
+    float4 *d_in = reinterpret_cast<float4 *>(base);
+    uint8_t *d_out = reinterpret_cast<uint8_t *>(base + n * 16);
+    float *d_ldr = reinterpret_cast<float *>(base + n * 20);
+    HIPCHECK(r, hipMemcpyAsync(d_in, hdr, n * 16, hipMemcpyHostToDevice, r->stream));
+    HIPCHECK(r, launch_post_process(d_in, w, h, st->tm_method, 1.0f / st->gamma, st->exposure, d_out, out_ldr ? d_ldr : nullptr, r->stream));
+    HIPCHECK(r, hipMemcpyAsync(out_rgba8, d_out, n * 4, hipMemcpyDeviceToHost, r->stream));
+    if (out_ldr) HIPCHECK(r, hipMemcpyAsync(out_ldr, d_ldr, n * 12, hipMemcpyDeviceToHost, r->stream));
+    HIPCHECK(r, hipStreamSynchronize(r->stream));
+    return ARCTIC_OK;
+}
+
+int arctic_time_shade(ArcticRenderer *r, const ArcticScene *scene, const ArcticSettings *settings, uint32_t warmup, uint32_t iters,
+                      float *ms_each) {
+    if (!r) return ARCTIC_E_INVALID;
+    if (!scene || !settings || !ms_each || iters == 0) return r->fail(ARCTIC_E_INVALID, "time_shade: bad arguments");
+    int rc = select_device(r);
+    if (rc) return rc;
+    ShadeParams sp;
+    if ((rc = fill_shade_params(r, scene, settings, nullptr, sp)) != ARCTIC_OK) return rc;
+    sp.light_evals = nullptr;
+    for (uint32_t i = 0; i < warmup; ++i) HIPCHECK(r, launch_shade(sp, r->stream));
+    std::vector<hipEvent_t> ev(2 * (size_t)iters);
+    for (auto &e : ev) HIPCHECK(r, hipEventCreate(&e));
+    for (uint32_t i = 0; i < iters; ++i) {
+        HIPCHECK(r, hipEventRecord(ev[2 * i], r->stream));
+        HIPCHECK(r, launch_shade(sp, r->stream));
+        HIPCHECK(r, hipEventRecord(ev[2 * i + 1], r->stream));
+    }
+    HIPCHECK(r, hipStreamSynchronize(r->stream));
+    for (uint32_t i = 0; i < iters; ++i) HIPCHECK(r, hipEventElapsedTime(&ms_each[i], ev[2 * i], ev[2 * i + 1]));
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    r->have_output = true;
+    return ARCTIC_OK;
+}
+
+int arctic_read_gbuffer(ArcticRenderer *r, float *attrs, uint32_t *material, float *depth, uint32_t *tri) {
+    if (!r) return ARCTIC_E_INVALID;
+    if (!r->have_gbuffer) return r->fail(ARCTIC_E_STATE, "read_gbuffer: no G-buffer");
+    int rc = select_device(r);
+    if (rc) return rc;
+    size_t px = (size_t)r->rows() * r->width;
+    if (attrs || material) {
+        HIPCHECK(r, r->d_stage.ensure(px * 76));
+        float *d_attrs = r->d_stage.as<float>();
+        uint32_t *d_mat = reinterpret_cast<uint32_t *>(r->d_stage.as<char>() + px * 72);
+        HIPCHECK(r, launch_gbuffer_tile(r->gbuffer(), d_attrs, d_mat, r->width, r->rows(), r->row0_in_tile, r->tiles_x, r->tiles_y, 0, r->stream));
+        if (attrs) HIPCHECK(r, hipMemcpyAsync(attrs, d_attrs, px * 72, hipMemcpyDeviceToHost, r->stream));
+        if (material) HIPCHECK(r, hipMemcpyAsync(material, d_mat, px * 4, hipMemcpyDeviceToHost, r->stream));
+        HIPCHECK(r, hipStreamSynchronize(r->stream));
+    }
+    if (depth || tri) {
+        size_t tp = r->n_tiles() * TILE_PIXELS;
+        std::vector<float> hd(depth ? tp : 0);
+        std::vector<uint32_t> ht(tri ? tp : 0);
+        HIPCHECK(r, hipStreamSynchronize(r->stream));
+        if (depth) HIPCHECK(r, hipMemcpy(hd.data(), r->d_depth.p, tp * 4, hipMemcpyDeviceToHost));
+        if (tri) HIPCHECK(r, hipMemcpy(ht.data(), r->d_src.p, tp * 4, hipMemcpyDeviceToHost));
+        for (uint32_t y = 0; y < r->rows(); ++y)
+            for (uint32_t x = 0; x < r->width; ++x) {
+                uint32_t yy = y + r->row0_in_tile;
+                size_t idx = ((size_t)(yy / 8) * r->tiles_x + x / 8) * 64 + (yy % 8) * 8 + (x % 8);
+                if (depth) depth[(size_t)y * r->width + x] = hd[idx];
+                if (tri) tri[(size_t)y * r->width + x] = ht[idx];
+            }
+    }
+    return ARCTIC_OK;
+}
+
+int arctic_write_gbuffer(ArcticRenderer *r, const float *attrs, const uint32_t *material) {
+    if (!r) return ARCTIC_E_INVALID;
+    if (!attrs || !material) return r->fail(ARCTIC_E_INVALID, "write_gbuffer: null");
+    int rc = select_device(r);
+    if (rc) return rc;
+    size_t px = (size_t)r->rows() * r->width;
+    HIPCHECK(r, r->d_stage.ensure(px * 76));
+    float *d_attrs = r->d_stage.as<float>();
+    uint32_t *d_mat = reinterpret_cast<uint32_t *>(r->d_stage.as<char>() + px * 72);
+    HIPCHECK(r, hipMemcpyAsync(d_attrs, attrs, px * 72, hipMemcpyHostToDevice, r->stream));
+    HIPCHECK(r, hipMemcpyAsync(d_mat, material, px * 4, hipMemcpyHostToDevice, r->stream));
+    HIPCHECK(r, launch_gbuffer_tile(r->gbuffer(), d_attrs, d_mat, r->width, r->rows(), r->row0_in_tile, r->tiles_x, r->tiles_y, 1, r->stream));
+    HIPCHECK(r, hipStreamSynchronize(r->stream));
+    r->have_gbuffer = true;
+    return ARCTIC_OK;
+}
+
+int arctic_read_shadow_map(ArcticRenderer *r, float *depth) {
+    if (!r) return ARCTIC_E_INVALID;
+    if (!depth || !r->shadow_size) return r->fail(ARCTIC_E_INVALID, "read_shadow_map: null or no shadow map");
+    int rc = select_device(r);
+    if (rc) return rc;
+    HIPCHECK(r, hipStreamSynchronize(r->stream));
+    HIPCHECK(r, hipMemcpy(depth, r->d_shadow.p, (size_t)r->shadow_size * r->shadow_size * 4, hipMemcpyDeviceToHost));
+    return ARCTIC_OK;
+}
+
+int arctic_write_shadow_map(ArcticRenderer *r, const float *depth) {
+    if (!r) return ARCTIC_E_INVALID;
+    if (!depth || !r->shadow_size) return r->fail(ARCTIC_E_INVALID, "write_shadow_map: null or no shadow map");
+    int rc = select_device(r);
+    if (rc) return rc;
+    HIPCHECK(r, hipStreamSynchronize(r->stream));
+    HIPCHECK(r, hipMemcpy(r->d_shadow.p, depth, (size_t)r->shadow_size * r->shadow_size * 4, hipMemcpyHostToDevice));
+    return ARCTIC_OK;
+}
+
+int arctic_read_output(ArcticRenderer *r, float *ldr, float *hdr, uint8_t *rgba8) {
+    if (!r) return ARCTIC_E_INVALID;
+    if (!r->have_output) return r->fail(ARCTIC_E_STATE, "read_output: nothing shaded into the handle's own buffers yet");
+    if ((ldr || hdr) && !r->keep_float) return r->fail(ARCTIC_E_STATE, "read_output: float planes need ARCTIC_OPT_KEEP_FLOAT_OUTPUT");
+    int rc = select_device(r);
+    if (rc) return rc;
+    size_t px = (size_t)r->rows() * r->width;
+    HIPCHECK(r, hipStreamSynchronize(r->stream));
+    if (ldr) HIPCHECK(r, hipMemcpy(ldr, r->d_ldr.p, px * 12, hipMemcpyDeviceToHost));
+    if (hdr) HIPCHECK(r, hipMemcpy(hdr, r->d_hdr.p, px * 12, hipMemcpyDeviceToHost));
+    if (rgba8) HIPCHECK(r, hipMemcpy(rgba8, r->d_rgba8.p, px * 4, hipMemcpyDeviceToHost));
+    return ARCTIC_OK;
+}
+
+int arctic_frame_constants(const ArcticScene *scene, float *proj_view, float *light_proj_view, float *sun_dir) {
+    if (!scene) return ARCTIC_E_INVALID;
+    const ArcticCamera &c = scene->camera;
+    if (proj_view) camera_proj_view(c.eye, c.rotation, c.aspect, c.fov_y, c.z_near_far[0], c.z_near_far[1], proj_view);
+    if (light_proj_view) sun_proj_view(scene->sun.position, scene->sun.rotation, light_proj_view);
+    if (sun_dir) dir_from_rot(scene->sun.rotation, sun_dir);
+    return ARCTIC_OK;
+}
+
+int arctic_stats(ArcticRenderer *r, uint64_t *out, uint32_t n) {
+    if (!r || !out) return ARCTIC_E_INVALID;
+    for (uint32_t i = 0; i < n && i < 6; ++i) out[i] = r->stats[i];
+    return ARCTIC_OK;
+}
+
+int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value) {
+    if (!r) return ARCTIC_E_INVALID;
+    switch (option) {
+    case ARCTIC_OPT_KEEP_FLOAT_OUTPUT: r->keep_float = value != 0; break;
+    case ARCTIC_OPT_COUNT_LIGHT_EVALS: r->count_evals = value != 0; break;
+    case ARCTIC_OPT_CULLING: r->culling = value != 0; break;
+    default: return r->fail(ARCTIC_E_INVALID, "set_option: unknown option %u", option);
+    }
+    return ARCTIC_OK;
+}
+
+}  // extern "C"

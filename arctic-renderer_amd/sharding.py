@@ -1,0 +1,58 @@
+"""Screen-space sharding of one frame across the GPUs of a node.
+
+The reference is single-GPU (src/renderer/rhi.cpp:120-124); this is the MI355X-side extension
+BASELINE.json's north_star asks for.  Every pixel of the shading pass reads only its own G-buffer
+texel plus read-only scene data (forward.hlsl:208-235), so rank r of R owns the contiguous rows
+[r*H/R, (r+1)*H/R): no halo, no data-path collective while shading, and ONE exchange step at the
+end -- the gather of the finished RGBA8 shards on rank 0.  On the xGMI full mesh that gather is R-1
+independent point-to-point transfers, one per link into the root.
+
+One process per GPU, torch.distributed (backend "nccl" = RCCL on ROCm; "gloo" on CPU for tests).
+"""
+import torch
+import torch.distributed as dist
+
+
+def row_range(height, rank, world):
+    """rows [begin, end) of rank `rank`; balanced to within one row, contiguous, covering [0, height)."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world {world}")
+    base, extra = divmod(height, world)
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def gather_rows(shard, gathered, rank, world, root=0, group=None):
+    """gather the (rows_r, width, 4) uint8 shards on `root`; `gathered` is the root's list of per-rank
+    buffers (None elsewhere).  Shards may differ by one row, so this is send/recv into the root
+    rather than an equal-count ncclGather; when all counts are equal dist.gather is used."""
+    if world == 1:
+        return shard
+    sizes_equal = gathered is None or all(g.shape == gathered[0].shape for g in gathered)
+    if sizes_equal and _all_equal_rows(shard, world, group):
+        dist.gather(shard, gather_list=gathered if rank == root else None, dst=root, group=group)
+    elif rank == root:
+        gathered[root].copy_(shard)
+        reqs = [dist.irecv(gathered[k], src=k, group=group) for k in range(world) if k != root]
+        for q in reqs:
+            q.wait()
+    else:
+        dist.send(shard, dst=root, group=group)
+    return gathered
+
+
+_equal_cache = {}
+
+
+def _all_equal_rows(shard, world, group):
+    key = (tuple(shard.shape), world, id(group))
+    if key not in _equal_cache:
+        t = torch.tensor([shard.shape[0], -shard.shape[0]], dtype=torch.int64, device=shard.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        _equal_cache[key] = bool(t[0].item() == -t[1].item())
+    return _equal_cache[key]
+
+
+def assemble(gathered):
+    """root only: the full frame (height, width, 4) from the per-rank shards."""
+    return torch.cat(gathered, dim=0)

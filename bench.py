@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- Mshaded-pixels/s of the forward PBR shading pass (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE pass of the hot path (ps_main + post_process: G-buffer -> BRDF + PCF shadow +
+point lights -> tonemap + gamma -> RGBA8) over one 4K frame's G-buffer, resident in HBM.  The
+workload is BASELINE.json configs[2] (the config the metric is quoted on): the Sponza stand-in
+at 3840x2160, 1 directional + 64 point lights, 4000^2 shadow map, ACES -- synthetic (the glTF
+assets are not available offline), produced once, untimed, by the library's own shadow-map raster
+and G-buffer prepass.
+
+N > 1: the frame is sharded by rows (rank r shades rows [r*H/N, (r+1)*H/N)), every step ends with
+the RCCL gather of the finished RGBA8 shards on rank 0 (the path's one real exchange step), total
+work is fixed -> "scaling": "strong".
+
+The JSON line also carries
+  roofline     achieved = 80 B x shaded pixels / mean kernel time (HIP events on the launch stream)
+               against the 8 TB/s HBM peak (the VALU roof is reported next to it: with 65 light
+               evaluations per lit pixel the kernel is FP32-VALU bound)
+  cpu_baseline the CPU oracle (scalar C++ port of the same HLSL math) shading a bounded stripe of
+               the SAME G-buffer on this host's cores -- a baseline, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+BYTES_PER_PIXEL = 80          # 72 B attributes + 4 B material id + 4 B RGBA8
+HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP32_PEAK_TFLOPS = 157.3      # vector FP32 (needs packed FMA)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", type=int, default=3, help="BASELINE.json config number (3 = the metric's config)")
+    ap.add_argument("--scale", type=float, default=1.0, help="<1 shrinks the workload (debug only; makes the number invalid)")
+    ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline shades (0 = auto)")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the product has no CPU path")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    pkg = entry.load_package()
+    sharding = __import__("arctic_renderer_amd.sharding", fromlist=["x"])
+    t0 = time.time()
+    sc = pkg.scenes.CONFIGS[args.config](scale=args.scale)
+    row_begin, row_end = sharding.row_range(sc.height, rank, world)
+    r = sc.upload(pkg.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights, device=local,
+                               row_begin=row_begin, row_end=row_end))
+    r.pass_shadow_map(sc.desc)      # untimed: the producers of the hot path's inputs
+    r.pass_gbuffer(sc.desc)
+    r.flush()
+    if rank == 0:
+        log(f"[bench] {sc.name}: {sc.width}x{sc.height}, {sc.n_triangles} triangles, {len(sc.materials)} materials, "
+            f"{len(sc.lights)} point lights, shadow {sc.shadow_size}^2; setup {time.time() - t0:.1f}s")
+
+    rows = row_end - row_begin
+    out = torch.empty((rows, sc.width, 4), dtype=torch.uint8, device="cuda")
+    gathered = [torch.empty((sharding.row_range(sc.height, k, world)[1] - sharding.row_range(sc.height, k, world)[0], sc.width, 4),
+                            dtype=torch.uint8, device="cuda") for k in range(world)] if (world > 1 and rank == 0) else None
+
+    def step():
+        r.pass_shade(sc.desc, sc.settings, out.data_ptr())
+        if world > 1:
+            r.flush()                                   # the gather runs on torch's stream
+            sharding.gather_rows(out, gathered, rank, world)
+
+    for _ in range(args.warmup):
+        step()
+    r.flush()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    r.flush()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t_start
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # shaded pixels = pixels with geometry (100 % in this scene); counted, not assumed
+    _, mat, _, _ = r.read_gbuffer(want=("material",))
+    shaded_local = int((mat != 0xFFFFFFFF).sum())
+    if world > 1:
+        t = torch.tensor([shaded_local], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t)
+        shaded = int(t.item())
+    else:
+        shaded = shaded_local
+
+    # roofline of the dominant kernel (k_shade), HIP events around each launch on its own stream
+    ms = r.time_shade(sc.desc, sc.settings, warmup=3, iters=max(10, min(args.steps, 50)))
+    kernel_ms = float(np.mean(ms))
+    achieved = shaded_local * BYTES_PER_PIXEL / (kernel_ms * 1e-3) / 1e9
+    # the same kernel with every wave-level cull disabled: all 1 + n_lights evaluations for every pixel
+    r.set_option("culling", 0)
+    ms_nocull = float(np.mean(r.time_shade(sc.desc, sc.settings, warmup=2, iters=10)))
+    r.set_option("culling", 1)
+    r.set_option("count_light_evals", 1)
+    r.pass_shade(sc.desc, sc.settings)
+    r.flush()
+    light_evals = int(r.stats()[5])
+    r.set_option("count_light_evals", 0)
+
+    result = None
+    if rank == 0:
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc_path) and world == 1 and args.scale == 1.0 and args.config == 3:
+            try:
+                traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        value = args.steps * shaded / dt / 1e6
+        result = {
+            "metric": "Mshaded-pixels/sec at 4K Sponza, 1 dir + 64 point lights; HBM GB/s vs roofline",
+            "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[{args.config - 1}]: {sc.name}, {sc.width}x{sc.height}, 1 dir + {len(sc.lights)} point lights, "
+                                   f"shadow {sc.shadow_size}^2 PCF 5x5, tonemap {sc.settings[0]}, {len(sc.materials)} materials; shading pass over a resident G-buffer",
+                       "triangles": sc.n_triangles, "shaded_pixels": shaded, "sharding": f"rows/{world}" if world > 1 else "none",
+                       "scale": args.scale},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "kernel": "k_shade", "kernel_ms": round(kernel_ms, 4), "bytes_per_pixel": BYTES_PER_PIXEL,
+                         "kernel_ms_no_culling": round(ms_nocull, 4),
+                         "achieved_no_culling": round(shaded_local * BYTES_PER_PIXEL / (ms_nocull * 1e-3) / 1e9, 1),
+                         "point_light_evals_per_pixel": round(light_evals / max(shaded_local, 1), 2)},
+        }
+        if world == 1 and not args.no_cpu:
+            result["cpu_baseline"] = cpu_baseline(pkg, sc, r, args.cpu_rows)
+    r.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+def cpu_baseline(pkg, sc, r, cpu_rows):
+    """the CPU oracle (test infrastructure; here only as the timed baseline) shading a bounded stripe
+    of the same G-buffer and shadow map, on all host threads."""
+    from oracle import oracle as O
+    O.build()
+    threads = O.hardware_threads() or os.cpu_count() or 1
+    attrs, mat, _, _ = r.read_gbuffer(want=("attrs", "material"))
+    o = sc.upload(O.Oracle(sc.width, sc.height, sc.shadow_size, sc.max_lights))
+    if sc.shadow_size:
+        o.write_shadow_map(r.read_shadow_map())
+    # calibrate on 8 rows, then size the sample for ~15 s
+    rows0 = min(8, attrs.shape[0])
+    mid = attrs.shape[0] // 2
+    t = time.perf_counter()
+    o.shade_gbuffer(sc.desc, sc.settings, attrs[mid:mid + rows0], mat[mid:mid + rows0], threads=threads, want=("rgba8",))
+    per_row = (time.perf_counter() - t) / rows0
+    n = cpu_rows or int(max(8, min(attrs.shape[0], 15.0 / max(per_row, 1e-6))))
+    n = max(4, n // 4 * 4)
+    start = max(0, mid - n // 2)
+    t = time.perf_counter()
+    o.shade_gbuffer(sc.desc, sc.settings, attrs[start:start + n], mat[start:start + n], threads=threads, want=("rgba8",))
+    dt = time.perf_counter() - t
+    px = int((mat[start:start + n] != 0xFFFFFFFF).sum())
+    o.close()
+    return {"value": round(px / dt / 1e6, 3), "unit": "Mpixels/s", "cores": threads, "kind": "port",
+            "sample": f"rows {start}..{start + n} of the {sc.height}-row frame ({px} shaded pixels, {dt:.1f} s), same G-buffer, "
+                      f"shadow map and {len(sc.lights)} lights; scalar C++ oracle, {threads} threads, no culling"}
+
+
+if __name__ == "__main__":
+    main()

@@ -275,6 +275,7 @@ bool setup_triangle(const ClipVert v[3], float vw, float vh, int sc_x0, int sc_y
     float hx = 0.5f * vw, hy = 0.5f * vh;
     int32_t X[3], Y[3]; float z[3], iw[3];
     for (int i = 0; i < 3; ++i) {
+        if (!(v[i].p.w > 0.0f)) return false;   // degenerate (w = 0 survives clipping only when z = w = 0)
         iw[i] = 1.0f / v[i].p.w;
         float nx = v[i].p.x * iw[i], ny = v[i].p.y * iw[i];
         z[i] = v[i].p.z * iw[i];
