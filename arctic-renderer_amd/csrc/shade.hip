@@ -98,15 +98,82 @@ __device__ float shadow_generic(const float *__restrict__ map, uint32_t S, float
     return shadow / 25.0f;
 }
 
+// 16-byte load from a 4-byte aligned address (gfx950 runs in unaligned-access mode: one global_load_dwordx4)
+typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));
+
+__device__ __forceinline__ float sel3(int k, float a, float b, float c) { return k == 0 ? a : (k == 1 ? b : c); }
+
+// Fast PCF.  The 25 taps are 1e-4 apart in uv (0.4 texel at S = 4000), so with their bilinear
+// neighbours they touch at most a 4x4 texel window whenever S <= 5000: load it once (4 x 16 B) and
+//   (1) every bilinear result lies in [min, max] of the window (fmaf lerps with weights in [0,1)
+//       cannot leave the interval of their operands), so pz > max => all 25 taps shadowed and
+//       pz <= min => none: decided without filtering, exactly;
+//   (2) otherwise evaluate the 25 bilinear compares from registers, in the oracle's operation order
+//       (horizontal lerps are shared between taps, which does not change any tap's value).
+// Lanes near the map border (WRAP would engage) or with a wider footprint use shadow_generic.
+__device__ __forceinline__ float shadow_window(const float *__restrict__ map, uint32_t S, float px, float py, float pz) {
+#pragma clang fp contract(off)
+    int x0[5], y0[5];
+    float fx[5], fy[5];
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        float u = px + (float)(i - 2) * 0.0001f, v = py + (float)(i - 2) * 0.0001f;
+        // inside [0,1): u - floor(u) == u, so this is wrap_axis without the wrap
+        ok = ok && u >= 0.0f && u < 1.0f && v >= 0.0f && v < 1.0f;
+        float x = u * (float)S - 0.5f, y = v * (float)S - 0.5f;
+        float xf = floorf(x), yf = floorf(y);
+        fx[i] = x - xf; fy[i] = y - yf;
+        x0[i] = (int)xf; y0[i] = (int)yf;
+    }
+    const int bx = x0[0], by = y0[0];
+    ok = ok && bx >= 0 && by >= 0 && x0[4] - bx <= 2 && y0[4] - by <= 2 && bx + 3 < (int)S && by + 3 < (int)S;
+    if (!ok) return shadow_generic(map, S, px, py, pz);
+    const float *base = map + (size_t)by * S + bx;
+    const float4u w0 = *reinterpret_cast<const float4u *>(base);
+    const float4u w1 = *reinterpret_cast<const float4u *>(base + S);
+    const float4u w2 = *reinterpret_cast<const float4u *>(base + 2 * (size_t)S);
+    const float4u w3 = *reinterpret_cast<const float4u *>(base + 3 * (size_t)S);
+    const float lo = fminf(fminf(fminf(fminf(w0.x, w0.y), fminf(w0.z, w0.w)), fminf(fminf(w1.x, w1.y), fminf(w1.z, w1.w))),
+                           fminf(fminf(fminf(w2.x, w2.y), fminf(w2.z, w2.w)), fminf(fminf(w3.x, w3.y), fminf(w3.z, w3.w))));
+    const float hi = fmaxf(fmaxf(fmaxf(fmaxf(w0.x, w0.y), fmaxf(w0.z, w0.w)), fmaxf(fmaxf(w1.x, w1.y), fmaxf(w1.z, w1.w))),
+                           fmaxf(fmaxf(fmaxf(w2.x, w2.y), fmaxf(w2.z, w2.w)), fmaxf(fmaxf(w3.x, w3.y), fmaxf(w3.z, w3.w))));
+    if (pz > hi) return 1.0f;
+    if (!(pz > lo)) return 0.0f;
+    // horizontal lerps: h[r][i] = lerp(w[r][c_i], w[r][c_i + 1], fx_i)
+    float h[4][5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int c = x0[i] - bx;
+        h[0][i] = lerp_exact(sel3(c, w0.x, w0.y, w0.z), sel3(c, w0.y, w0.z, w0.w), fx[i]);
+        h[1][i] = lerp_exact(sel3(c, w1.x, w1.y, w1.z), sel3(c, w1.y, w1.z, w1.w), fx[i]);
+        h[2][i] = lerp_exact(sel3(c, w2.x, w2.y, w2.z), sel3(c, w2.y, w2.z, w2.w), fx[i]);
+        h[3][i] = lerp_exact(sel3(c, w3.x, w3.y, w3.z), sel3(c, w3.y, w3.z, w3.w), fx[i]);
+    }
+    float shadow = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int rr = y0[j] - by;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const float closest = lerp_exact(sel3(rr, h[0][i], h[1][i], h[2][i]), sel3(rr, h[1][i], h[2][i], h[3][i]), fy[j]);
+            shadow += pz > closest ? 1.0f : 0.0f;
+        }
+    }
+    return shadow / 25.0f;
+}
+
 __device__ __forceinline__ float calculate_shadow(const float *__restrict__ map, uint32_t S, float4 ls) {
 #pragma clang fp contract(off)
     if (map == nullptr) return 0.0f;
-    float px = ls.x / ls.w, py = ls.y / ls.w, pz = ls.z / ls.w;
+    float px, py, pz;
+    if (__ballot(ls.w != 1.0f) == 0ull) { px = ls.x; py = ls.y; pz = ls.z; }   // orthographic sun: w == 1, x / 1 == x
+    else { px = ls.x / ls.w; py = ls.y / ls.w; pz = ls.z / ls.w; }
     px = px * 0.5f + 0.5f;
     py = py * 0.5f + 0.5f;
     py = 1.0f - py;
     if (pz > 1.0f || px < 0.0f || py < 0.0f || px > 1.0f || py > 1.0f) return 0.0f;
-    return shadow_generic(map, S, px, py, pz);
+    return S <= 5000u ? shadow_window(map, S, px, py, pz) : shadow_generic(map, S, px, py, pz);
 }
 
 // ---- forward.hlsl:126-193 -----------------------------------------------------------------------
@@ -229,7 +296,10 @@ __global__ __launch_bounds__(256) void k_shade(const ShadeParams sp) {
                 const f3 wi = d * inv;
                 const f3 radiance = mk(lc.x, lc.y, lc.z) * (inv * inv);
                 Lo = Lo + outgoing_radiance(s, wo, wi, radiance) * lit;
-                if (sp.light_evals && lane == 0) atomicAdd(sp.light_evals, (unsigned long long)__popcll(__ballot(1)));
+                if (sp.light_evals) {
+                    const unsigned long long active = __ballot(1);
+                    if (lane == (uint32_t)__ffsll((long long)active) - 1) atomicAdd(sp.light_evals, (unsigned long long)__popcll(active));
+                }
             }
         }
         color = Lo + s.base * sp.ambient;
