@@ -1,0 +1,15 @@
+# minimal program for rocprofv3: build config-3 G-buffer once, then launch k_shade a few times
+import sys, numpy as np
+sys.path.insert(0,'/root/repo')
+import __graft_entry__ as e
+pkg=e.load_package()
+mode=sys.argv[1] if len(sys.argv)>1 else "full"
+sc=pkg.scenes.CONFIGS[3](scale=1.0)
+r=sc.upload(pkg.Renderer(sc.width,sc.height,sc.shadow_size,sc.max_lights))
+r.pass_shadow_map(sc.desc); r.pass_gbuffer(sc.desc); r.flush()
+if mode=="nolights": r.update_lights(sc.lights[:0])
+if mode=="nocull": r.set_option("culling",0)
+for i in range(5):
+    r.pass_shade(sc.desc, sc.settings)
+r.flush()
+r.close()
