@@ -102,7 +102,10 @@ struct ShadeParams {
     float *out_hdr;              // optional rows*width*3
     unsigned long long *light_evals;  // optional counter
     int32_t culling;
+    int32_t desc_in_lds;         // texture descriptors staged in LDS (n_materials <= MAX_LDS_MATERIALS)
 };
+constexpr uint32_t MAX_LDS_MATERIALS = 512;   // 24 KiB of descriptors
+constexpr uint32_t MAX_SHADE_LIGHTS = 2048;    // 48 KiB of light pairs in LDS
 
 // ---- kernel launchers (geometry.hip, shade.hip) ---------------------------------------------
 // every launcher enqueues on `s` and returns the launch error, never synchronises.
@@ -122,7 +125,8 @@ hipError_t launch_resolve(const unsigned long long *vis, const SetupRec *recs, c
                           const GeomParams *gp, uint32_t n_tiles, GBuffer g, float *depth_out, uint32_t *src_out, hipStream_t s);
 hipError_t launch_fill_u64(unsigned long long *p, unsigned long long v, size_t n, hipStream_t s);
 hipError_t launch_fill_u32(uint32_t *p, uint32_t v, size_t n, hipStream_t s);
-hipError_t launch_shade(const ShadeParams &sp, hipStream_t s);
+hipError_t launch_shade(const ShadeParams &sp, uint32_t max_blocks, hipStream_t s);
+size_t shade_lds_bytes(const ShadeParams &sp);
 hipError_t launch_post_process(const float4 *hdr, uint32_t w, uint32_t h, int32_t tm, float inv_gamma, float exposure,
                                uint8_t *rgba8, float *ldr, hipStream_t s);
 hipError_t launch_gbuffer_tile(GBuffer g, float *attrs, uint32_t *mat, uint32_t width, uint32_t rows,

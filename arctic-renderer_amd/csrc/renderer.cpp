@@ -62,6 +62,7 @@ struct ArcticRenderer {
         d_recs, d_tile_count, d_tile_offset, d_scan, d_gp, d_stage;
     uint64_t stats[6] = {0, 0, 0, 0, 0, 0};
     int keep_float = 0, count_evals = 0, culling = 1;
+    uint32_t shade_blocks = 1024;   // persistent grid of k_shade: CUs x blocks per CU
     std::string err;
 
     int fail(int code, const char *fmt, ...) {
@@ -269,6 +270,7 @@ int fill_shade_params(ArcticRenderer *r, const ArcticScene *sc, const ArcticSett
     }
     sp.light_evals = r->count_evals ? r->d_counter.as<unsigned long long>() : nullptr;
     sp.culling = r->culling;
+    sp.desc_in_lds = sp.n_materials <= MAX_LDS_MATERIALS;
     return ARCTIC_OK;
 }
 
@@ -277,7 +279,7 @@ int pass_shade(ArcticRenderer *r, const ArcticScene *sc, const ArcticSettings *s
     int rc = fill_shade_params(r, sc, st, d_out, sp);
     if (rc != ARCTIC_OK) return rc;
     if (sp.light_evals) HIPCHECK(r, hipMemsetAsync(r->d_counter.p, 0, 8, r->stream));
-    HIPCHECK(r, launch_shade(sp, r->stream));
+    HIPCHECK(r, launch_shade(sp, r->shade_blocks, r->stream));
     if (sp.light_evals) {
         unsigned long long n = 0;
         HIPCHECK(r, hipMemcpyAsync(&n, r->d_counter.p, 8, hipMemcpyDeviceToHost, r->stream));
@@ -320,6 +322,11 @@ ArcticRenderer *arctic_create(const ArcticCreateInfo *info, char *err, uint64_t 
     hipError_t e;
     if ((e = hipSetDevice(r->device)) != hipSuccess) return bail("hipSetDevice", e);
     if ((e = hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    {
+        hipDeviceProp_t prop;
+        if ((e = hipGetDeviceProperties(&prop, r->device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
+        r->shade_blocks = (uint32_t)std::max(1, prop.multiProcessorCount) * 4;   // 4 workgroups of 4 waves per CU
+    }
     float lut[256];
     for (int i = 0; i < 256; ++i) lut[i] = srgb8_to_linear(i);
     if ((e = r->d_lut.ensure(sizeof lut)) != hipSuccess) return bail("hipMalloc lut", e);
@@ -419,6 +426,7 @@ int arctic_update_lights(ArcticRenderer *r, const ArcticPointLight *lights, uint
     int rc = select_device(r);
     if (rc) return rc;
     uint32_t k = (uint32_t)std::min<uint64_t>(n, r->max_lights);   // renderer.cpp:587-588
+    if (k > MAX_SHADE_LIGHTS) return r->fail(ARCTIC_E_CAPACITY, "update_lights: %u lights exceed the %u the shading kernel stages in LDS", k, MAX_SHADE_LIGHTS);
     HIPCHECK(r, hipStreamSynchronize(r->stream));
     if (k) HIPCHECK(r, hipMemcpy(r->d_lights.p, lights, (size_t)k * sizeof(ArcticPointLight), hipMemcpyHostToDevice));
     r->n_lights = k;
@@ -499,12 +507,12 @@ int arctic_time_shade(ArcticRenderer *r, const ArcticScene *scene, const ArcticS
     ShadeParams sp;
     if ((rc = fill_shade_params(r, scene, settings, nullptr, sp)) != ARCTIC_OK) return rc;
     sp.light_evals = nullptr;
-    for (uint32_t i = 0; i < warmup; ++i) HIPCHECK(r, launch_shade(sp, r->stream));
+    for (uint32_t i = 0; i < warmup; ++i) HIPCHECK(r, launch_shade(sp, r->shade_blocks, r->stream));
     std::vector<hipEvent_t> ev(2 * (size_t)iters);
     for (auto &e : ev) HIPCHECK(r, hipEventCreate(&e));
     for (uint32_t i = 0; i < iters; ++i) {
         HIPCHECK(r, hipEventRecord(ev[2 * i], r->stream));
-        HIPCHECK(r, launch_shade(sp, r->stream));
+        HIPCHECK(r, launch_shade(sp, r->shade_blocks, r->stream));
         HIPCHECK(r, hipEventRecord(ev[2 * i + 1], r->stream));
     }
     HIPCHECK(r, hipStreamSynchronize(r->stream));

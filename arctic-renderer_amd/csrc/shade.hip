@@ -36,7 +36,7 @@ __device__ __forceinline__ float pow_fast(float x, float e) {   // x >= 0
     return __builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf(x));
 }
 
-constexpr float PI = 3.14159265f;   // forward.hlsl:1
+// PI = 3.14159265 as written at forward.hlsl:1
 constexpr float INV_PI = 1.0f / 3.14159265f;
 
 // ---- sampler: MIN_MAG_MIP_LINEAR + WRAP (forward_pass.cpp:38-51), texel centres at +0.5 ----------
@@ -177,30 +177,96 @@ __device__ __forceinline__ float calculate_shadow(const float *__restrict__ map,
 }
 
 // ---- forward.hlsl:126-193 -----------------------------------------------------------------------
-struct Surface { f3 base, n; float metal, rough; };
+// calculate_outgoing_radiance with everything that does not depend on the light hoisted into Pix,
+// written once for T = float (the sun) and T = v2 (TWO point lights per pass in the packed
+// v_pk_{fma,mul,add}_f32 forms: the only way to reach gfx950's 157 TFLOP/s FP32 vector rate).
+typedef float v2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ f3 outgoing_radiance(const Surface &s, f3 wo, f3 wi, f3 Li) {
-    f3 h = normalize(wo + wi);
-    float ndwo = fmaxf(dot(s.n, wo), 0.0f), ndwi = fmaxf(dot(s.n, wi), 0.0f);
-    float ndh = fmaxf(dot(s.n, h), 0.0f), hdwo = fmaxf(dot(h, wo), 0.0f);
-    // fresnel_schlick :126-129
-    f3 F0 = mk(0.04f + s.metal * (s.base.x - 0.04f), 0.04f + s.metal * (s.base.y - 0.04f), 0.04f + s.metal * (s.base.z - 0.04f));
-    float m = sat(1.0f - hdwo), m2 = m * m, p5 = m2 * m2 * m;
-    f3 F = mk(F0.x + (1.0f - F0.x) * p5, F0.y + (1.0f - F0.y) * p5, F0.z + (1.0f - F0.z) * p5);
-    // distribution_ggx :131-143
-    float a = s.rough * s.rough, a2 = a * a;
-    float d = ndh * ndh * (a2 - 1.0f) + 1.0f;
-    float NDF = a2 * rcp(PI * d * d);
-    // geometry_smith :145-163
-    float r1 = s.rough + 1.0f, k = r1 * r1 * 0.125f;
-    float G = ndwo * rcp(ndwo * (1.0f - k) + k) * ndwi * rcp(ndwi * (1.0f - k) + k);
-    // brdf_cook_torrance :165-175
-    float spec = NDF * G * rcp(4.0f * ndwo * ndwi + 0.0001f);
-    // calculate_outgoing_radiance :177-193
-    float km = 1.0f - s.metal;
-    f3 kD = mk((1.0f - F.x) * km, (1.0f - F.y) * km, (1.0f - F.z) * km);
-    f3 c = mk(kD.x * s.base.x * INV_PI + spec * F.x, kD.y * s.base.y * INV_PI + spec * F.y, kD.z * s.base.z * INV_PI + spec * F.z);
-    return c * Li * ndwi;
+template <class T> __device__ __forceinline__ T splat(float x);
+template <> __device__ __forceinline__ float splat<float>(float x) { return x; }
+template <> __device__ __forceinline__ v2 splat<v2>(float x) { v2 r = {x, x}; return r; }
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ v2 fma_t(v2 a, v2 b, v2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ float max0(float a) { return fmaxf(a, 0.0f); }
+__device__ __forceinline__ v2 max0(v2 a) { v2 r = {fmaxf(a.x, 0.0f), fmaxf(a.y, 0.0f)}; return r; }
+__device__ __forceinline__ float maxf_t(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ v2 maxf_t(v2 a, float b) { v2 r = {fmaxf(a.x, b), fmaxf(a.y, b)}; return r; }
+__device__ __forceinline__ float sat_t(float a) { return sat(a); }
+__device__ __forceinline__ v2 sat_t(v2 a) { v2 r = {sat(a.x), sat(a.y)}; return r; }
+__device__ __forceinline__ float rsq_t(float a) { return rsq(a); }
+__device__ __forceinline__ v2 rsq_t(v2 a) { v2 r = {rsq(a.x), rsq(a.y)}; return r; }
+__device__ __forceinline__ float sqrt_t(float a) { return __builtin_amdgcn_sqrtf(a); }
+__device__ __forceinline__ v2 sqrt_t(v2 a) { v2 r = {__builtin_amdgcn_sqrtf(a.x), __builtin_amdgcn_sqrtf(a.y)}; return r; }
+__device__ __forceinline__ float sel_pos(float c, float a, float b) { return c > 0.0f ? a : b; }
+__device__ __forceinline__ v2 sel_pos(v2 c, v2 a, v2 b) { v2 r = {c.x > 0.0f ? a.x : b.x, c.y > 0.0f ? a.y : b.y}; return r; }
+__device__ __forceinline__ float rcp_t(float a) { return rcp(a); }
+__device__ __forceinline__ v2 rcp_t(v2 a) { v2 r = {rcp(a.x), rcp(a.y)}; return r; }
+
+struct Pix {
+    f3 n, wo, world;
+    f3 F0, omF0;          // F0 = lerp(0.04, base, metal), 1 - F0                              (:181-182, :128)
+    f3 kdb;               // (1 - metal) * base / PI: kD * base / PI = kdb - F * kdb            (:187-192)
+    float a2, oma2;       // roughness^4, 1 - roughness^4                                        (:133-139)
+    float k, omk;         // k = (roughness + 1)^2 / 8, 1 - k                                    (:147-148)
+    float num;            // a2 * g(n.wo) / PI: the light-independent factor of NDF * G          (:131-163)
+    float four_ndwo;      // 4 * max(n.wo, 0)                                                    (:172)
+    float lit;            // 1 - shadow
+};
+
+__device__ __forceinline__ Pix make_pix(f3 n, f3 wo, f3 world, f3 base, float metal, float rough, float lit) {
+    Pix p;
+    p.n = n; p.wo = wo; p.world = world; p.lit = lit;
+    p.F0 = mk(0.04f + metal * (base.x - 0.04f), 0.04f + metal * (base.y - 0.04f), 0.04f + metal * (base.z - 0.04f));
+    p.omF0 = mk(1.0f - p.F0.x, 1.0f - p.F0.y, 1.0f - p.F0.z);
+    const float km = (1.0f - metal) * INV_PI;
+    p.kdb = mk(base.x * km, base.y * km, base.z * km);
+    const float ndwo = fmaxf(dot(n, wo), 0.0f);
+    const float a = rough * rough, a2 = a * a;
+    p.a2 = a2; p.oma2 = 1.0f - a2;
+    const float r1 = rough + 1.0f;
+    p.k = r1 * r1 * 0.125f;
+    p.omk = 1.0f - p.k;
+    p.num = a2 * INV_PI * ndwo * rcp(ndwo * p.omk + p.k);
+    p.four_ndwo = 4.0f * ndwo;
+    return p;
+}
+
+// radiance reflected towards wo from light direction d (unnormalised, towards the light) with colour (cr,cg,cb);
+// POINT: radiance = colour / |d|^2 (forward.hlsl:226-229); otherwise d is already unit and there is no falloff.
+// nd = n . d is passed in because the culling test has already computed it.  Accumulates into (ar, ag, ab).
+template <class T, bool POINT>
+__device__ __forceinline__ void accumulate_light(const Pix &p, T dx, T dy, T dz, T nd, T cr, T cg, T cb, T &ar, T &ag, T &ab) {
+    const T one = splat<T>(1.0f);
+    T inv = one, sc = splat<T>(p.lit);
+    if (POINT) {
+        const T d2 = fma_t(dz, dz, fma_t(dy, dy, dx * dx));
+        inv = rsq_t(d2);
+        sc = sc * inv * inv;
+    }
+    const T ndwi = max0(nd * inv);                                                    // max(n . wi, 0)
+    // h = normalize(wo + wi), formed component-wise like the HLSL: when wi is nearly opposite to wo the sum cancels,
+    // and only the same cancellation keeps the result within rounding distance of the fp32 oracle
+    const T hx = fma_t(dx, inv, splat<T>(p.wo.x)), hy = fma_t(dy, inv, splat<T>(p.wo.y)), hz = fma_t(dz, inv, splat<T>(p.wo.z));
+    const T ihh = rcp_t(fma_t(hz, hz, fma_t(hy, hy, hx * hx)));                          // 1 / |h|^2
+    const T nh = fma_t(splat<T>(p.n.z), hz, fma_t(splat<T>(p.n.y), hy, splat<T>(p.n.x) * hx));
+    const T hwo = fma_t(splat<T>(p.wo.z), hz, fma_t(splat<T>(p.wo.y), hy, splat<T>(p.wo.x) * hx));
+    const T m = sat_t(fma_t(-hwo, sqrt_t(ihh), one));                                    // clamp(1 - max(h . wo, 0), 0, 1)
+    const T m2 = m * m, p5 = m2 * m2 * m;
+    // distribution_ggx's denominator n_dot_h^2 * (a2 - 1) + 1 (forward.hlsl:137) cancels to ~a2 at a highlight; written
+    // as sin^2 * (1 - a2) + a2 with sin^2 = |n x h|^2 / |h|^2 it has no cancellation (same value in exact arithmetic)
+    const T cx = fma_t(splat<T>(p.n.y), hz, -(splat<T>(p.n.z) * hy)), cy = fma_t(splat<T>(p.n.z), hx, -(splat<T>(p.n.x) * hz)),
+            cz = fma_t(splat<T>(p.n.x), hy, -(splat<T>(p.n.y) * hx));
+    const T sin2 = fma_t(cz, cz, fma_t(cy, cy, cx * cx)) * ihh;
+    const T dd = sel_pos(nh, fma_t(sin2, splat<T>(p.oma2), splat<T>(p.a2)), one);   // n . h <= 0: max(n.h, 0) = 0, denominator 1
+    const T Fx = fma_t(splat<T>(p.omF0.x), p5, splat<T>(p.F0.x)), Fy = fma_t(splat<T>(p.omF0.y), p5, splat<T>(p.F0.y)),
+            Fz = fma_t(splat<T>(p.omF0.z), p5, splat<T>(p.F0.z));
+    const T den = (dd * dd) * fma_t(ndwi, splat<T>(p.omk), splat<T>(p.k)) * fma_t(ndwi, splat<T>(p.four_ndwo), splat<T>(0.0001f));
+    const T spec = (splat<T>(p.num) * ndwi) * rcp_t(den);                              // NDF * G / (4 n.wo n.wi + 1e-4)
+    sc = sc * ndwi;
+    const T kx = splat<T>(p.kdb.x), ky = splat<T>(p.kdb.y), kz = splat<T>(p.kdb.z);
+    ar = fma_t(fma_t(spec, Fx, fma_t(-Fx, kx, kx)), cr * sc, ar);
+    ag = fma_t(fma_t(spec, Fy, fma_t(-Fy, ky, ky)), cg * sc, ag);
+    ab = fma_t(fma_t(spec, Fz, fma_t(-Fz, kz, kz)), cb * sc, ab);
 }
 
 // ---- post_process.hlsl ---------------------------------------------------------------------------
@@ -234,82 +300,129 @@ __device__ __forceinline__ uint32_t unorm8(float x) {
     return (uint32_t)(x * 255.0f + 0.5f);
 }
 
-__global__ __launch_bounds__(256) void k_shade(const ShadeParams sp) {
-    __shared__ float lut[256];
+struct TileData { float4 q0, q1, q2, q3; float nx, ny, nz; };
+__device__ __forceinline__ TileData load_tile(const GBuffer &g, size_t idx) {
+    TileData t;
+    t.q0 = g.p0[idx]; t.q1 = g.p1[idx]; t.q2 = g.p2[idx]; t.q3 = g.p3[idx];
+    t.nx = g.p4[idx * 3]; t.ny = g.p4[idx * 3 + 1]; t.nz = g.p4[idx * 3 + 2];
+    return t;
+}
+
+// LDS image of one workgroup (dynamic):  [0,256) sRGB LUT | texture descriptors (4 dwords each, when they fit) |
+// point lights as PAIRS, 12 floats per pair {x0,x1, y0,y1, z0,z1, r0,r1, g0,g1, b0,b1} = 3 x ds_read_b128 (broadcast)
+__device__ __forceinline__ TexDesc lds_desc(const uint4 *d) {
+    const uint4 v = *d;
+    TexDesc t;
+    t.texels = reinterpret_cast<const uint32_t *>(((unsigned long long)v.y << 32) | v.x);
+    t.w = v.z; t.h = v.w;
+    return t;
+}
+
+// Persistent kernel: gridDim.x workgroups of 4 waves; the workgroup stages the constants into LDS once, then wave w
+// of block b shades tiles (k * gridDim.x + b) * 4 + w, k = 0, 1, ...: the 4 waves of a block always work on 4
+// horizontally adjacent tiles (their RGBA8 rows complete 128-byte lines together), and lit (expensive) screen
+// regions are dealt round-robin over all CUs.  The next tile's G-buffer is requested before the light loop of the
+// current one, so its HBM latency hides under the BRDF arithmetic.
+__global__ __launch_bounds__(256, 4) void k_shade(const ShadeParams sp) {
+    extern __shared__ __align__(16) float smem[];
+    float *lut = smem;
+    uint4 *ldesc = reinterpret_cast<uint4 *>(smem + 256);
+    const uint32_t n_desc = sp.desc_in_lds ? sp.n_materials * 3 : 0;
+    float4 *llights = reinterpret_cast<float4 *>(smem + 256 + 4 * n_desc);
+    const uint32_t n_pairs = (sp.n_lights + 1) >> 1;
+
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t n_tiles = sp.tiles_x * sp.tiles_y, stride = gridDim.x * 4;
+    uint32_t t = blockIdx.x * 4 + wave;
+    TileData cur;
+    if (t < n_tiles) cur = load_tile(sp.g, (size_t)t * 64 + lane);   // in flight while LDS is staged
+
     lut[threadIdx.x] = sp.srgb_lut[threadIdx.x];
+    for (uint32_t i = threadIdx.x; i < n_desc; i += 256) ldesc[i] = reinterpret_cast<const uint4 *>(sp.tex)[i];
+    for (uint32_t i = threadIdx.x; i < 2 * n_pairs; i += 256) {
+        float4 lp = make_float4(0.0f, 1.0e6f, 0.0f, 0.0f), lc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // pad: colour 0
+        if (i < sp.n_lights) { lp = sp.lights[2 * i]; lc = sp.lights[2 * i + 1]; }
+        float *dst = reinterpret_cast<float *>(llights) + (size_t)(i >> 1) * 12 + (i & 1);
+        dst[0] = lp.x; dst[2] = lp.y; dst[4] = lp.z; dst[6] = lc.x; dst[8] = lc.y; dst[10] = lc.z;
+    }
     __syncthreads();
 
-    const uint32_t bw = (sp.tiles_x + 1) >> 1;
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t tx = (blockIdx.x % bw) * 2 + (wave & 1), ty = (blockIdx.x / bw) * 2 + (wave >> 1);
-    if (tx >= sp.tiles_x || ty >= sp.tiles_y) return;
-    const size_t idx = ((size_t)ty * sp.tiles_x + tx) * 64 + lane;
-    const uint32_t x = tx * 8 + (lane & 7);
-    const int32_t y = (int32_t)(ty * 8 + (lane >> 3)) - (int32_t)sp.row0_in_tile;
-    const bool in_frame = x < sp.width && y >= 0 && y < (int32_t)sp.rows;
+    while (t < n_tiles) {
+        const uint32_t tx = t % sp.tiles_x, ty = t / sp.tiles_x;
+        const uint32_t x = tx * 8 + (lane & 7);
+        const int32_t y = (int32_t)(ty * 8 + (lane >> 3)) - (int32_t)sp.row0_in_tile;
+        const bool in_frame = x < sp.width && y >= 0 && y < (int32_t)sp.rows;
+        const float4 q0 = cur.q0, q1 = cur.q1, q2 = cur.q2, q3 = cur.q3;
+        const uint32_t mat = __float_as_uint(q0.w);
+        const bool covered = in_frame && mat < sp.n_materials;
 
-    const float4 q0 = sp.g.p0[idx], q1 = sp.g.p1[idx], q2 = sp.g.p2[idx], q3 = sp.g.p3[idx];
-    const float nx = sp.g.p4[idx * 3], ny = sp.g.p4[idx * 3 + 1], nz = sp.g.p4[idx * 3 + 2];
-    const uint32_t mat = __float_as_uint(q0.w);
-    const bool covered = in_frame && mat < sp.n_materials;
-
-    f3 color = mk(0.0f, 0.0f, 0.0f);
-    if (covered) {
-        // ---- material fetch, forward.hlsl:98-124 ------------------------------------------------
-        const TexDesc *td = sp.tex + (size_t)mat * 3;
-        const float u = q2.x, v = q2.y;
-        Surface s;
-        {
-            Taps t = fetch_taps(td[0], u, v);
-            s.base = mk(filt_srgb(t, 0, lut), filt_srgb(t, 1, lut), filt_srgb(t, 2, lut));
-        }
-        {
-            Taps t = fetch_taps(td[1], u, v);
-            float r = filt_unorm(t, 0), g = 1.0f - filt_unorm(t, 1), b = filt_unorm(t, 2);   // normal.g = 1 - normal.g
+        f3 base = mk(0.0f, 0.0f, 0.0f), n = mk(0.0f, 0.0f, 1.0f);
+        float metal = 0.0f, rough = 1.0f, lit = 0.0f;
+        if (covered) {
+            // ---- material fetch, forward.hlsl:98-124 --------------------------------------------
+            TexDesc d0, d1, d2;
+            if (sp.desc_in_lds) { d0 = lds_desc(ldesc + mat * 3); d1 = lds_desc(ldesc + mat * 3 + 1); d2 = lds_desc(ldesc + mat * 3 + 2); }
+            else { const TexDesc *td = sp.tex + (size_t)mat * 3; d0 = td[0]; d1 = td[1]; d2 = td[2]; }
+            const float u = q2.x, v = q2.y;
+            const Taps t0 = fetch_taps(d0, u, v), t1 = fetch_taps(d1, u, v), t2 = fetch_taps(d2, u, v);
+            lit = 1.0f - calculate_shadow(sp.shadow_map, sp.shadow_size, q1);
+            base = mk(filt_srgb(t0, 0, lut), filt_srgb(t0, 1, lut), filt_srgb(t0, 2, lut));
+            float r = filt_unorm(t1, 0), g = 1.0f - filt_unorm(t1, 1), b = filt_unorm(t1, 2);   // normal.g = 1 - normal.g
             r = r * 2.0f - 1.0f; g = g * 2.0f - 1.0f; b = b * 2.0f - 1.0f;
             // mul(tbn, v), tbn columns t, b, n
-            f3 T = mk(q2.z, q2.w, q3.x), B = mk(q3.y, q3.z, q3.w), N = mk(nx, ny, nz);
-            s.n = normalize(T * r + B * g + N * b);
-        }
-        {
-            Taps t = fetch_taps(td[2], u, v);
-            s.rough = filt_unorm(t, 1);   // .g
-            s.metal = filt_unorm(t, 2);   // .b
+            const f3 T = mk(q2.z, q2.w, q3.x), B = mk(q3.y, q3.z, q3.w), N = mk(cur.nx, cur.ny, cur.nz);
+            n = normalize(T * r + B * g + N * b);
+            rough = filt_unorm(t2, 1);   // .g
+            metal = filt_unorm(t2, 2);   // .b
         }
         const f3 world = mk(q0.x, q0.y, q0.z);
-        const f3 wo = normalize(mk(sp.eye[0], sp.eye[1], sp.eye[2]) - world);
-        const float shadow = calculate_shadow(sp.shadow_map, sp.shadow_size, q1);
-        const float lit = 1.0f - shadow;
-        f3 Lo = mk(0.0f, 0.0f, 0.0f);
-        // exact culling: everything below is multiplied by (1 - shadow) (point lights too: forward.hlsl:230),
-        // so a wave whose pixels are all fully shadowed skips the sun and the whole light loop
-        const bool wave_lit = !sp.culling || __ballot(lit != 0.0f) != 0ull;
-        if (wave_lit) {
-            Lo = outgoing_radiance(s, wo, mk(-sp.sun_dir[0], -sp.sun_dir[1], -sp.sun_dir[2]),
-                                   mk(sp.sun_color[0], sp.sun_color[1], sp.sun_color[2])) * lit;
-            for (uint32_t i = 0; i < sp.n_lights; ++i) {
-                const float4 lp = sp.lights[2 * i], lc = sp.lights[2 * i + 1];
-                const f3 d = mk(lp.x, lp.y, lp.z) - world;
-                // exact culling: n.wi <= 0 zeroes the light (forward.hlsl:191-192); skip it when that holds wave-wide
-                if (sp.culling && __ballot(lit != 0.0f && dot(s.n, d) > 0.0f) == 0ull) continue;
-                const float d2 = dot(d, d), inv = rsq(d2);
-                const f3 wi = d * inv;
-                const f3 radiance = mk(lc.x, lc.y, lc.z) * (inv * inv);
-                Lo = Lo + outgoing_radiance(s, wo, wi, radiance) * lit;
+
+        // request the next tile now: nothing below touches `cur` any more
+        const uint32_t tn = t + stride;
+        if (tn < n_tiles) cur = load_tile(sp.g, (size_t)tn * 64 + lane);
+
+        f3 color = mk(0.0f, 0.0f, 0.0f);
+        // exact culling 1: every light term is multiplied by (1 - shadow) (point lights too: forward.hlsl:230), so a
+        // wave with no covered, not fully shadowed pixel skips the sun and the whole light loop
+        const bool live = covered && lit != 0.0f;
+        if (__ballot(sp.culling ? live : covered) != 0ull) {
+            const f3 wo = normalize(mk(sp.eye[0], sp.eye[1], sp.eye[2]) - world);
+            const Pix px = make_pix(n, wo, world, base, metal, rough, covered ? lit : 0.0f);
+            float sr = 0.0f, sg = 0.0f, sb = 0.0f;
+            {   // the sun: wi = -sun_dir, radiance = sun_color (forward.hlsl:221-222)
+                const float dx = -sp.sun_dir[0], dy = -sp.sun_dir[1], dz = -sp.sun_dir[2];
+                const float nd = n.x * dx + n.y * dy + n.z * dz;
+                accumulate_light<float, false>(px, dx, dy, dz, nd, sp.sun_color[0], sp.sun_color[1], sp.sun_color[2], sr, sg, sb);
+            }
+            v2 ar = {sr, 0.0f}, ag = {sg, 0.0f}, ab = {sb, 0.0f};
+            const v2 wx = splat<v2>(world.x), wy = splat<v2>(world.y), wz = splat<v2>(world.z);
+            for (uint32_t p = 0; p < n_pairs; ++p) {
+                const float4 A = llights[3 * p], Bq = llights[3 * p + 1], C = llights[3 * p + 2];
+                const v2 dx = (v2){A.x, A.y} - wx, dy = (v2){A.z, A.w} - wy, dz = (v2){Bq.x, Bq.y} - wz;
+                const v2 nd = fma_t(splat<v2>(n.z), dz, fma_t(splat<v2>(n.y), dy, splat<v2>(n.x) * dx));
+                // exact culling 2: n.wi <= 0 zeroes a light (forward.hlsl:191-192); skip the pair when that holds for
+                // both lights in every live lane of the wave
+                if (sp.culling && __ballot(live && (nd.x > 0.0f || nd.y > 0.0f)) == 0ull) continue;
+                accumulate_light<v2, true>(px, dx, dy, dz, nd, (v2){Bq.z, Bq.w}, (v2){C.x, C.y}, (v2){C.z, C.w}, ar, ag, ab);
                 if (sp.light_evals) {
                     const unsigned long long active = __ballot(1);
-                    if (lane == (uint32_t)__ffsll((long long)active) - 1) atomicAdd(sp.light_evals, (unsigned long long)__popcll(active));
+                    const uint32_t k = (2 * p + 1 < sp.n_lights) ? 2u : 1u;
+                    if (lane == (uint32_t)__ffsll((long long)active) - 1) atomicAdd(sp.light_evals, (unsigned long long)__popcll(active) * k);
                 }
             }
+            color = mk(ar.x + ar.y, ag.x + ag.y, ab.x + ab.y);
         }
-        color = Lo + s.base * sp.ambient;
+        if (covered) color = color + base * sp.ambient;
+        if (in_frame) {
+            const f3 l = post_process(color, sp.tm_method, sp.inv_gamma, sp.exposure);
+            const size_t o = (size_t)y * sp.width + x;
+            reinterpret_cast<uint32_t *>(sp.out_rgba8)[o] = unorm8(l.x) | (unorm8(l.y) << 8) | (unorm8(l.z) << 16) | 0xFF000000u;
+            if (sp.out_ldr) { sp.out_ldr[o * 3] = l.x; sp.out_ldr[o * 3 + 1] = l.y; sp.out_ldr[o * 3 + 2] = l.z; }
+            if (sp.out_hdr) { sp.out_hdr[o * 3] = color.x; sp.out_hdr[o * 3 + 1] = color.y; sp.out_hdr[o * 3 + 2] = color.z; }
+        }
+        t = tn;
     }
-    if (!in_frame) return;
-    const f3 l = post_process(color, sp.tm_method, sp.inv_gamma, sp.exposure);
-    const size_t p = (size_t)y * sp.width + x;
-    reinterpret_cast<uint32_t *>(sp.out_rgba8)[p] = unorm8(l.x) | (unorm8(l.y) << 8) | (unorm8(l.z) << 16) | 0xFF000000u;
-    if (sp.out_ldr) { sp.out_ldr[p * 3] = l.x; sp.out_ldr[p * 3 + 1] = l.y; sp.out_ldr[p * 3 + 2] = l.z; }
-    if (sp.out_hdr) { sp.out_hdr[p * 3] = color.x; sp.out_hdr[p * 3 + 1] = color.y; sp.out_hdr[p * 3 + 2] = color.z; }
 }
 
 // PostProcessPass::run alone (post_process_pass.cpp:73-95): float RGBA in, RGBA8 (+ optional float rgb) out
@@ -325,10 +438,15 @@ __global__ __launch_bounds__(256) void k_post_process(const float4 *__restrict__
 
 }  // namespace
 
-hipError_t launch_shade(const ShadeParams &sp, hipStream_t s) {
-    uint32_t bw = (sp.tiles_x + 1) / 2, bh = (sp.tiles_y + 1) / 2;
-    if (bw * bh == 0) return hipSuccess;
-    k_shade<<<bw * bh, 256, 0, s>>>(sp);
+size_t shade_lds_bytes(const ShadeParams &sp) {
+    return (256 + (sp.desc_in_lds ? (size_t)sp.n_materials * 12 : 0) + (size_t)((sp.n_lights + 1) / 2) * 12) * sizeof(float);
+}
+
+hipError_t launch_shade(const ShadeParams &sp, uint32_t max_blocks, hipStream_t s) {
+    uint32_t n_tiles = sp.tiles_x * sp.tiles_y;
+    if (n_tiles == 0) return hipSuccess;
+    uint32_t blocks = std::min((n_tiles + 3) / 4, max_blocks);
+    k_shade<<<blocks, 256, shade_lds_bytes(sp), s>>>(sp);
     return hipGetLastError();
 }
 

@@ -359,6 +359,7 @@ struct Oracle {
     std::vector<uint8_t> rgba8;     // rows*width*4
     float srgb_lut[256];
     uint64_t stats[6] = {0, 0, 0, 0, 0, 0};
+    int precision = 64;   // arithmetic of the BRDF/tonemap: 64 = float64 (parity arbiter), 32 = literal fp32 (CPU baseline)
     std::string err;
     uint32_t rows() const { return row_end - row_begin; }
 };
@@ -493,18 +494,6 @@ float srgb_to_linear(uint8_t c) {
     float x = (float)c / 255.0f;
     return x <= 0.04045f ? x / 12.92f : std::pow((x + 0.055f) / 1.055f, 2.4f);
 }
-// returns rgba; srgb applies to rgb only
-void sample_rgba8(const Oracle &o, const Texture &t, float u, float v, bool srgb, float out[4]) {
-    Footprint f = footprint(u, v, t.w, t.h);
-    const uint8_t *p00 = &t.px[((size_t)f.y0 * t.w + f.x0) * 4], *p10 = &t.px[((size_t)f.y0 * t.w + f.x1) * 4];
-    const uint8_t *p01 = &t.px[((size_t)f.y1 * t.w + f.x0) * 4], *p11 = &t.px[((size_t)f.y1 * t.w + f.x1) * 4];
-    for (int c = 0; c < 4; ++c) {
-        float a, b, cc, d;
-        if (srgb && c < 3) { a = o.srgb_lut[p00[c]]; b = o.srgb_lut[p10[c]]; cc = o.srgb_lut[p01[c]]; d = o.srgb_lut[p11[c]]; }
-        else { a = (float)p00[c] / 255.0f; b = (float)p10[c] / 255.0f; cc = (float)p01[c] / 255.0f; d = (float)p11[c] / 255.0f; }
-        out[c] = bilerp(a, b, cc, d, f.fx, f.fy);
-    }
-}
 float sample_r32(const float *map, uint32_t S, float u, float v) {
     Footprint f = footprint(u, v, S, S);
     return bilerp(map[(size_t)f.y0 * S + f.x0], map[(size_t)f.y0 * S + f.x1],
@@ -533,128 +522,174 @@ float calculate_shadow(const float *map, uint32_t S, V4 ls) {
 }
 
 // ----------------------------------------------------------------------------
-// BRDF: forward.hlsl:126-193.  PI as written at forward.hlsl:1.
+// BRDF + tonemap, templated on the real type R.
+//   R = float : the literal fp32 restatement of the HLSL (every operation rounds to fp32, in
+//               source order).  Timed as the CPU baseline; its output carries fp32 rounding noise.
+//   R = double: the same formulas evaluated in float64 on the same fp32 inputs = the value the
+//               HLSL text defines, free of implementation-specific rounding.  THIS is what the
+//               parity tests compare the HIP kernel against.
+// Why both: forward.hlsl:137 computes denom = n_dot_h^2 * (a2 - 1) + 1, which cancels to ~a2 at a
+// highlight; with roughness 0.05 (a2 = 6e-6) one fp32 ulp of n_dot_h moves the NDF by > 1 %, so two
+// equally valid fp32 evaluation orders (this file's, DXC's on some GPU, the HIP kernel's) differ by
+// up to ~1e-3 after tonemapping on a handful of highlight pixels.  Against the float64 value a
+// well-conditioned fp32 kernel can be held to 1e-4 everywhere; tests/test_oracle_kat.py also
+// bounds |fp32 oracle - float64 oracle| to document that noise floor.
+// Discrete decisions (texel addresses and weights, the 25 shadow compares, coverage) are always
+// taken in fp32 exactly as above, for both R.
+// PI as written at forward.hlsl:1.
 // ----------------------------------------------------------------------------
-constexpr float PI = 3.14159265f;
+template <class R> struct Vec3 { R x, y, z; };
+template <class R> inline Vec3<R> vec3(R x, R y, R z) { return Vec3<R>{x, y, z}; }
+template <class R> inline Vec3<R> operator+(Vec3<R> a, Vec3<R> b) { return vec3<R>(a.x + b.x, a.y + b.y, a.z + b.z); }
+template <class R> inline Vec3<R> operator-(Vec3<R> a, Vec3<R> b) { return vec3<R>(a.x - b.x, a.y - b.y, a.z - b.z); }
+template <class R> inline Vec3<R> operator*(Vec3<R> a, Vec3<R> b) { return vec3<R>(a.x * b.x, a.y * b.y, a.z * b.z); }
+template <class R> inline Vec3<R> operator*(Vec3<R> a, R s) { return vec3<R>(a.x * s, a.y * s, a.z * s); }
+template <class R> inline Vec3<R> operator/(Vec3<R> a, R s) { return vec3<R>(a.x / s, a.y / s, a.z / s); }
+template <class R> inline R dot(Vec3<R> a, Vec3<R> b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+template <class R> inline Vec3<R> normalize(Vec3<R> v) { R inv = R(1) / std::sqrt(dot(v, v)); return v * inv; }
+template <class R> inline R rmax(R a, R b) { return a > b ? a : b; }   // max(x, 0) of finite values
+template <class R> inline R rclamp01(R x) { return x < R(0) ? R(0) : (x > R(1) ? R(1) : x); }
+inline float rlerp(float a, float b, float t) { return std::fmaf(t, b - a, a); }   // HLSL lerp as one mad
+inline double rlerp(double a, double b, double t) { return a + t * (b - a); }
+template <class R> constexpr R PI_R = R(3.14159265);   // the literal of forward.hlsl:1 (as double, then as float)
 
 // forward.hlsl:126-129 (cos_theta is a scalar broadcast to float3)
-inline V3 fresnel_schlick(float cos_theta, V3 F0) {
-    float p = std::pow(clamp01(1.0f - cos_theta), 5.0f);
-    return v3(F0.x + (1.0f - F0.x) * p, F0.y + (1.0f - F0.y) * p, F0.z + (1.0f - F0.z) * p);
+template <class R> inline Vec3<R> fresnel_schlick(R cos_theta, Vec3<R> F0) {
+    R p = std::pow(rclamp01<R>(R(1) - cos_theta), R(5));
+    return vec3<R>(F0.x + (R(1) - F0.x) * p, F0.y + (R(1) - F0.y) * p, F0.z + (R(1) - F0.z) * p);
 }
 // forward.hlsl:131-143
-inline float distribution_ggx(V3 n, V3 h, float roughness) {
-    float a = roughness * roughness;
-    float a2 = a * a;
-    float ndh = std::fmax(dot(n, h), 0.0f);
-    float ndh2 = ndh * ndh;
-    float denom = ndh2 * (a2 - 1.0f) + 1.0f;
-    denom = PI * denom * denom;
+template <class R> inline R distribution_ggx(Vec3<R> n, Vec3<R> h, R roughness) {
+    R a = roughness * roughness;
+    R a2 = a * a;
+    R ndh = rmax<R>(dot(n, h), R(0));
+    R ndh2 = ndh * ndh;
+    R denom = ndh2 * (a2 - R(1)) + R(1);
+    denom = PI_R<R> * denom * denom;
     return a2 / denom;
 }
 // forward.hlsl:145-154
-inline float geometry_schlick_ggx(float ndwo, float roughness) {
-    float r = roughness + 1.0f;
-    float k = (r * r) / 8.0f;
-    return ndwo / (ndwo * (1.0f - k) + k);
+template <class R> inline R geometry_schlick_ggx(R ndwo, R roughness) {
+    R r = roughness + R(1);
+    R k = (r * r) / R(8);
+    return ndwo / (ndwo * (R(1) - k) + k);
 }
 // forward.hlsl:156-163
-inline float geometry_smith(V3 n, V3 wo, V3 wi, float roughness) {
-    float ndwo = std::fmax(dot(n, wo), 0.0f), ndwi = std::fmax(dot(n, wi), 0.0f);
+template <class R> inline R geometry_smith(Vec3<R> n, Vec3<R> wo, Vec3<R> wi, R roughness) {
+    R ndwo = rmax<R>(dot(n, wo), R(0)), ndwi = rmax<R>(dot(n, wi), R(0));
     return geometry_schlick_ggx(ndwo, roughness) * geometry_schlick_ggx(ndwi, roughness);
 }
 // forward.hlsl:165-175
-inline V3 brdf_cook_torrance(V3 n, V3 h, V3 wo, V3 wi, float roughness, V3 F) {
-    float NDF = distribution_ggx(n, h, roughness);
-    float G = geometry_smith(n, wo, wi, roughness);
-    V3 num = scale(F, NDF * G);
-    float denom = 4.0f * std::fmax(dot(n, wo), 0.0f) * std::fmax(dot(n, wi), 0.0f) + 0.0001f;
-    return divs(num, denom);
+template <class R> inline Vec3<R> brdf_cook_torrance(Vec3<R> n, Vec3<R> h, Vec3<R> wo, Vec3<R> wi, R roughness, Vec3<R> F) {
+    R NDF = distribution_ggx(n, h, roughness);
+    R G = geometry_smith(n, wo, wi, roughness);
+    Vec3<R> num = F * (NDF * G);
+    R denom = R(4) * rmax<R>(dot(n, wo), R(0)) * rmax<R>(dot(n, wi), R(0)) + R(0.0001f);
+    return num / denom;
 }
 // forward.hlsl:177-193
-V3 calculate_outgoing_radiance(V3 n, V3 wo, V3 wi, V3 Li, V3 base, float metal, float rough) {
-    V3 h = normalize(add(wo, wi));
-    V3 F0 = v3(lerp1(0.04f, base.x, metal), lerp1(0.04f, base.y, metal), lerp1(0.04f, base.z, metal));
-    V3 F = fresnel_schlick(std::fmax(dot(h, wo), 0.0f), F0);
-    V3 spec = brdf_cook_torrance(n, h, wo, wi, rough, F);
-    V3 kD = v3(1.0f - F.x, 1.0f - F.y, 1.0f - F.z);
-    kD = scale(kD, 1.0f - metal);
-    float ndwi = std::fmax(dot(n, wi), 0.0f);
-    V3 diff = divs(mul(kD, base), PI);
-    return scale(mul(add(diff, spec), Li), ndwi);
+template <class R> Vec3<R> calculate_outgoing_radiance(Vec3<R> n, Vec3<R> wo, Vec3<R> wi, Vec3<R> Li, Vec3<R> base, R metal, R rough) {
+    Vec3<R> h = normalize(wo + wi);
+    Vec3<R> F0 = vec3<R>(rlerp(R(0.04f), base.x, metal), rlerp(R(0.04f), base.y, metal), rlerp(R(0.04f), base.z, metal));
+    Vec3<R> F = fresnel_schlick(rmax<R>(dot(h, wo), R(0)), F0);
+    Vec3<R> spec = brdf_cook_torrance(n, h, wo, wi, rough, F);
+    Vec3<R> kD = vec3<R>(R(1) - F.x, R(1) - F.y, R(1) - F.z);
+    kD = kD * (R(1) - metal);
+    R ndwi = rmax<R>(dot(n, wi), R(0));
+    Vec3<R> diff = (kD * base) / PI_R<R>;
+    return ((diff + spec) * Li) * ndwi;
+}
+
+// filtered RGBA of one material texture; texel selection and weights in fp32 (shared with the HIP kernel), the
+// filter arithmetic in R
+template <class R> void sample_rgba8_r(const Oracle &o, const Texture &t, float u, float v, bool srgb, R out[4]) {
+    Footprint f = footprint(u, v, t.w, t.h);
+    const uint8_t *p00 = &t.px[((size_t)f.y0 * t.w + f.x0) * 4], *p10 = &t.px[((size_t)f.y0 * t.w + f.x1) * 4];
+    const uint8_t *p01 = &t.px[((size_t)f.y1 * t.w + f.x0) * 4], *p11 = &t.px[((size_t)f.y1 * t.w + f.x1) * 4];
+    for (int c = 0; c < 4; ++c) {
+        R a, b, cc, d;
+        if (srgb && c < 3) { a = o.srgb_lut[p00[c]]; b = o.srgb_lut[p10[c]]; cc = o.srgb_lut[p01[c]]; d = o.srgb_lut[p11[c]]; }
+        else { a = (R)p00[c] / R(255); b = (R)p10[c] / R(255); cc = (R)p01[c] / R(255); d = (R)p11[c] / R(255); }
+        R top = rlerp(a, b, (R)f.fx), bot = rlerp(cc, d, (R)f.fx);
+        out[c] = rlerp(top, bot, (R)f.fy);
+    }
 }
 
 // forward.hlsl:98-124 material fetch
-struct Surface { V3 base, n; float metal, rough; };
-Surface fetch_surface(const Oracle &o, const MaterialData &m, const float *attr) {
+template <class R> struct SurfaceR { Vec3<R> base, n; R metal, rough; };
+template <class R> SurfaceR<R> fetch_surface(const Oracle &o, const MaterialData &m, const float *attr) {
     float u = attr[0], v = attr[1];
-    float d[4], nm[4], mr[4];
-    sample_rgba8(o, m.diffuse, u, v, true, d);
-    sample_rgba8(o, m.normal, u, v, false, nm);
-    sample_rgba8(o, m.mr, u, v, false, mr);
-    Surface s;
-    s.base = v3(d[0], d[1], d[2]);
-    V3 tn = v3(nm[0], 1.0f - nm[1], nm[2]);                      // normal.g = 1 - normal.g
-    tn = v3(tn.x * 2.0f - 1.0f, tn.y * 2.0f - 1.0f, tn.z * 2.0f - 1.0f);
+    R d[4], nm[4], mr[4];
+    sample_rgba8_r<R>(o, m.diffuse, u, v, true, d);
+    sample_rgba8_r<R>(o, m.normal, u, v, false, nm);
+    sample_rgba8_r<R>(o, m.mr, u, v, false, mr);
+    SurfaceR<R> s;
+    s.base = vec3<R>(d[0], d[1], d[2]);
+    Vec3<R> tn = vec3<R>(nm[0], R(1) - nm[1], nm[2]);                      // normal.g = 1 - normal.g
+    tn = vec3<R>(tn.x * R(2) - R(1), tn.y * R(2) - R(1), tn.z * R(2) - R(1));
     // mul(tbn, v) with tbn columns t,b,n: t*v.x + b*v.y + n*v.z per component
-    V3 T = v3(attr[2], attr[3], attr[4]), B = v3(attr[5], attr[6], attr[7]), N = v3(attr[8], attr[9], attr[10]);
-    V3 w = v3((T.x * tn.x + B.x * tn.y) + N.x * tn.z, (T.y * tn.x + B.y * tn.y) + N.y * tn.z, (T.z * tn.x + B.z * tn.y) + N.z * tn.z);
+    Vec3<R> T = vec3<R>(attr[2], attr[3], attr[4]), B = vec3<R>(attr[5], attr[6], attr[7]), N = vec3<R>(attr[8], attr[9], attr[10]);
+    Vec3<R> w = vec3<R>((T.x * tn.x + B.x * tn.y) + N.x * tn.z, (T.y * tn.x + B.y * tn.y) + N.y * tn.z, (T.z * tn.x + B.z * tn.y) + N.z * tn.z);
     s.n = normalize(w);
     s.metal = mr[2];   // .b  (forward.hlsl:117)
     s.rough = mr[1];   // .g  (forward.hlsl:123)
     return s;
 }
 
-// forward.hlsl:208-235 ps_main; returns HDR rgb, *n_evals = point lights evaluated
-V3 ps_main(const Oracle &o, const float *attr, uint32_t mat, V3 eye, V3 sun_dir, V3 sun_color, float ambient,
-           const float *shadow_map) {
+// forward.hlsl:208-235 ps_main; returns HDR rgb
+template <class R> Vec3<R> ps_main(const Oracle &o, const float *attr, uint32_t mat, V3 eye_f, V3 sun_dir_f, V3 sun_color_f, float ambient,
+                                   const float *shadow_map) {
     const MaterialData &m = o.materials[mat];
-    Surface s = fetch_surface(o, m, attr);
-    V3 world = v3(attr[11], attr[12], attr[13]);
-    V3 wo = normalize(sub(eye, world));
-    V3 Lo = v3(0.0f, 0.0f, 0.0f);
-    float shadow = calculate_shadow(shadow_map, o.shadow_size, V4{attr[14], attr[15], attr[16], attr[17]});
-    float lit = 1.0f - shadow;
-    Lo = add(Lo, scale(calculate_outgoing_radiance(s.n, wo, v3(-sun_dir.x, -sun_dir.y, -sun_dir.z), sun_color, s.base, s.metal, s.rough), lit));
+    SurfaceR<R> s = fetch_surface<R>(o, m, attr);
+    Vec3<R> eye = vec3<R>(eye_f.x, eye_f.y, eye_f.z), sun_color = vec3<R>(sun_color_f.x, sun_color_f.y, sun_color_f.z);
+    Vec3<R> world = vec3<R>(attr[11], attr[12], attr[13]);
+    Vec3<R> wo = normalize(eye - world);
+    Vec3<R> Lo = vec3<R>(0, 0, 0);
+    R shadow = calculate_shadow(shadow_map, o.shadow_size, V4{attr[14], attr[15], attr[16], attr[17]});   // always fp32: k/25
+    R lit = R(1) - shadow;
+    Lo = Lo + calculate_outgoing_radiance<R>(s.n, wo, vec3<R>(-sun_dir_f.x, -sun_dir_f.y, -sun_dir_f.z), sun_color, s.base, s.metal, s.rough) * lit;
     for (size_t i = 0; i < o.lights.size(); ++i) {
         const PointLight &L = o.lights[i];
-        V3 d = sub(v3(L.position[0], L.position[1], L.position[2]), world);
-        float dist = std::sqrt(dot(d, d));
-        V3 wi = divs(d, dist);
-        V3 radiance = divs(v3(L.color[0], L.color[1], L.color[2]), dist * dist);
-        Lo = add(Lo, scale(calculate_outgoing_radiance(s.n, wo, wi, radiance, s.base, s.metal, s.rough), lit));
+        Vec3<R> d = vec3<R>(L.position[0], L.position[1], L.position[2]) - world;
+        R dist = std::sqrt(dot(d, d));
+        Vec3<R> wi = d / dist;
+        Vec3<R> radiance = vec3<R>(L.color[0], L.color[1], L.color[2]) / (dist * dist);
+        Lo = Lo + calculate_outgoing_radiance<R>(s.n, wo, wi, radiance, s.base, s.metal, s.rough) * lit;
     }
-    return add(Lo, scale(s.base, ambient));
+    return Lo + s.base * (R)ambient;
 }
 
 // ----------------------------------------------------------------------------
 // post_process.hlsl
 // ----------------------------------------------------------------------------
-inline V3 tm_reinhard(V3 c) { return v3(c.x / (c.x + 1.0f), c.y / (c.y + 1.0f), c.z / (c.z + 1.0f)); }       // :39-42
-inline V3 tm_exposure(V3 c, float e) { return v3(1.0f - std::exp(-c.x * e), 1.0f - std::exp(-c.y * e), 1.0f - std::exp(-c.z * e)); }  // :44-47
-inline float rrt_odt(float c) {                                                                               // :27-32
-    float a = c * (c + 0.0245786f) - 0.000090537f;
-    float b = c * (0.983729f * c + 0.4329510f) + 0.238081f;
+template <class R> inline Vec3<R> tm_reinhard(Vec3<R> c) { return vec3<R>(c.x / (c.x + R(1)), c.y / (c.y + R(1)), c.z / (c.z + R(1))); }   // :39-42
+template <class R> inline Vec3<R> tm_exposure(Vec3<R> c, R e) { return vec3<R>(R(1) - std::exp(-c.x * e), R(1) - std::exp(-c.y * e), R(1) - std::exp(-c.z * e)); }  // :44-47
+template <class R> inline R rrt_odt(R c) {                                                                    // :27-32
+    R a = c * (c + R(0.0245786f)) - R(0.000090537f);
+    R b = c * (R(0.983729f) * c + R(0.4329510f)) + R(0.238081f);
     return a / b;
 }
-inline V3 tm_aces(V3 c) {                                                                                     // :15-25, :50-57
-    V3 i = v3((0.59719f * c.x + 0.35458f * c.y) + 0.04823f * c.z,
-              (0.07600f * c.x + 0.90834f * c.y) + 0.01566f * c.z,
-              (0.02840f * c.x + 0.13383f * c.y) + 0.837f * c.z);
-    i = v3(rrt_odt(i.x), rrt_odt(i.y), rrt_odt(i.z));
-    V3 r = v3((1.60475f * i.x + -0.53108f * i.y) + -0.07367f * i.z,
-              (-0.10208f * i.x + 1.10813f * i.y) + -0.00605f * i.z,
-              (-0.00327f * i.x + -0.07276f * i.y) + 1.07f * i.z);
-    return v3(clamp01(r.x), clamp01(r.y), clamp01(r.z));
+template <class R> inline Vec3<R> tm_aces(Vec3<R> c) {                                                        // :15-25, :50-57
+    Vec3<R> i = vec3<R>((R(0.59719f) * c.x + R(0.35458f) * c.y) + R(0.04823f) * c.z,
+                        (R(0.07600f) * c.x + R(0.90834f) * c.y) + R(0.01566f) * c.z,
+                        (R(0.02840f) * c.x + R(0.13383f) * c.y) + R(0.837f) * c.z);
+    i = vec3<R>(rrt_odt(i.x), rrt_odt(i.y), rrt_odt(i.z));
+    Vec3<R> r = vec3<R>((R(1.60475f) * i.x + R(-0.53108f) * i.y) + R(-0.07367f) * i.z,
+                        (R(-0.10208f) * i.x + R(1.10813f) * i.y) + R(-0.00605f) * i.z,
+                        (R(-0.00327f) * i.x + R(-0.07276f) * i.y) + R(1.07f) * i.z);
+    return vec3<R>(rclamp01(r.x), rclamp01(r.y), rclamp01(r.z));
 }
-inline V3 post_process(V3 c, const Settings &st) {                                                            // :59-93
+template <class R> inline Vec3<R> tonemap_only(Vec3<R> c, const Settings &st) {
     switch (st.tm_method) {
-    case 1: c = tm_exposure(c, st.exposure); break;
-    case 2: c = tm_aces(c); break;
-    default: c = tm_reinhard(c); break;
+    case 1: return tm_exposure<R>(c, (R)st.exposure);
+    case 2: return tm_aces<R>(c);
+    default: return tm_reinhard<R>(c);
     }
-    float ig = 1.0f / st.gamma;                                                                               // :34-37
-    return v3(std::pow(std::fabs(c.x), ig), std::pow(std::fabs(c.y), ig), std::pow(std::fabs(c.z), ig));
+}
+template <class R> inline Vec3<R> post_process(Vec3<R> c, const Settings &st) {                               // :59-93
+    c = tonemap_only<R>(c, st);
+    R ig = R(1) / (R)st.gamma;                                                                                // :34-37
+    return vec3<R>(std::pow(std::fabs(c.x), ig), std::pow(std::fabs(c.y), ig), std::pow(std::fabs(c.z), ig));
 }
 // float -> UNORM8 store of the RGBA8 target (renderer.cpp:161-175): D3D rule = saturate (NaN -> 0), *255, +0.5, truncate
 inline uint8_t to_unorm8(float x) {
@@ -663,6 +698,7 @@ inline uint8_t to_unorm8(float x) {
     return (uint8_t)(x * 255.0f + 0.5f);
 }
 
+template <class R>
 void shade_rows(Oracle &o, const Scene &sc, const Settings &st, const float *attrs, const uint32_t *matid,
                 uint32_t r0, uint32_t r1, float *hdr, float *ldr, uint8_t *rgba8, std::atomic<uint64_t> *shaded) {
     uint32_t W = o.width;
@@ -674,16 +710,16 @@ void shade_rows(Oracle &o, const Scene &sc, const Settings &st, const float *att
     for (uint32_t y = r0; y < r1; ++y)
         for (uint32_t x = 0; x < W; ++x) {
             size_t p = (size_t)y * W + x;
-            V3 c = v3(0.0f, 0.0f, 0.0f);   // no geometry: the reference's skybox is out of scope, defined black
+            Vec3<R> c = vec3<R>(0, 0, 0);   // no geometry: the reference's skybox is out of scope, defined black
             uint32_t m = matid[p];
             if (m != 0xFFFFFFFFu && m < o.materials.size()) {
-                c = ps_main(o, attrs + p * 18, m, eye, sun_dir, sun_color, sc.ambient, smap);
+                c = ps_main<R>(o, attrs + p * 18, m, eye, sun_dir, sun_color, sc.ambient, smap);
                 ++count;
             }
-            V3 l = post_process(c, st);
-            if (hdr) { hdr[p * 3] = c.x; hdr[p * 3 + 1] = c.y; hdr[p * 3 + 2] = c.z; }
-            if (ldr) { ldr[p * 3] = l.x; ldr[p * 3 + 1] = l.y; ldr[p * 3 + 2] = l.z; }
-            if (rgba8) { rgba8[p * 4] = to_unorm8(l.x); rgba8[p * 4 + 1] = to_unorm8(l.y); rgba8[p * 4 + 2] = to_unorm8(l.z); rgba8[p * 4 + 3] = 255; }
+            Vec3<R> l = post_process<R>(c, st);
+            if (hdr) { hdr[p * 3] = (float)c.x; hdr[p * 3 + 1] = (float)c.y; hdr[p * 3 + 2] = (float)c.z; }
+            if (ldr) { ldr[p * 3] = (float)l.x; ldr[p * 3 + 1] = (float)l.y; ldr[p * 3 + 2] = (float)l.z; }
+            if (rgba8) { rgba8[p * 4] = to_unorm8((float)l.x); rgba8[p * 4 + 1] = to_unorm8((float)l.y); rgba8[p * 4 + 2] = to_unorm8((float)l.z); rgba8[p * 4 + 3] = 255; }
         }
     if (shaded) shaded->fetch_add(count);
 }
@@ -692,14 +728,17 @@ void shade_parallel(Oracle &o, const Scene &sc, const Settings &st, const float 
                     uint32_t rows, float *hdr, float *ldr, uint8_t *rgba8, int threads) {
     if (threads < 1) threads = 1;
     std::atomic<uint64_t> shaded{0};
-    if (threads == 1) { shade_rows(o, sc, st, attrs, matid, 0, rows, hdr, ldr, rgba8, &shaded); }
+    auto run = [&](uint32_t a, uint32_t b) {
+        if (o.precision == 32) shade_rows<float>(o, sc, st, attrs, matid, a, b, hdr, ldr, rgba8, &shaded);
+        else shade_rows<double>(o, sc, st, attrs, matid, a, b, hdr, ldr, rgba8, &shaded);
+    };
+    if (threads == 1) run(0, rows);
     else {
         // rows dealt in bands of 4 for balance; each thread takes bands t, t+T, ...
         std::vector<std::thread> pool;
         for (int t = 0; t < threads; ++t)
             pool.emplace_back([&, t]() {
-                for (uint32_t b = (uint32_t)t * 4; b < rows; b += (uint32_t)threads * 4)
-                    shade_rows(o, sc, st, attrs, matid, b, std::min(rows, b + 4), hdr, ldr, rgba8, &shaded);
+                for (uint32_t b = (uint32_t)t * 4; b < rows; b += (uint32_t)threads * 4) run(b, std::min(rows, b + 4));
             });
         for (auto &th : pool) th.join();
     }
@@ -852,15 +891,15 @@ int oracle_frame_constants(const Scene *sc, float *pv, float *lpv, float *sun_di
 void oracle_dir_from_rot(const float rot[2], float out[3]) { V3 d = dir_from_rot(rot); out[0] = d.x; out[1] = d.y; out[2] = d.z; }
 void oracle_outgoing_radiance(const float n[3], const float wo[3], const float wi[3], const float Li[3], const float base[3],
                               float metal, float rough, float out[3]) {
-    V3 r = calculate_outgoing_radiance(v3(n[0], n[1], n[2]), v3(wo[0], wo[1], wo[2]), v3(wi[0], wi[1], wi[2]),
-                                       v3(Li[0], Li[1], Li[2]), v3(base[0], base[1], base[2]), metal, rough);
+    Vec3<float> r = calculate_outgoing_radiance<float>(vec3<float>(n[0], n[1], n[2]), vec3<float>(wo[0], wo[1], wo[2]), vec3<float>(wi[0], wi[1], wi[2]),
+                                                       vec3<float>(Li[0], Li[1], Li[2]), vec3<float>(base[0], base[1], base[2]), metal, rough);
     out[0] = r.x; out[1] = r.y; out[2] = r.z;
 }
 void oracle_tonemap(int32_t method, float gamma, float exposure, const float in[3], float tm[3], float out[3]) {
     Settings st{method, gamma, exposure};
-    V3 c = v3(in[0], in[1], in[2]), t;
-    switch (method) { case 1: t = tm_exposure(c, exposure); break; case 2: t = tm_aces(c); break; default: t = tm_reinhard(c); break; }
-    V3 r = post_process(c, st);
+    Vec3<float> c = vec3<float>(in[0], in[1], in[2]);
+    Vec3<float> t = tonemap_only<float>(c, st);
+    Vec3<float> r = post_process<float>(c, st);
     if (tm) { tm[0] = t.x; tm[1] = t.y; tm[2] = t.z; }
     out[0] = r.x; out[1] = r.y; out[2] = r.z;
 }
@@ -872,14 +911,21 @@ int oracle_fetch_surface(void *h, uint32_t mat, float u, float v, const float tb
     float attr[18] = {0};
     attr[0] = u; attr[1] = v;
     for (int i = 0; i < 9; ++i) attr[2 + i] = tbn[i];
-    Surface s = fetch_surface(*o, o->materials[mat], attr);
-    float nm[4]; sample_rgba8(*o, o->materials[mat].normal, u, v, false, nm);
+    SurfaceR<float> s = fetch_surface<float>(*o, o->materials[mat], attr);
+    float nm[4]; sample_rgba8_r<float>(*o, o->materials[mat].normal, u, v, false, nm);
     out[0] = s.base.x; out[1] = s.base.y; out[2] = s.base.z;
     out[3] = nm[0] * 2.0f - 1.0f; out[4] = (1.0f - nm[1]) * 2.0f - 1.0f; out[5] = nm[2] * 2.0f - 1.0f;
     out[6] = s.n.x; out[7] = s.n.y; out[8] = s.n.z; out[9] = s.metal; out[10] = s.rough;
     return 0;
 }
 uint8_t oracle_to_unorm8(float x) { return to_unorm8(x); }
+// 64 (default): BRDF + tonemap in float64, the parity arbiter; 32: the literal fp32 restatement (timed CPU baseline)
+int oracle_set_precision(void *h, int bits) {
+    Oracle *o = static_cast<Oracle *>(h);
+    if (!o || (bits != 32 && bits != 64)) return -1;
+    o->precision = bits;
+    return 0;
+}
 int oracle_hardware_threads(void) { return (int)std::thread::hardware_concurrency(); }
 
 }  // extern "C"

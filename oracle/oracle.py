@@ -86,6 +86,7 @@ def lib():
         L.oracle_to_unorm8.restype = C.c_uint8
         L.oracle_to_unorm8.argtypes = [f32]
         L.oracle_hardware_threads.restype = i32
+        L.oracle_set_precision.argtypes = [vp, i32]
         _lib = L
     return _lib
 
@@ -109,6 +110,11 @@ class Oracle:
         self.h = self.L.oracle_create(width, height, shadow_size, max_lights, row_begin, row_end)
         if not self.h:
             raise ValueError("oracle_create failed")
+
+    def set_precision(self, bits):
+        """64 (default): BRDF/tonemap in float64 = the parity arbiter; 32: literal fp32 restatement (CPU baseline)."""
+        assert self.L.oracle_set_precision(self.h, bits) == 0
+        return self
 
     def close(self):
         if self.h:
