@@ -71,10 +71,14 @@ struct GeomParams {
 };
 
 // texture descriptor, 16 B; three consecutive per material: diffuse (sRGB), normal, metal-rough
+// When a material's three images have equal size they are stored INTERLEAVED, texel by texel {diffuse, normal,
+// metal-rough} (12 B), so one bilinear footprint = four 12-byte loads instead of twelve 4-byte ones; bit 31 of w marks
+// it, and descriptor k then points at dword k of the first texel.
 struct TexDesc {
-    const uint32_t *texels;  // RGBA8 little endian (r = low byte), row-major, tightly packed
-    uint32_t w, h;
+    const uint32_t *texels;  // RGBA8 little endian (r = low byte), row-major; tightly packed, or every 3rd dword
+    uint32_t w, h;           // w bit 31: interleaved
 };
+constexpr uint32_t TEX_INTERLEAVED = 0x80000000u;
 
 // point light as uploaded (scene.hpp:88-94): float3 pos, pad, float3 color, pad = 2 x float4
 struct ShadeParams {
@@ -102,8 +106,14 @@ struct ShadeParams {
     float *out_hdr;              // optional rows*width*3
     unsigned long long *light_evals;  // optional counter
     int32_t culling;
-    int32_t desc_in_lds;         // texture descriptors staged in LDS (n_materials <= MAX_LDS_MATERIALS)
+    // lit-pixel stream written by k_material, read by k_light (capacity = pixels of the shard)
+    float4 *lit_r0, *lit_r1, *lit_r2;   // (world.xyz, 1-shadow) (n.xyz, roughness) (base.xyz, metalness)
+    uint32_t *lit_px;                   // pixel index y*width + x inside the shard
+    uint32_t *lit_count;                // LIT_SHARDS counters, LIT_COUNTER_STRIDE apart
+    int32_t debug;                      // timing experiments only: 1 skip material textures, 2 skip shadow test
+    uint32_t lit_shard_cap;             // records per shard: ceil(workgroups / LIT_SHARDS) * 256, cannot overflow
 };
+constexpr uint32_t LIT_SHARDS = 256, LIT_COUNTER_STRIDE = 32;
 constexpr uint32_t MAX_LDS_MATERIALS = 512;   // 24 KiB of descriptors
 constexpr uint32_t MAX_SHADE_LIGHTS = 2048;    // 48 KiB of light pairs in LDS
 
@@ -125,8 +135,7 @@ hipError_t launch_resolve(const unsigned long long *vis, const SetupRec *recs, c
                           const GeomParams *gp, uint32_t n_tiles, GBuffer g, float *depth_out, uint32_t *src_out, hipStream_t s);
 hipError_t launch_fill_u64(unsigned long long *p, unsigned long long v, size_t n, hipStream_t s);
 hipError_t launch_fill_u32(uint32_t *p, uint32_t v, size_t n, hipStream_t s);
-hipError_t launch_shade(const ShadeParams &sp, uint32_t max_blocks, hipStream_t s);
-size_t shade_lds_bytes(const ShadeParams &sp);
+hipError_t launch_shade(const ShadeParams &sp, uint32_t light_blocks, hipStream_t s);
 hipError_t launch_post_process(const float4 *hdr, uint32_t w, uint32_t h, int32_t tm, float inv_gamma, float exposure,
                                uint8_t *rgba8, float *ldr, hipStream_t s);
 hipError_t launch_gbuffer_tile(GBuffer g, float *attrs, uint32_t *mat, uint32_t width, uint32_t rows,

@@ -56,12 +56,13 @@ struct ArcticRenderer {
     uint32_t n_lights = 0;
     // frame targets
     DevBuf d_vis, d_p0, d_p1, d_p2, d_p3, d_p4, d_depth, d_src, d_rgba8, d_ldr, d_hdr, d_counter;
+    DevBuf d_lit0, d_lit1, d_lit2, d_litpx, d_litcount;   // lit-pixel stream between k_material and k_light
     bool have_gbuffer = false, have_output = false;
     // per-frame geometry scratch
     DevBuf d_objs, d_vblock_obj, d_vblock_first, d_tblock_obj, d_tblock_first, d_xverts, d_sub_count, d_sub_offset,
         d_recs, d_tile_count, d_tile_offset, d_scan, d_gp, d_stage;
-    uint64_t stats[6] = {0, 0, 0, 0, 0, 0};
-    int keep_float = 0, count_evals = 0, culling = 1;
+    uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int keep_float = 0, count_evals = 0, culling = 1, debug = 0;
     uint32_t shade_blocks = 1024;   // persistent grid of k_shade: CUs x blocks per CU
     std::string err;
 
@@ -75,6 +76,8 @@ struct ArcticRenderer {
         return code;
     }
     uint32_t rows() const { return row_end - row_begin; }
+    // records per shard of the lit-pixel stream: workgroup (ty, col) goes to shard (ty * bpr + col) % LIT_SHARDS
+    uint32_t lit_shard_cap() const { uint32_t bpr = (tiles_x + 3) / 4; return ((tiles_y * bpr + LIT_SHARDS - 1) / LIT_SHARDS) * 256; }
     size_t n_tiles() const { return (size_t)tiles_x * tiles_y; }
     GBuffer gbuffer() const { return GBuffer{d_p0.as<float4>(), d_p1.as<float4>(), d_p2.as<float4>(), d_p3.as<float4>(), d_p4.as<float>()}; }
 };
@@ -108,6 +111,14 @@ int alloc_targets(ArcticRenderer *r) {
     HIPCHECK(r, r->d_src.ensure(px * 4));
     HIPCHECK(r, r->d_rgba8.ensure(out_px * 4));
     HIPCHECK(r, r->d_counter.ensure(64));
+    {
+        size_t cap = (size_t)r->lit_shard_cap() * LIT_SHARDS;
+        HIPCHECK(r, r->d_lit0.ensure(cap * 16));
+        HIPCHECK(r, r->d_lit1.ensure(cap * 16));
+        HIPCHECK(r, r->d_lit2.ensure(cap * 16));
+        HIPCHECK(r, r->d_litpx.ensure(cap * 4));
+        HIPCHECK(r, r->d_litcount.ensure((size_t)LIT_SHARDS * LIT_COUNTER_STRIDE * 4));
+    }
     r->have_gbuffer = r->have_output = false;
     return ARCTIC_OK;
 }
@@ -270,7 +281,10 @@ int fill_shade_params(ArcticRenderer *r, const ArcticScene *sc, const ArcticSett
     }
     sp.light_evals = r->count_evals ? r->d_counter.as<unsigned long long>() : nullptr;
     sp.culling = r->culling;
-    sp.desc_in_lds = sp.n_materials <= MAX_LDS_MATERIALS;
+    sp.debug = r->debug;
+    sp.lit_r0 = r->d_lit0.as<float4>(); sp.lit_r1 = r->d_lit1.as<float4>(); sp.lit_r2 = r->d_lit2.as<float4>();
+    sp.lit_px = r->d_litpx.as<uint32_t>(); sp.lit_count = r->d_litcount.as<uint32_t>();
+    sp.lit_shard_cap = r->lit_shard_cap();
     return ARCTIC_OK;
 }
 
@@ -282,9 +296,13 @@ int pass_shade(ArcticRenderer *r, const ArcticScene *sc, const ArcticSettings *s
     HIPCHECK(r, launch_shade(sp, r->shade_blocks, r->stream));
     if (sp.light_evals) {
         unsigned long long n = 0;
+        std::vector<uint32_t> counts((size_t)LIT_SHARDS * LIT_COUNTER_STRIDE);
         HIPCHECK(r, hipMemcpyAsync(&n, r->d_counter.p, 8, hipMemcpyDeviceToHost, r->stream));
+        HIPCHECK(r, hipMemcpyAsync(counts.data(), sp.lit_count, counts.size() * 4, hipMemcpyDeviceToHost, r->stream));
         HIPCHECK(r, hipStreamSynchronize(r->stream));
         r->stats[5] = n;
+        r->stats[6] = 0;
+        for (uint32_t k = 0; k < LIT_SHARDS; ++k) r->stats[6] += counts[(size_t)k * LIT_COUNTER_STRIDE];
     }
     r->have_output = (d_out == nullptr);
     return ARCTIC_OK;
@@ -350,7 +368,7 @@ void arctic_destroy(ArcticRenderer *r) {
     for (Mesh &m : r->meshes) { if (m.d_vertices) (void)hipFree(m.d_vertices); if (m.d_indices) (void)hipFree(m.d_indices); }
     for (void *p : r->tex_allocs) (void)hipFree(p);
     DevBuf *bufs[] = {&r->d_tex, &r->d_lut, &r->d_lights, &r->d_shadow, &r->d_vis, &r->d_p0, &r->d_p1, &r->d_p2, &r->d_p3, &r->d_p4,
-                      &r->d_depth, &r->d_src, &r->d_rgba8, &r->d_ldr, &r->d_hdr, &r->d_counter, &r->d_objs, &r->d_vblock_obj,
+                      &r->d_depth, &r->d_src, &r->d_rgba8, &r->d_ldr, &r->d_hdr, &r->d_counter, &r->d_lit0, &r->d_lit1, &r->d_lit2, &r->d_litpx, &r->d_litcount, &r->d_objs, &r->d_vblock_obj,
                       &r->d_vblock_first, &r->d_tblock_obj, &r->d_tblock_first, &r->d_xverts, &r->d_sub_count, &r->d_sub_offset,
                       &r->d_recs, &r->d_tile_count, &r->d_tile_offset, &r->d_scan, &r->d_gp, &r->d_stage};
     for (DevBuf *b : bufs) b->release();
@@ -381,18 +399,39 @@ int arctic_create_material(ArcticRenderer *r, const void *diffuse, uint32_t dw, 
                            uint32_t nh, const void *mr, uint32_t mw, uint32_t mh) {
     if (!r) return ARCTIC_E_INVALID;
     if (!diffuse || !normal || !mr || !dw || !dh || !nw || !nh || !mw || !mh) return r->fail(ARCTIC_E_INVALID, "create_material: null image or zero size");
+    if ((dw | dh | nw | nh | mw | mh) & 0xFFFF0000u) return r->fail(ARCTIC_E_CAPACITY, "create_material: image side above 65535");
+    if (r->tex.size() / 3 >= MAX_LDS_MATERIALS) return r->fail(ARCTIC_E_CAPACITY, "create_material: more than %u materials (their descriptors live in LDS)", MAX_LDS_MATERIALS);
     int rc = select_device(r);
     if (rc) return rc;
     const void *src[3] = {diffuse, normal, mr};
     const uint32_t w[3] = {dw, nw, mw}, h[3] = {dh, nh, mh};
     TexDesc td[3];
-    for (int i = 0; i < 3; ++i) {
+    if (dw == nw && dw == mw && dh == nh && dh == mh) {
+        // equal sizes (the usual glTF case): interleave {diffuse, normal, metal-rough} per texel
+        size_t n = (size_t)dw * dh;
+        std::vector<uint32_t> packed(n * 3);
+        const uint32_t *a = static_cast<const uint32_t *>(diffuse), *b = static_cast<const uint32_t *>(normal), *c = static_cast<const uint32_t *>(mr);
+        for (size_t i = 0; i < n; ++i) {
+            uint32_t t[3];
+            std::memcpy(&t[0], reinterpret_cast<const char *>(a) + 4 * i, 4);   // caller buffers need not be 4-byte aligned
+            std::memcpy(&t[1], reinterpret_cast<const char *>(b) + 4 * i, 4);
+            std::memcpy(&t[2], reinterpret_cast<const char *>(c) + 4 * i, 4);
+            packed[3 * i] = t[0]; packed[3 * i + 1] = t[1]; packed[3 * i + 2] = t[2];
+        }
         void *p = nullptr;
-        size_t bytes = (size_t)w[i] * h[i] * 4;
-        HIPCHECK(r, hipMalloc(&p, bytes));
+        HIPCHECK(r, hipMalloc(&p, n * 12));
         r->tex_allocs.push_back(p);
-        HIPCHECK(r, hipMemcpy(p, src[i], bytes, hipMemcpyHostToDevice));   // synchronous like rhi.cpp:480-519
-        td[i].texels = static_cast<const uint32_t *>(p); td[i].w = w[i]; td[i].h = h[i];
+        HIPCHECK(r, hipMemcpy(p, packed.data(), n * 12, hipMemcpyHostToDevice));   // synchronous like rhi.cpp:480-519
+        for (int i = 0; i < 3; ++i) { td[i].texels = static_cast<const uint32_t *>(p) + i; td[i].w = dw | TEX_INTERLEAVED; td[i].h = dh; }
+    } else {
+        for (int i = 0; i < 3; ++i) {
+            void *p = nullptr;
+            size_t bytes = (size_t)w[i] * h[i] * 4;
+            HIPCHECK(r, hipMalloc(&p, bytes));
+            r->tex_allocs.push_back(p);
+            HIPCHECK(r, hipMemcpy(p, src[i], bytes, hipMemcpyHostToDevice));
+            td[i].texels = static_cast<const uint32_t *>(p); td[i].w = w[i]; td[i].h = h[i];
+        }
     }
     r->tex.insert(r->tex.end(), td, td + 3);
     HIPCHECK(r, hipStreamSynchronize(r->stream));
@@ -617,7 +656,7 @@ int arctic_frame_constants(const ArcticScene *scene, float *proj_view, float *li
 
 int arctic_stats(ArcticRenderer *r, uint64_t *out, uint32_t n) {
     if (!r || !out) return ARCTIC_E_INVALID;
-    for (uint32_t i = 0; i < n && i < 6; ++i) out[i] = r->stats[i];
+    for (uint32_t i = 0; i < n && i < 8; ++i) out[i] = r->stats[i];
     return ARCTIC_OK;
 }
 
@@ -627,6 +666,7 @@ int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value) {
     case ARCTIC_OPT_KEEP_FLOAT_OUTPUT: r->keep_float = value != 0; break;
     case ARCTIC_OPT_COUNT_LIGHT_EVALS: r->count_evals = value != 0; break;
     case ARCTIC_OPT_CULLING: r->culling = value != 0; break;
+    case ARCTIC_OPT_DEBUG: r->debug = (int)value; break;
     default: return r->fail(ARCTIC_E_INVALID, "set_option: unknown option %u", option);
     }
     return ARCTIC_OK;

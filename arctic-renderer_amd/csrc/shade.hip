@@ -5,11 +5,19 @@
 // shaders/post_process.hlsl:59-93 (Reinhard / exposure / ACES :39-57, gamma :34-37) with ONE
 // HIP kernel that reads the tile-major G-buffer written by geometry.hip and stores RGBA8.
 //
-// Mapping: 1 wavefront = one 8x8 pixel tile (lane l = pixel (l&7, l>>3)), 1 workgroup = 4 waves =
-// 16x16 pixels.  G-buffer reads are 16 B / lane, contiguous per wave.  There is no texture
-// hardware on gfx950, so every Sample() is address arithmetic + global_load_dword + weights;
-// sRGB decode is a 256-entry LDS table.  Lights are wave-uniform, so they are fetched with scalar
-// loads and live in SGPRs.  Scalar-per-pixel FP32 (VALU): no MFMA, by design.
+// Two kernels, each shaped for its own regime (MI355X has no pixel-shader scheduler to do this for us):
+//   k_material  1 wavefront = one 8x8 tile (lane l = pixel (l&7, l>>3)), 4 tiles per workgroup.  Reads the tile-major
+//               G-buffer with 16 B / lane contiguous loads, fetches the material (software bilinear: address math +
+//               global_load + weights; sRGB decode through a 256-entry LDS table; descriptors in LDS) and runs the
+//               PCF shadow test.  Memory-latency bound, small register footprint, high occupancy.  Pixels whose
+//               (1 - shadow) is 0 are FINISHED here (every light term of ps_main is multiplied by it, point lights
+//               included: forward.hlsl:222,230), the others are compacted with a wave-wide ballot into a dense
+//               "lit pixel" stream (52 B records).
+//   k_light     persistent; 1 lane = one lit pixel of that stream, so no lane idles at shadow boundaries.  Point lights
+//               sit in LDS as PAIRS and are evaluated two at a time in packed FP32 (v_pk_fma_f32 ...), the sun first;
+//               a pair whose n.wi <= 0 for the whole wave is skipped (exact: the term is multiplied by max(n.wi, 0)).
+//               Pure VALU; then tonemap + gamma + RGBA8 store.
+// Scalar-per-pixel FP32: no MFMA, by design.
 //
 // Numerics: texel coordinates/weights and the whole shadow test are computed exactly as the
 // CPU oracle does (fp contract off, IEEE divide) because they feed discontinuous decisions; the
@@ -55,17 +63,38 @@ __device__ __forceinline__ void wrap_axis(float u, uint32_t n, int &i0, int &i1,
 
 struct Taps { uint32_t t00, t10, t01, t11; float w00, w10, w01, w11; };
 
-__device__ __forceinline__ Taps fetch_taps(const TexDesc &d, float u, float v) {
+// one texture of a material: `stride` dwords between horizontally adjacent texels (1 = plain RGBA8 image, 3 = the
+// material's three equally sized images interleaved texel by texel: {diffuse, normal, metal-rough})
+struct TexRef { const uint32_t *texels; uint32_t w, h, stride; };
+
+__device__ __forceinline__ Taps fetch_taps(const TexRef &d, float u, float v) {
     int x0, x1, y0, y1;
     float fx, fy;
     wrap_axis(u, d.w, x0, x1, fx);
     wrap_axis(v, d.h, y0, y1, fy);
-    const uint32_t *r0 = d.texels + (size_t)y0 * d.w, *r1 = d.texels + (size_t)y1 * d.w;
+    const uint32_t *r0 = d.texels + (size_t)y0 * d.w * d.stride, *r1 = d.texels + (size_t)y1 * d.w * d.stride;
     Taps t;
-    t.t00 = r0[x0]; t.t10 = r0[x1]; t.t01 = r1[x0]; t.t11 = r1[x1];
+    t.t00 = r0[x0 * d.stride]; t.t10 = r0[x1 * d.stride]; t.t01 = r1[x0 * d.stride]; t.t11 = r1[x1 * d.stride];
     float gx = 1.0f - fx, gy = 1.0f - fy;
     t.w00 = gx * gy; t.w10 = fx * gy; t.w01 = gx * fy; t.w11 = fx * fy;
     return t;
+}
+
+// interleaved material: ONE footprint, four 12-byte loads fetch all three textures' taps
+typedef uint32_t uint3u __attribute__((ext_vector_type(3), aligned(4)));
+__device__ __forceinline__ void fetch_taps3(const TexRef &d, float u, float v, Taps &a, Taps &b, Taps &c) {
+    int x0, x1, y0, y1;
+    float fx, fy;
+    wrap_axis(u, d.w, x0, x1, fx);
+    wrap_axis(v, d.h, y0, y1, fy);
+    const uint32_t *r0 = d.texels + (size_t)y0 * d.w * 3, *r1 = d.texels + (size_t)y1 * d.w * 3;
+    const uint3u q00 = *reinterpret_cast<const uint3u *>(r0 + x0 * 3), q10 = *reinterpret_cast<const uint3u *>(r0 + x1 * 3);
+    const uint3u q01 = *reinterpret_cast<const uint3u *>(r1 + x0 * 3), q11 = *reinterpret_cast<const uint3u *>(r1 + x1 * 3);
+    float gx = 1.0f - fx, gy = 1.0f - fy;
+    a.w00 = b.w00 = c.w00 = gx * gy; a.w10 = b.w10 = c.w10 = fx * gy; a.w01 = b.w01 = c.w01 = gx * fy; a.w11 = b.w11 = c.w11 = fx * fy;
+    a.t00 = q00.x; a.t10 = q10.x; a.t01 = q01.x; a.t11 = q11.x;
+    b.t00 = q00.y; b.t10 = q10.y; b.t01 = q01.y; b.t11 = q11.y;
+    c.t00 = q00.z; c.t10 = q10.z; c.t01 = q01.z; c.t11 = q11.z;
 }
 __device__ __forceinline__ float ch(uint32_t t, int c) { return (float)((t >> (8 * c)) & 0xFFu); }
 __device__ __forceinline__ float filt_unorm(const Taps &t, int c) {
@@ -308,38 +337,107 @@ __device__ __forceinline__ TileData load_tile(const GBuffer &g, size_t idx) {
     return t;
 }
 
-// LDS image of one workgroup (dynamic):  [0,256) sRGB LUT | texture descriptors (4 dwords each, when they fit) |
-// point lights as PAIRS, 12 floats per pair {x0,x1, y0,y1, z0,z1, r0,r1, g0,g1, b0,b1} = 3 x ds_read_b128 (broadcast)
-__device__ __forceinline__ TexDesc lds_desc(const uint4 *d) {
+__device__ __forceinline__ TexRef lds_desc(const uint4 *d) {
     const uint4 v = *d;
-    TexDesc t;
+    TexRef t;
     t.texels = reinterpret_cast<const uint32_t *>(((unsigned long long)v.y << 32) | v.x);
-    t.w = v.z; t.h = v.w;
+    t.w = v.z & 0x7FFFFFFFu; t.h = v.w;
+    t.stride = (v.z >> 31) ? 3u : 1u;   // TexDesc::w bit 31: interleaved material
     return t;
 }
 
-// Persistent kernel: gridDim.x workgroups of 4 waves; the workgroup stages the constants into LDS once, then wave w
-// of block b shades tiles (k * gridDim.x + b) * 4 + w, k = 0, 1, ...: the 4 waves of a block always work on 4
-// horizontally adjacent tiles (their RGBA8 rows complete 128-byte lines together), and lit (expensive) screen
-// regions are dealt round-robin over all CUs.  The next tile's G-buffer is requested before the light loop of the
-// current one, so its HBM latency hides under the BRDF arithmetic.
-__global__ __launch_bounds__(256, 4) void k_shade(const ShadeParams sp) {
+__device__ __forceinline__ void store_pixel(const ShadeParams &sp, size_t o, f3 color) {
+    const f3 l = post_process(color, sp.tm_method, sp.inv_gamma, sp.exposure);
+    reinterpret_cast<uint32_t *>(sp.out_rgba8)[o] = unorm8(l.x) | (unorm8(l.y) << 8) | (unorm8(l.z) << 16) | 0xFF000000u;
+    if (sp.out_ldr) { sp.out_ldr[o * 3] = l.x; sp.out_ldr[o * 3 + 1] = l.y; sp.out_ldr[o * 3 + 2] = l.z; }
+    if (sp.out_hdr) { sp.out_hdr[o * 3] = color.x; sp.out_hdr[o * 3 + 1] = color.y; sp.out_hdr[o * 3 + 2] = color.z; }
+}
+
+// ---- kernel 1: material fetch + shadow + classification ---------------------------------------------------------
+// LDS (dynamic): [0,256) sRGB LUT | texture descriptors, 4 dwords each
+__global__ __launch_bounds__(256) void k_material(const ShadeParams sp) {
     extern __shared__ __align__(16) float smem[];
     float *lut = smem;
     uint4 *ldesc = reinterpret_cast<uint4 *>(smem + 256);
-    const uint32_t n_desc = sp.desc_in_lds ? sp.n_materials * 3 : 0;
-    float4 *llights = reinterpret_cast<float4 *>(smem + 256 + 4 * n_desc);
-    const uint32_t n_pairs = (sp.n_lights + 1) >> 1;
-
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t n_tiles = sp.tiles_x * sp.tiles_y, stride = gridDim.x * 4;
-    uint32_t t = blockIdx.x * 4 + wave;
+    // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (each with its own 4 MiB L2), so physical block b
+    // runs on XCD b % 8.  A workgroup = 4 horizontally adjacent tiles; XCD x takes the tile rows y = x (mod 8), walking
+    // each row left to right, so horizontal neighbours -- which share texture and shadow-map cache lines -- meet in the
+    // same L2, while all eight XCDs stay within 8 tile rows of each other in the G-buffer stream.  (Placement is a speed
+    // matter only; the grid is padded to whole groups of 8 rows and surplus blocks exit.)
+    const uint32_t bpr = (sp.tiles_x + 3) >> 2;                       // workgroups per tile row
+    const uint32_t xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
+    const uint32_t ty = (idx / bpr) * 8 + xcd, tx = (idx % bpr) * 4 + wave;
+    const bool tile_ok = ty < sp.tiles_y && tx < sp.tiles_x;
+    const uint32_t t = ty * sp.tiles_x + tx;
     TileData cur;
-    if (t < n_tiles) cur = load_tile(sp.g, (size_t)t * 64 + lane);   // in flight while LDS is staged
-
+    if (tile_ok) cur = load_tile(sp.g, (size_t)t * 64 + lane);   // in flight while LDS is staged
     lut[threadIdx.x] = sp.srgb_lut[threadIdx.x];
-    for (uint32_t i = threadIdx.x; i < n_desc; i += 256) ldesc[i] = reinterpret_cast<const uint4 *>(sp.tex)[i];
+    for (uint32_t i = threadIdx.x; i < sp.n_materials * 3; i += 256) ldesc[i] = reinterpret_cast<const uint4 *>(sp.tex)[i];
+    __syncthreads();
+    if (!tile_ok) return;
+
+    const uint32_t x = tx * 8 + (lane & 7);
+    const int32_t y = (int32_t)(ty * 8 + (lane >> 3)) - (int32_t)sp.row0_in_tile;
+    const bool in_frame = x < sp.width && y >= 0 && y < (int32_t)sp.rows;
+    const uint32_t mat = __float_as_uint(cur.q0.w);
+    const bool covered = in_frame && mat < sp.n_materials;
+    const size_t o = (size_t)y * sp.width + x;
+
+    f3 base = mk(0.0f, 0.0f, 0.0f), n = mk(0.0f, 0.0f, 1.0f);
+    float metal = 0.0f, rough = 1.0f, lit = 0.0f;
+    if (covered) {
+        // ---- material fetch, forward.hlsl:98-124 ----------------------------------------------------------------
+        const float u = cur.q2.x, v = cur.q2.y;
+        if (!(sp.debug & 2)) lit = 1.0f - calculate_shadow(sp.shadow_map, sp.shadow_size, cur.q1);
+        if (!(sp.debug & 1)) {
+        Taps t0, t1, t2;
+        const TexRef d0 = lds_desc(ldesc + mat * 3);
+        if (__ballot(d0.stride != 3u) == 0ull) fetch_taps3(d0, u, v, t0, t1, t2);   // the usual case: whole wave on interleaved materials
+        else { t0 = fetch_taps(d0, u, v); t1 = fetch_taps(lds_desc(ldesc + mat * 3 + 1), u, v); t2 = fetch_taps(lds_desc(ldesc + mat * 3 + 2), u, v); }
+        base = mk(filt_srgb(t0, 0, lut), filt_srgb(t0, 1, lut), filt_srgb(t0, 2, lut));
+        float r = filt_unorm(t1, 0), g = 1.0f - filt_unorm(t1, 1), b = filt_unorm(t1, 2);   // normal.g = 1 - normal.g
+        r = r * 2.0f - 1.0f; g = g * 2.0f - 1.0f; b = b * 2.0f - 1.0f;
+        // mul(tbn, v), tbn columns t, b, n
+        const f3 T = mk(cur.q2.z, cur.q2.w, cur.q3.x), B = mk(cur.q3.y, cur.q3.z, cur.q3.w), N = mk(cur.nx, cur.ny, cur.nz);
+        n = normalize(T * r + B * g + N * b);
+        rough = filt_unorm(t2, 1);   // .g
+        metal = filt_unorm(t2, 2);   // .b
+        } else { base = mk(u, v, cur.q3.x + cur.nx); n = mk(cur.q3.y, cur.q3.z, cur.q3.w); }
+    }
+    // exact culling 1: Lo of ps_main is a sum of terms each multiplied by (1 - shadow), so a fully shadowed pixel is
+    // ambient * base and needs neither the sun nor any point light.  Everything else goes to the lit-pixel stream.
+    const bool live = covered && (sp.culling ? lit != 0.0f : true);
+    if (in_frame && !live) store_pixel(sp, o, base * sp.ambient);   // uncovered: base = 0 -> black (the skybox is out of scope)
+    // wave-wide compaction of the live pixels into this workgroup's SHARD of the stream (one atomicAdd per wave, on one
+    // of LIT_SHARDS counters each on its own 128-byte line: a single counter would serialise at ~88 atomics/us)
+    const unsigned long long m = __ballot(live);
+    if (m != 0ull) {
+        const uint32_t shard = (ty * bpr + (tx >> 2)) % LIT_SHARDS;   // by screen position: lit regions spread over all shards
+        uint32_t first = (uint32_t)__ffsll((long long)m) - 1, slot0 = 0;
+        if (lane == first) slot0 = atomicAdd(sp.lit_count + shard * LIT_COUNTER_STRIDE, (uint32_t)__popcll(m));
+        slot0 = __shfl(slot0, (int)first);
+        if (live) {
+            const size_t slot = (size_t)shard * sp.lit_shard_cap + slot0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            sp.lit_r0[slot] = make_float4(cur.q0.x, cur.q0.y, cur.q0.z, lit);
+            sp.lit_r1[slot] = make_float4(n.x, n.y, n.z, rough);
+            sp.lit_r2[slot] = make_float4(base.x, base.y, base.z, metal);
+            sp.lit_px[slot] = (uint32_t)o;
+        }
+    }
+}
+
+// ---- kernel 2: the sun + point lights over the lit-pixel stream, tonemap, store ----------------------------------
+// LDS (dynamic): point lights as PAIRS, 12 floats per pair {x0,x1, y0,y1, z0,z1, r0,r1, g0,g1, b0,b1} = 3 x ds_read_b128
+// (every lane reads the same address: broadcast).  Persistent: gridDim.x workgroups, wave w of block b takes the
+// 64-pixel groups b*4 + w, + 4*gridDim.x, ...
+__global__ __launch_bounds__(256, 4) void k_light(const ShadeParams sp) {
+    extern __shared__ __align__(16) float smem[];
+    float4 *llights = reinterpret_cast<float4 *>(smem);
+    const uint32_t n_pairs = (sp.n_lights + 1) >> 1;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (uint32_t i = threadIdx.x; i < 2 * n_pairs; i += 256) {
         float4 lp = make_float4(0.0f, 1.0e6f, 0.0f, 0.0f), lc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // pad: colour 0
         if (i < sp.n_lights) { lp = sp.lights[2 * i]; lc = sp.lights[2 * i + 1]; }
@@ -347,81 +445,44 @@ __global__ __launch_bounds__(256, 4) void k_shade(const ShadeParams sp) {
         dst[0] = lp.x; dst[2] = lp.y; dst[4] = lp.z; dst[6] = lc.x; dst[8] = lc.y; dst[10] = lc.z;
     }
     __syncthreads();
-
-    while (t < n_tiles) {
-        const uint32_t tx = t % sp.tiles_x, ty = t / sp.tiles_x;
-        const uint32_t x = tx * 8 + (lane & 7);
-        const int32_t y = (int32_t)(ty * 8 + (lane >> 3)) - (int32_t)sp.row0_in_tile;
-        const bool in_frame = x < sp.width && y >= 0 && y < (int32_t)sp.rows;
-        const float4 q0 = cur.q0, q1 = cur.q1, q2 = cur.q2, q3 = cur.q3;
-        const uint32_t mat = __float_as_uint(q0.w);
-        const bool covered = in_frame && mat < sp.n_materials;
-
-        f3 base = mk(0.0f, 0.0f, 0.0f), n = mk(0.0f, 0.0f, 1.0f);
-        float metal = 0.0f, rough = 1.0f, lit = 0.0f;
-        if (covered) {
-            // ---- material fetch, forward.hlsl:98-124 --------------------------------------------
-            TexDesc d0, d1, d2;
-            if (sp.desc_in_lds) { d0 = lds_desc(ldesc + mat * 3); d1 = lds_desc(ldesc + mat * 3 + 1); d2 = lds_desc(ldesc + mat * 3 + 2); }
-            else { const TexDesc *td = sp.tex + (size_t)mat * 3; d0 = td[0]; d1 = td[1]; d2 = td[2]; }
-            const float u = q2.x, v = q2.y;
-            const Taps t0 = fetch_taps(d0, u, v), t1 = fetch_taps(d1, u, v), t2 = fetch_taps(d2, u, v);
-            lit = 1.0f - calculate_shadow(sp.shadow_map, sp.shadow_size, q1);
-            base = mk(filt_srgb(t0, 0, lut), filt_srgb(t0, 1, lut), filt_srgb(t0, 2, lut));
-            float r = filt_unorm(t1, 0), g = 1.0f - filt_unorm(t1, 1), b = filt_unorm(t1, 2);   // normal.g = 1 - normal.g
-            r = r * 2.0f - 1.0f; g = g * 2.0f - 1.0f; b = b * 2.0f - 1.0f;
-            // mul(tbn, v), tbn columns t, b, n
-            const f3 T = mk(q2.z, q2.w, q3.x), B = mk(q3.y, q3.z, q3.w), N = mk(cur.nx, cur.ny, cur.nz);
-            n = normalize(T * r + B * g + N * b);
-            rough = filt_unorm(t2, 1);   // .g
-            metal = filt_unorm(t2, 2);   // .b
+    const f3 eye = mk(sp.eye[0], sp.eye[1], sp.eye[2]);
+    // wave w works on shard w % LIT_SHARDS and takes every (n_waves / LIT_SHARDS)-th 64-pixel group of it
+    const uint32_t w = blockIdx.x * 4 + wave, n_waves = gridDim.x * 4;
+    const bool wide = n_waves >= LIT_SHARDS;
+    const uint32_t nsub = wide ? n_waves / LIT_SHARDS : 1u, sub = wide ? w / LIT_SHARDS : 0u;
+    if (sub >= nsub) return;
+    for (uint32_t shard = wide ? w % LIT_SHARDS : w; shard < LIT_SHARDS; shard += wide ? LIT_SHARDS : n_waves)
+    for (uint32_t count = sp.lit_count[shard * LIT_COUNTER_STRIDE], grp = sub; grp * 64 < count; grp += nsub) {
+        if (grp * 64 + lane >= count) continue;
+        const size_t i = (size_t)shard * sp.lit_shard_cap + grp * 64 + lane;
+        const float4 r0 = sp.lit_r0[i], r1 = sp.lit_r1[i], r2 = sp.lit_r2[i];
+        const uint32_t o = sp.lit_px[i];
+        const f3 world = mk(r0.x, r0.y, r0.z), n = mk(r1.x, r1.y, r1.z), base = mk(r2.x, r2.y, r2.z);
+        const f3 wo = normalize(eye - world);
+        const Pix px = make_pix(n, wo, world, base, r2.w, r1.w, r0.w);
+        float sr = 0.0f, sg = 0.0f, sb = 0.0f;
+        {   // the sun: wi = -sun_dir, radiance = sun_color (forward.hlsl:221-222)
+            const float dx = -sp.sun_dir[0], dy = -sp.sun_dir[1], dz = -sp.sun_dir[2];
+            const float nd = n.x * dx + n.y * dy + n.z * dz;
+            accumulate_light<float, false>(px, dx, dy, dz, nd, sp.sun_color[0], sp.sun_color[1], sp.sun_color[2], sr, sg, sb);
         }
-        const f3 world = mk(q0.x, q0.y, q0.z);
-
-        // request the next tile now: nothing below touches `cur` any more
-        const uint32_t tn = t + stride;
-        if (tn < n_tiles) cur = load_tile(sp.g, (size_t)tn * 64 + lane);
-
-        f3 color = mk(0.0f, 0.0f, 0.0f);
-        // exact culling 1: every light term is multiplied by (1 - shadow) (point lights too: forward.hlsl:230), so a
-        // wave with no covered, not fully shadowed pixel skips the sun and the whole light loop
-        const bool live = covered && lit != 0.0f;
-        if (__ballot(sp.culling ? live : covered) != 0ull) {
-            const f3 wo = normalize(mk(sp.eye[0], sp.eye[1], sp.eye[2]) - world);
-            const Pix px = make_pix(n, wo, world, base, metal, rough, covered ? lit : 0.0f);
-            float sr = 0.0f, sg = 0.0f, sb = 0.0f;
-            {   // the sun: wi = -sun_dir, radiance = sun_color (forward.hlsl:221-222)
-                const float dx = -sp.sun_dir[0], dy = -sp.sun_dir[1], dz = -sp.sun_dir[2];
-                const float nd = n.x * dx + n.y * dy + n.z * dz;
-                accumulate_light<float, false>(px, dx, dy, dz, nd, sp.sun_color[0], sp.sun_color[1], sp.sun_color[2], sr, sg, sb);
+        v2 ar = {sr, 0.0f}, ag = {sg, 0.0f}, ab = {sb, 0.0f};
+        const v2 wx = splat<v2>(world.x), wy = splat<v2>(world.y), wz = splat<v2>(world.z);
+        for (uint32_t p = 0; p < n_pairs; ++p) {
+            const float4 A = llights[3 * p], Bq = llights[3 * p + 1], C = llights[3 * p + 2];
+            const v2 dx = (v2){A.x, A.y} - wx, dy = (v2){A.z, A.w} - wy, dz = (v2){Bq.x, Bq.y} - wz;
+            const v2 nd = fma_t(splat<v2>(n.z), dz, fma_t(splat<v2>(n.y), dy, splat<v2>(n.x) * dx));
+            // exact culling 2: n.wi <= 0 zeroes a light (forward.hlsl:191-192); skip the pair when that holds for both
+            // lights in every lane of the wave
+            if (sp.culling && __ballot(nd.x > 0.0f || nd.y > 0.0f) == 0ull) continue;
+            accumulate_light<v2, true>(px, dx, dy, dz, nd, (v2){Bq.z, Bq.w}, (v2){C.x, C.y}, (v2){C.z, C.w}, ar, ag, ab);
+            if (sp.light_evals) {
+                const unsigned long long active = __ballot(1);
+                const uint32_t k = (2 * p + 1 < sp.n_lights) ? 2u : 1u;
+                if (lane == (uint32_t)__ffsll((long long)active) - 1) atomicAdd(sp.light_evals, (unsigned long long)__popcll(active) * k);
             }
-            v2 ar = {sr, 0.0f}, ag = {sg, 0.0f}, ab = {sb, 0.0f};
-            const v2 wx = splat<v2>(world.x), wy = splat<v2>(world.y), wz = splat<v2>(world.z);
-            for (uint32_t p = 0; p < n_pairs; ++p) {
-                const float4 A = llights[3 * p], Bq = llights[3 * p + 1], C = llights[3 * p + 2];
-                const v2 dx = (v2){A.x, A.y} - wx, dy = (v2){A.z, A.w} - wy, dz = (v2){Bq.x, Bq.y} - wz;
-                const v2 nd = fma_t(splat<v2>(n.z), dz, fma_t(splat<v2>(n.y), dy, splat<v2>(n.x) * dx));
-                // exact culling 2: n.wi <= 0 zeroes a light (forward.hlsl:191-192); skip the pair when that holds for
-                // both lights in every live lane of the wave
-                if (sp.culling && __ballot(live && (nd.x > 0.0f || nd.y > 0.0f)) == 0ull) continue;
-                accumulate_light<v2, true>(px, dx, dy, dz, nd, (v2){Bq.z, Bq.w}, (v2){C.x, C.y}, (v2){C.z, C.w}, ar, ag, ab);
-                if (sp.light_evals) {
-                    const unsigned long long active = __ballot(1);
-                    const uint32_t k = (2 * p + 1 < sp.n_lights) ? 2u : 1u;
-                    if (lane == (uint32_t)__ffsll((long long)active) - 1) atomicAdd(sp.light_evals, (unsigned long long)__popcll(active) * k);
-                }
-            }
-            color = mk(ar.x + ar.y, ag.x + ag.y, ab.x + ab.y);
         }
-        if (covered) color = color + base * sp.ambient;
-        if (in_frame) {
-            const f3 l = post_process(color, sp.tm_method, sp.inv_gamma, sp.exposure);
-            const size_t o = (size_t)y * sp.width + x;
-            reinterpret_cast<uint32_t *>(sp.out_rgba8)[o] = unorm8(l.x) | (unorm8(l.y) << 8) | (unorm8(l.z) << 16) | 0xFF000000u;
-            if (sp.out_ldr) { sp.out_ldr[o * 3] = l.x; sp.out_ldr[o * 3 + 1] = l.y; sp.out_ldr[o * 3 + 2] = l.z; }
-            if (sp.out_hdr) { sp.out_hdr[o * 3] = color.x; sp.out_hdr[o * 3 + 1] = color.y; sp.out_hdr[o * 3 + 2] = color.z; }
-        }
-        t = tn;
+        store_pixel(sp, o, mk(ar.x + ar.y, ag.x + ag.y, ab.x + ab.y) + base * sp.ambient);
     }
 }
 
@@ -438,15 +499,18 @@ __global__ __launch_bounds__(256) void k_post_process(const float4 *__restrict__
 
 }  // namespace
 
-size_t shade_lds_bytes(const ShadeParams &sp) {
-    return (256 + (sp.desc_in_lds ? (size_t)sp.n_materials * 12 : 0) + (size_t)((sp.n_lights + 1) / 2) * 12) * sizeof(float);
-}
-
-hipError_t launch_shade(const ShadeParams &sp, uint32_t max_blocks, hipStream_t s) {
+// the shading pass = reset the stream counter, k_material over every tile, k_light over the lit pixels it produced
+hipError_t launch_shade(const ShadeParams &sp, uint32_t light_blocks, hipStream_t s) {
     uint32_t n_tiles = sp.tiles_x * sp.tiles_y;
     if (n_tiles == 0) return hipSuccess;
-    uint32_t blocks = std::min((n_tiles + 3) / 4, max_blocks);
-    k_shade<<<blocks, 256, shade_lds_bytes(sp), s>>>(sp);
+    hipError_t e = hipMemsetAsync(sp.lit_count, 0, LIT_SHARDS * LIT_COUNTER_STRIDE * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    size_t lds_a = (256 + (size_t)sp.n_materials * 12) * sizeof(float);
+    uint32_t bpr = (sp.tiles_x + 3) / 4, row_groups = (sp.tiles_y + 7) / 8;
+    k_material<<<row_groups * 8 * bpr, 256, lds_a, s>>>(sp);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    size_t lds_b = std::max<size_t>(16, (size_t)((sp.n_lights + 1) / 2) * 12 * sizeof(float));
+    k_light<<<std::max(1u, std::min(light_blocks, (n_tiles + 3) / 4)), 256, lds_b, s>>>(sp);
     return hipGetLastError();
 }
 

@@ -174,8 +174,8 @@ class Renderer:
         return ldr, hdr, rgba
 
     def stats(self):
-        s = np.zeros(6, np.uint64)
-        self._check(self.L.arctic_stats(self.h, _ptr(s), 6))
+        s = np.zeros(8, np.uint64)
+        self._check(self.L.arctic_stats(self.h, _ptr(s), 8))
         return s
 
     def set_option(self, name, value):

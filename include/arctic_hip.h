@@ -239,6 +239,7 @@ int arctic_stats(ArcticRenderer *r, uint64_t *out, uint32_t n);
 #define ARCTIC_OPT_KEEP_FLOAT_OUTPUT 1 /* 1 = shade also stores float LDR+HDR planes (tests); 0 = RGBA8 only (bench) */
 #define ARCTIC_OPT_COUNT_LIGHT_EVALS 2 /* 1 = shade counts evaluated lights per pixel (slower) */
 #define ARCTIC_OPT_CULLING           3 /* 0 = evaluate every light for every pixel; 1 = exact wave-level culling (default) */
+#define ARCTIC_OPT_DEBUG             4 /* timing experiments only (wrong images): bit 0 skip material textures, bit 1 skip shadow test */
 int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value);
 
 /* library/ABI version: major*10000 + minor*100 + patch */

@@ -9,6 +9,7 @@ r=sc.upload(pkg.Renderer(sc.width,sc.height,sc.shadow_size,sc.max_lights))
 r.pass_shadow_map(sc.desc); r.pass_gbuffer(sc.desc); r.flush()
 if mode=="nolights": r.update_lights(sc.lights[:0])
 if mode=="nocull": r.set_option("culling",0)
+if mode.startswith("dbg"): r.set_option("debug", int(mode[3:])); r.update_lights(sc.lights[:0])
 for i in range(5):
     r.pass_shade(sc.desc, sc.settings)
 r.flush()
