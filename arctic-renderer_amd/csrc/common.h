@@ -111,7 +111,15 @@ struct ShadeParams {
     uint32_t *lit_px;                   // pixel index y*width + x inside the shard
     uint32_t *lit_count;                // LIT_SHARDS counters, LIT_COUNTER_STRIDE apart
     int32_t debug;                      // timing experiments only: 1 skip material textures, 2 skip shadow test
-    uint32_t lit_shard_cap;             // records per shard: ceil(workgroups / LIT_SHARDS) * 256, cannot overflow
+    uint32_t lit_shard_cap;             // records per shard of one band: ceil(band workgroups / LIT_SHARDS) * 256, cannot overflow
+    uint32_t band, n_bands;             // set by launch_shade
+};
+constexpr uint32_t MAX_BANDS = 16;
+struct ShadeLaunch {
+    hipStream_t main, aux;
+    hipEvent_t band_done[MAX_BANDS], aux_done;
+    uint32_t n_bands, light_blocks;
+    hipEvent_t mid;   // optional: recorded between k_material and k_light (single band), for per-kernel timing
 };
 constexpr uint32_t LIT_SHARDS = 256, LIT_COUNTER_STRIDE = 32;
 constexpr uint32_t MAX_LDS_MATERIALS = 512;   // 24 KiB of descriptors
@@ -135,7 +143,7 @@ hipError_t launch_resolve(const unsigned long long *vis, const SetupRec *recs, c
                           const GeomParams *gp, uint32_t n_tiles, GBuffer g, float *depth_out, uint32_t *src_out, hipStream_t s);
 hipError_t launch_fill_u64(unsigned long long *p, unsigned long long v, size_t n, hipStream_t s);
 hipError_t launch_fill_u32(uint32_t *p, uint32_t v, size_t n, hipStream_t s);
-hipError_t launch_shade(const ShadeParams &sp, uint32_t light_blocks, hipStream_t s);
+hipError_t launch_shade(const ShadeParams &sp, const ShadeLaunch &L);
 hipError_t launch_post_process(const float4 *hdr, uint32_t w, uint32_t h, int32_t tm, float inv_gamma, float exposure,
                                uint8_t *rgba8, float *ldr, hipStream_t s);
 hipError_t launch_gbuffer_tile(GBuffer g, float *attrs, uint32_t *mat, uint32_t width, uint32_t rows,

@@ -63,7 +63,7 @@ struct ArcticRenderer {
         d_recs, d_tile_count, d_tile_offset, d_scan, d_gp, d_stage;
     uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int keep_float = 0, count_evals = 0, culling = 1, debug = 0;
-    uint32_t shade_blocks = 1024;   // persistent grid of k_shade: CUs x blocks per CU
+    ShadeLaunch launch{};           // streams, events, band count and k_light's persistent grid
     std::string err;
 
     int fail(int code, const char *fmt, ...) {
@@ -77,7 +77,11 @@ struct ArcticRenderer {
     }
     uint32_t rows() const { return row_end - row_begin; }
     // records per shard of the lit-pixel stream: workgroup (ty, col) goes to shard (ty * bpr + col) % LIT_SHARDS
-    uint32_t lit_shard_cap() const { uint32_t bpr = (tiles_x + 3) / 4; return ((tiles_y * bpr + LIT_SHARDS - 1) / LIT_SHARDS) * 256; }
+    uint32_t lit_shard_cap() const {
+        uint32_t bpr = (tiles_x + 3) / 4, row_groups = (tiles_y + 7) / 8, nb = std::max(1u, std::min(launch.n_bands, row_groups));
+        uint32_t band_blocks = ((row_groups + nb - 1) / nb) * 8 * bpr;
+        return ((band_blocks + LIT_SHARDS - 1) / LIT_SHARDS) * 256;
+    }
     size_t n_tiles() const { return (size_t)tiles_x * tiles_y; }
     GBuffer gbuffer() const { return GBuffer{d_p0.as<float4>(), d_p1.as<float4>(), d_p2.as<float4>(), d_p3.as<float4>(), d_p4.as<float>()}; }
 };
@@ -112,12 +116,12 @@ int alloc_targets(ArcticRenderer *r) {
     HIPCHECK(r, r->d_rgba8.ensure(out_px * 4));
     HIPCHECK(r, r->d_counter.ensure(64));
     {
-        size_t cap = (size_t)r->lit_shard_cap() * LIT_SHARDS;
+        size_t cap = (size_t)r->lit_shard_cap() * LIT_SHARDS * std::max(1u, r->launch.n_bands);   // re-checked per frame: the band count is an option
         HIPCHECK(r, r->d_lit0.ensure(cap * 16));
         HIPCHECK(r, r->d_lit1.ensure(cap * 16));
         HIPCHECK(r, r->d_lit2.ensure(cap * 16));
         HIPCHECK(r, r->d_litpx.ensure(cap * 4));
-        HIPCHECK(r, r->d_litcount.ensure((size_t)LIT_SHARDS * LIT_COUNTER_STRIDE * 4));
+        HIPCHECK(r, r->d_litcount.ensure((size_t)MAX_BANDS * LIT_SHARDS * LIT_COUNTER_STRIDE * 4));
     }
     r->have_gbuffer = r->have_output = false;
     return ARCTIC_OK;
@@ -285,6 +289,11 @@ int fill_shade_params(ArcticRenderer *r, const ArcticScene *sc, const ArcticSett
     sp.lit_r0 = r->d_lit0.as<float4>(); sp.lit_r1 = r->d_lit1.as<float4>(); sp.lit_r2 = r->d_lit2.as<float4>();
     sp.lit_px = r->d_litpx.as<uint32_t>(); sp.lit_count = r->d_litcount.as<uint32_t>();
     sp.lit_shard_cap = r->lit_shard_cap();
+    {
+        size_t cap = (size_t)sp.lit_shard_cap * LIT_SHARDS * r->launch.n_bands;
+        HIPCHECK(r, r->d_lit0.ensure(cap * 16)); HIPCHECK(r, r->d_lit1.ensure(cap * 16)); HIPCHECK(r, r->d_lit2.ensure(cap * 16)); HIPCHECK(r, r->d_litpx.ensure(cap * 4));
+        sp.lit_r0 = r->d_lit0.as<float4>(); sp.lit_r1 = r->d_lit1.as<float4>(); sp.lit_r2 = r->d_lit2.as<float4>(); sp.lit_px = r->d_litpx.as<uint32_t>();
+    }
     return ARCTIC_OK;
 }
 
@@ -293,16 +302,16 @@ int pass_shade(ArcticRenderer *r, const ArcticScene *sc, const ArcticSettings *s
     int rc = fill_shade_params(r, sc, st, d_out, sp);
     if (rc != ARCTIC_OK) return rc;
     if (sp.light_evals) HIPCHECK(r, hipMemsetAsync(r->d_counter.p, 0, 8, r->stream));
-    HIPCHECK(r, launch_shade(sp, r->shade_blocks, r->stream));
+    HIPCHECK(r, launch_shade(sp, r->launch));
     if (sp.light_evals) {
         unsigned long long n = 0;
-        std::vector<uint32_t> counts((size_t)LIT_SHARDS * LIT_COUNTER_STRIDE);
+        std::vector<uint32_t> counts((size_t)r->launch.n_bands * LIT_SHARDS * LIT_COUNTER_STRIDE);
         HIPCHECK(r, hipMemcpyAsync(&n, r->d_counter.p, 8, hipMemcpyDeviceToHost, r->stream));
         HIPCHECK(r, hipMemcpyAsync(counts.data(), sp.lit_count, counts.size() * 4, hipMemcpyDeviceToHost, r->stream));
         HIPCHECK(r, hipStreamSynchronize(r->stream));
         r->stats[5] = n;
         r->stats[6] = 0;
-        for (uint32_t k = 0; k < LIT_SHARDS; ++k) r->stats[6] += counts[(size_t)k * LIT_COUNTER_STRIDE];
+        for (uint32_t k = 0; k < r->launch.n_bands * LIT_SHARDS; ++k) r->stats[6] += counts[(size_t)k * LIT_COUNTER_STRIDE];
     }
     r->have_output = (d_out == nullptr);
     return ARCTIC_OK;
@@ -343,7 +352,13 @@ ArcticRenderer *arctic_create(const ArcticCreateInfo *info, char *err, uint64_t 
     {
         hipDeviceProp_t prop;
         if ((e = hipGetDeviceProperties(&prop, r->device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
-        r->shade_blocks = (uint32_t)std::max(1, prop.multiProcessorCount) * 4;   // 4 workgroups of 4 waves per CU
+        r->launch.light_blocks = (uint32_t)std::max(1, prop.multiProcessorCount) * 4;   // k_light: persistent, 4 workgroups of 4 waves per CU
+        r->launch.n_bands = 1;
+        r->launch.main = r->stream;
+        if ((e = hipStreamCreateWithFlags(&r->launch.aux, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate aux", e);
+        for (uint32_t k = 0; k < MAX_BANDS; ++k)
+            if ((e = hipEventCreateWithFlags(&r->launch.band_done[k], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+        if ((e = hipEventCreateWithFlags(&r->launch.aux_done, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     }
     float lut[256];
     for (int i = 0; i < 256; ++i) lut[i] = srgb8_to_linear(i);
@@ -364,6 +379,9 @@ ArcticRenderer *arctic_create(const ArcticCreateInfo *info, char *err, uint64_t 
 void arctic_destroy(ArcticRenderer *r) {
     if (!r) return;
     (void)hipSetDevice(r->device);
+    if (r->launch.aux) { (void)hipStreamSynchronize(r->launch.aux); (void)hipStreamDestroy(r->launch.aux); }
+    for (uint32_t k = 0; k < MAX_BANDS; ++k) if (r->launch.band_done[k]) (void)hipEventDestroy(r->launch.band_done[k]);
+    if (r->launch.aux_done) (void)hipEventDestroy(r->launch.aux_done);
     if (r->stream) { (void)hipStreamSynchronize(r->stream); (void)hipStreamDestroy(r->stream); }
     for (Mesh &m : r->meshes) { if (m.d_vertices) (void)hipFree(m.d_vertices); if (m.d_indices) (void)hipFree(m.d_indices); }
     for (void *p : r->tex_allocs) (void)hipFree(p);
@@ -539,23 +557,36 @@ int arctic_post_process(ArcticRenderer *r, const float *hdr, uint32_t w, uint32_
 
 int arctic_time_shade(ArcticRenderer *r, const ArcticScene *scene, const ArcticSettings *settings, uint32_t warmup, uint32_t iters,
                       float *ms_each) {
+    return arctic_time_shade_split(r, scene, settings, warmup, iters, ms_each, nullptr, nullptr);
+}
+
+int arctic_time_shade_split(ArcticRenderer *r, const ArcticScene *scene, const ArcticSettings *settings, uint32_t warmup,
+                            uint32_t iters, float *ms_each, float *ms_material, float *ms_light) {
     if (!r) return ARCTIC_E_INVALID;
     if (!scene || !settings || !ms_each || iters == 0) return r->fail(ARCTIC_E_INVALID, "time_shade: bad arguments");
+    const bool split = ms_material || ms_light;
+    if (split && r->launch.n_bands != 1) return r->fail(ARCTIC_E_STATE, "time_shade_split: per-kernel times need ARCTIC_OPT_BANDS = 1");
     int rc = select_device(r);
     if (rc) return rc;
     ShadeParams sp;
     if ((rc = fill_shade_params(r, scene, settings, nullptr, sp)) != ARCTIC_OK) return rc;
     sp.light_evals = nullptr;
-    for (uint32_t i = 0; i < warmup; ++i) HIPCHECK(r, launch_shade(sp, r->shade_blocks, r->stream));
-    std::vector<hipEvent_t> ev(2 * (size_t)iters);
+    for (uint32_t i = 0; i < warmup; ++i) HIPCHECK(r, launch_shade(sp, r->launch));
+    std::vector<hipEvent_t> ev(3 * (size_t)iters);
     for (auto &e : ev) HIPCHECK(r, hipEventCreate(&e));
     for (uint32_t i = 0; i < iters; ++i) {
-        HIPCHECK(r, hipEventRecord(ev[2 * i], r->stream));
-        HIPCHECK(r, launch_shade(sp, r->shade_blocks, r->stream));
-        HIPCHECK(r, hipEventRecord(ev[2 * i + 1], r->stream));
+        ShadeLaunch L = r->launch;
+        L.mid = split ? ev[3 * i + 1] : nullptr;
+        HIPCHECK(r, hipEventRecord(ev[3 * i], r->stream));
+        HIPCHECK(r, launch_shade(sp, L));
+        HIPCHECK(r, hipEventRecord(ev[3 * i + 2], r->stream));
     }
     HIPCHECK(r, hipStreamSynchronize(r->stream));
-    for (uint32_t i = 0; i < iters; ++i) HIPCHECK(r, hipEventElapsedTime(&ms_each[i], ev[2 * i], ev[2 * i + 1]));
+    for (uint32_t i = 0; i < iters; ++i) {
+        HIPCHECK(r, hipEventElapsedTime(&ms_each[i], ev[3 * i], ev[3 * i + 2]));
+        if (ms_material) HIPCHECK(r, hipEventElapsedTime(&ms_material[i], ev[3 * i], ev[3 * i + 1]));
+        if (ms_light) HIPCHECK(r, hipEventElapsedTime(&ms_light[i], ev[3 * i + 1], ev[3 * i + 2]));
+    }
     for (auto &e : ev) (void)hipEventDestroy(e);
     r->have_output = true;
     return ARCTIC_OK;
@@ -667,6 +698,10 @@ int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value) {
     case ARCTIC_OPT_COUNT_LIGHT_EVALS: r->count_evals = value != 0; break;
     case ARCTIC_OPT_CULLING: r->culling = value != 0; break;
     case ARCTIC_OPT_DEBUG: r->debug = (int)value; break;
+    case ARCTIC_OPT_BANDS:
+        if (value < 1 || value > (int64_t)MAX_BANDS) return r->fail(ARCTIC_E_INVALID, "set_option: bands must be 1..%u", MAX_BANDS);
+        r->launch.n_bands = (uint32_t)value;
+        break;
     default: return r->fail(ARCTIC_E_INVALID, "set_option: unknown option %u", option);
     }
     return ARCTIC_OK;

@@ -272,7 +272,9 @@ def config2(scale=1.0, tex=None):
 def atrium(width, height, shadow_size, n_lights, scale=1.0, tex=None, tm=TM_ACES, seed=3, name="atrium"):
     """Sponza stand-in (configs 3-5): closed 30 x 14 x 12 m hall, two storeys of 2 x 10 columns, balconies,
     ceiling with a 20 x 6 m opening the sun shines through; camera inside -> 100 % pixel coverage,
-    near-plane and guard-band clipping exercised, overdraw 2-3x."""
+    near-plane and guard-band clipping exercised, overdraw 2-3x.  UV tiling repeats every 4 m, i.e. 1024^2 textures are
+    sampled at ~1 texel per pixel at 4K from ~10 m ("~1:1 texel density"; the reference has one mip level,
+    rhi.cpp:550, so anything denser is pure minification overfetch)."""
     rng = np.random.default_rng(SEED + seed)
     tex = tex or max(64, int(1024 * scale))
     q = max(0.1, scale)
@@ -285,26 +287,26 @@ def atrium(width, height, shadow_size, n_lights, scale=1.0, tex=None, tm=TM_ACES
         objs.append((np.eye(4, dtype=np.float32) if trs is None else trs, len(meshes) - 1))
 
     X, Z, H = 15.0, 7.0, 12.0
-    add(quad((-X, 0, Z), (2 * X, 0, 0), (0, 0, -2 * Z), g(30), g(14), (15.0, 7.0)), 0)                  # floor (+y)
+    add(quad((-X, 0, Z), (2 * X, 0, 0), (0, 0, -2 * Z), g(30), g(14), (7.5, 3.5)), 0)                  # floor (+y)
     # ceiling (-y) around the opening x in [-10,10], z in [-3,3]
-    ceil = [quad((-X, H, -Z), (2 * X, 0, 0), (0, 0, 4.0), g(30), g(4), (15.0, 2.0)),
-            quad((-X, H, 3.0), (2 * X, 0, 0), (0, 0, 4.0), g(30), g(4), (15.0, 2.0)),
-            quad((-X, H, -3.0), (5.0, 0, 0), (0, 0, 6.0), g(5), g(6), (2.5, 3.0)),
-            quad((10.0, H, -3.0), (5.0, 0, 0), (0, 0, 6.0), g(5), g(6), (2.5, 3.0))]
+    ceil = [quad((-X, H, -Z), (2 * X, 0, 0), (0, 0, 4.0), g(30), g(4), (7.5, 1.0)),
+            quad((-X, H, 3.0), (2 * X, 0, 0), (0, 0, 4.0), g(30), g(4), (7.5, 1.0)),
+            quad((-X, H, -3.0), (5.0, 0, 0), (0, 0, 6.0), g(5), g(6), (1.25, 1.5)),
+            quad((10.0, H, -3.0), (5.0, 0, 0), (0, 0, 6.0), g(5), g(6), (1.25, 1.5))]
     add(merge(ceil), 1)
-    add(quad((X, 0, -Z), (0, 0, 2 * Z), (0, H, 0), g(14), g(12), (7.0, 6.0)), 2)      # far wall x=+15 (faces -x)
-    add(quad((-X, 0, Z), (0, 0, -2 * Z), (0, H, 0), g(14), g(12), (7.0, 6.0)), 3)     # back wall x=-15 (faces +x)
-    add(quad((X, 0, Z), (-2 * X, 0, 0), (0, H, 0), g(30), g(12), (15.0, 6.0)), 4)     # wall z=+7 (faces -z)
-    add(quad((-X, 0, -Z), (2 * X, 0, 0), (0, H, 0), g(30), g(12), (15.0, 6.0)), 5)    # wall z=-7 (faces +z)
+    add(quad((X, 0, -Z), (0, 0, 2 * Z), (0, H, 0), g(14), g(12), (3.5, 3.0)), 2)      # far wall x=+15 (faces -x)
+    add(quad((-X, 0, Z), (0, 0, -2 * Z), (0, H, 0), g(14), g(12), (3.5, 3.0)), 3)     # back wall x=-15 (faces +x)
+    add(quad((X, 0, Z), (-2 * X, 0, 0), (0, H, 0), g(30), g(12), (7.5, 3.0)), 4)     # wall z=+7 (faces -z)
+    add(quad((-X, 0, -Z), (2 * X, 0, 0), (0, H, 0), g(30), g(12), (7.5, 3.0)), 5)    # wall z=-7 (faces +z)
     for s, mat in ((1.0, 6), (-1.0, 7)):                                              # balconies at y = 6
         z_in, z_out = 4.0 * s, Z * s
-        top = quad((-X, 6.0, max(z_in, z_out)), (2 * X, 0, 0), (0, 0, -3.0), g(30), g(3), (15.0, 1.5))
-        bot = quad((-X, 5.7, min(z_in, z_out)), (2 * X, 0, 0), (0, 0, 3.0), g(30), g(3), (15.0, 1.5))
-        edge = (quad((X, 5.7, z_in), (-2 * X, 0, 0), (0, 0.3, 0), g(30), 1, (15.0, 0.15)) if s > 0 else
-                quad((-X, 5.7, z_in), (2 * X, 0, 0), (0, 0.3, 0), g(30), 1, (15.0, 0.15)))
+        top = quad((-X, 6.0, max(z_in, z_out)), (2 * X, 0, 0), (0, 0, -3.0), g(30), g(3), (7.5, 0.75))
+        bot = quad((-X, 5.7, min(z_in, z_out)), (2 * X, 0, 0), (0, 0, 3.0), g(30), g(3), (7.5, 0.75))
+        edge = (quad((X, 5.7, z_in), (-2 * X, 0, 0), (0, 0.3, 0), g(30), 1, (7.5, 0.075)) if s > 0 else
+                quad((-X, 5.7, z_in), (2 * X, 0, 0), (0, 0.3, 0), g(30), 1, (7.5, 0.075)))
         add(merge([top, bot, edge]), mat)
-    col_lo = cylinder(0.35, 0.0, 5.7, max(8, int(32 * q)), max(2, int(64 * q)), (2.0, 6.0))
-    col_hi = cylinder(0.30, 6.0, 12.0, max(8, int(32 * q)), max(2, int(64 * q)), (2.0, 6.0))
+    col_lo = cylinder(0.35, 0.0, 5.7, max(8, int(32 * q)), max(2, int(64 * q)), (0.5, 1.5))
+    col_hi = cylinder(0.30, 6.0, 12.0, max(8, int(32 * q)), max(2, int(64 * q)), (0.5, 1.5))
     k = 0
     for base in (col_lo, col_hi):                                                     # one mesh per column: a mesh owns its material
         for zrow in (-4.5, 4.5):

@@ -16,9 +16,9 @@ the RCCL gather of the finished RGBA8 shards on rank 0 (the path's one real exch
 work is fixed -> "scaling": "strong".
 
 The JSON line also carries
-  roofline     achieved = 80 B x shaded pixels / mean kernel time (HIP events on the launch stream)
-               against the 8 TB/s HBM peak (the VALU roof is reported next to it: with 65 light
-               evaluations per lit pixel the kernel is FP32-VALU bound)
+  roofline     achieved = 80 B x shaded pixels / mean time of the pass's two kernels (HIP events on
+               the launch stream) against the 8 TB/s HBM peak; per-kernel times and rates next to it
+               (k_light, 65 light evaluations per lit pixel, is FP32-VALU bound: SURVEY.md 7.3-1)
   cpu_baseline the CPU oracle (scalar C++ port of the same HLSL math) shading a bounded stripe of
                the SAME G-buffer on this host's cores -- a baseline, not the target.
 """
@@ -123,19 +123,26 @@ def main():
     else:
         shaded = shaded_local
 
-    # roofline of the dominant kernel (k_shade), HIP events around each launch on its own stream
-    ms = r.time_shade(sc.desc, sc.settings, warmup=3, iters=max(10, min(args.steps, 50)))
-    kernel_ms = float(np.mean(ms))
-    achieved = shaded_local * BYTES_PER_PIXEL / (kernel_ms * 1e-3) / 1e9
-    # the same kernel with every wave-level cull disabled: all 1 + n_lights evaluations for every pixel
+    # roofline: the shading pass is two kernels on one stream, timed with HIP events on that stream
+    #   k_material  G-buffer read + material fetch + shadow + classification   (memory bound)
+    #   k_light     sun + point lights over the lit pixels + tonemap + store   (FP32 VALU bound)
+    iters = max(10, min(args.steps, 50))
+    ms, ms_mat, ms_light = r.time_shade_split(sc.desc, sc.settings, warmup=3, iters=iters)
+    pass_ms, mat_ms, light_ms = float(np.mean(ms)), float(np.mean(ms_mat)), float(np.mean(ms_light))
+    achieved = shaded_local * BYTES_PER_PIXEL / (pass_ms * 1e-3) / 1e9
+    # the same pass with the exact culling disabled: every covered pixel evaluates the sun and all n_lights
     r.set_option("culling", 0)
     ms_nocull = float(np.mean(r.time_shade(sc.desc, sc.settings, warmup=2, iters=10)))
     r.set_option("culling", 1)
     r.set_option("count_light_evals", 1)
     r.pass_shade(sc.desc, sc.settings)
     r.flush()
-    light_evals = int(r.stats()[5])
+    st = r.stats()
+    light_evals, lit_px = int(st[5]), int(st[6])
     r.set_option("count_light_evals", 0)
+    # bytes each kernel really moves (its own figure, next to the 80 B/px algorithmic one)
+    mat_bytes = shaded_local * 76 + (shaded_local - lit_px) * 4 + lit_px * 52
+    light_bytes = lit_px * (52 + 4)
 
     result = None
     if rank == 0:
@@ -158,10 +165,16 @@ def main():
                        "scale": args.scale},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "kernel": "k_shade", "kernel_ms": round(kernel_ms, 4), "bytes_per_pixel": BYTES_PER_PIXEL,
+                         "kernel": "k_material + k_light (the shading pass)", "kernel_ms": round(pass_ms, 4),
+                         "bytes_per_pixel": BYTES_PER_PIXEL,
+                         "k_material_ms": round(mat_ms, 4), "k_material_GBps": round(mat_bytes / (mat_ms * 1e-3) / 1e9, 1),
+                         "k_light_ms": round(light_ms, 4), "k_light_GBps": round(light_bytes / (light_ms * 1e-3) / 1e9, 1),
+                         "k_light_bound": "fp32 valu", "lit_pixel_fraction": round(lit_px / max(shaded_local, 1), 4),
+                         "point_light_evals_per_lit_pixel": round(light_evals / max(lit_px, 1), 2),
+                         "point_light_evals_per_pixel": round(light_evals / max(shaded_local, 1), 2),
+                         "k_light_Gevals_per_s": round(light_evals / (light_ms * 1e-3) / 1e9, 1),
                          "kernel_ms_no_culling": round(ms_nocull, 4),
-                         "achieved_no_culling": round(shaded_local * BYTES_PER_PIXEL / (ms_nocull * 1e-3) / 1e9, 1),
-                         "point_light_evals_per_pixel": round(light_evals / max(shaded_local, 1), 2)},
+                         "achieved_no_culling": round(shaded_local * BYTES_PER_PIXEL / (ms_nocull * 1e-3) / 1e9, 1)},
         }
         if world == 1 and not args.no_cpu:
             result["cpu_baseline"] = cpu_baseline(pkg, sc, r, args.cpu_rows)
@@ -183,7 +196,8 @@ def cpu_baseline(pkg, sc, r, cpu_rows):
     o = sc.upload(O.Oracle(sc.width, sc.height, sc.shadow_size, sc.max_lights))
     if sc.shadow_size:
         o.write_shadow_map(r.read_shadow_map())
-    # calibrate on 8 rows, then size the sample for ~15 s
+    o.set_precision(32)     # the literal fp32 restatement of the HLSL: what a CPU port of the shader would run
+    # calibrate on 8 rows, then size the sample for ~15 s of wall time (whole frame, repeated, if the host is fast)
     rows0 = min(8, attrs.shape[0])
     mid = attrs.shape[0] // 2
     t = time.perf_counter()
@@ -192,14 +206,17 @@ def cpu_baseline(pkg, sc, r, cpu_rows):
     n = cpu_rows or int(max(8, min(attrs.shape[0], 15.0 / max(per_row, 1e-6))))
     n = max(4, n // 4 * 4)
     start = max(0, mid - n // 2)
+    reps, dt = 0, 0.0
     t = time.perf_counter()
-    o.shade_gbuffer(sc.desc, sc.settings, attrs[start:start + n], mat[start:start + n], threads=threads, want=("rgba8",))
-    dt = time.perf_counter() - t
+    while reps < 1 or (dt < 10.0 and reps < 50):
+        o.shade_gbuffer(sc.desc, sc.settings, attrs[start:start + n], mat[start:start + n], threads=threads, want=("rgba8",))
+        reps += 1
+        dt = time.perf_counter() - t
     px = int((mat[start:start + n] != 0xFFFFFFFF).sum())
     o.close()
-    return {"value": round(px / dt / 1e6, 3), "unit": "Mpixels/s", "cores": threads, "kind": "port",
-            "sample": f"rows {start}..{start + n} of the {sc.height}-row frame ({px} shaded pixels, {dt:.1f} s), same G-buffer, "
-                      f"shadow map and {len(sc.lights)} lights; scalar C++ oracle, {threads} threads, no culling"}
+    return {"value": round(px * reps / dt / 1e6, 3), "unit": "Mpixels/s", "cores": threads, "kind": "port",
+            "sample": f"rows {start}..{start + n} of the {sc.height}-row frame x {reps} ({px * reps} shaded pixels, {dt:.1f} s), same "
+                      f"G-buffer, shadow map and {len(sc.lights)} lights; scalar fp32 C++ oracle, {threads} threads, no culling"}
 
 
 if __name__ == "__main__":

@@ -205,6 +205,12 @@ int arctic_post_process(ArcticRenderer *r, const float *hdr_rgba32f, uint32_t w,
 int arctic_time_shade(ArcticRenderer *r, const ArcticScene *scene, const ArcticSettings *settings,
                       uint32_t warmup, uint32_t iters, float *ms_each);
 
+/* same, additionally splitting each pass at the boundary between its two kernels: ms_material = material fetch +
+ * shadow + classification (k_material), ms_light = sun + point lights + tonemap over the lit pixels (k_light).
+ * Either may be NULL. */
+int arctic_time_shade_split(ArcticRenderer *r, const ArcticScene *scene, const ArcticSettings *settings,
+                            uint32_t warmup, uint32_t iters, float *ms_each, float *ms_material, float *ms_light);
+
 /* ---- read-back / injection for tests ------------------------------------- */
 
 /* G-buffer of this shard, de-tiled to row-major: attrs = rows*width*18 floats
@@ -231,8 +237,9 @@ int arctic_frame_constants(const ArcticScene *scene, float *proj_view, float *li
 
 /* counters of the last frame: [0] setup triangles (forward), [1] raster work
  * items (forward), [2] setup triangles (shadow), [3] raster work items
- * (shadow), [4] shaded (covered) pixels, [5] point-light evaluations summed
- * over pixels (only when stats were requested with arctic_set_option). */
+ * (shadow), [4] reserved, [5] point-light evaluations summed over pixels and
+ * [6] lit pixels handed to the light kernel (both only with
+ * ARCTIC_OPT_COUNT_LIGHT_EVALS), [7] reserved.  n <= 8. */
 int arctic_stats(ArcticRenderer *r, uint64_t *out, uint32_t n);
 
 /* tuning / debug switches. */
@@ -240,6 +247,7 @@ int arctic_stats(ArcticRenderer *r, uint64_t *out, uint32_t n);
 #define ARCTIC_OPT_COUNT_LIGHT_EVALS 2 /* 1 = shade counts evaluated lights per pixel (slower) */
 #define ARCTIC_OPT_CULLING           3 /* 0 = evaluate every light for every pixel; 1 = exact wave-level culling (default) */
 #define ARCTIC_OPT_DEBUG             4 /* timing experiments only (wrong images): bit 0 skip material textures, bit 1 skip shadow test */
+#define ARCTIC_OPT_BANDS             5 /* 1..16 interleaved screen bands the two shading kernels are pipelined over (default 1: no gain measured) */
 int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value);
 
 /* library/ABI version: major*10000 + minor*100 + patch */

@@ -11,6 +11,9 @@ def t(r, label, settings=None):
     ms=r.time_shade(sc.desc, settings or sc.settings, warmup=3, iters=15)
     print(f"{label:40s} {np.median(ms):.4f} ms  (min {ms.min():.4f})", flush=True)
 r=mk()
+for nb in (1,2,4,8,16):
+    r.set_option("bands",nb); t(r,f"full (culling) bands={nb}")
+r.set_option("bands",4)
 t(r,"full (culling)")
 r.set_option("culling",0); t(r,"full (no culling)"); r.set_option("culling",1)
 r.update_lights(sc.lights[:0]); t(r,"0 lights")
