@@ -28,8 +28,7 @@ def gather_rows(shard, gathered, rank, world, root=0, group=None):
     rather than an equal-count ncclGather; when all counts are equal dist.gather is used."""
     if world == 1:
         return shard
-    sizes_equal = gathered is None or all(g.shape == gathered[0].shape for g in gathered)
-    if sizes_equal and _all_equal_rows(shard, world, group):
+    if _all_equal_rows(shard, world, group):   # decided collectively: every rank must take the same branch
         dist.gather(shard, gather_list=gathered if rank == root else None, dst=root, group=group)
     elif rank == root:
         gathered[root].copy_(shard)

@@ -99,3 +99,134 @@ def test_culling_is_exact(pair):
     b = r.read_output()[0]
     r.set_option("culling", 1)
     assert np.abs(a - b).max() <= 2e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# beyond the per-scene fixtures: sharding, odd inputs, the stand-alone post-process kernel, full-size properties
+# ---------------------------------------------------------------------------------------------------------------
+def test_row_shards_equal_full_frame(pkg, oracle, hip):
+    """multi-GPU invariant: the frame assembled from row shards is bit-identical to the single-device frame.
+    The cut at row 37 is deliberately not a multiple of the 8-pixel tile."""
+    sc = pkg.scenes.config3(scale=0.1)
+    full = sc.upload(hip.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights))
+    ref = full.render_frame(sc.desc, sc.settings)
+    for cuts in ([0, 37, sc.height], [0, 64, 128, sc.height]):
+        parts = []
+        for b, e in zip(cuts, cuts[1:]):
+            r = sc.upload(hip.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights, row_begin=b, row_end=e))
+            parts.append(r.render_frame(sc.desc, sc.settings))
+            assert parts[-1].shape == (e - b, sc.width, 4)
+            r.close()
+        np.testing.assert_array_equal(np.concatenate(parts, 0), ref)
+    full.close()
+
+
+def test_materials_with_unequal_texture_sizes(pkg, oracle, hip):
+    """equal-size triples are stored interleaved; this exercises the other layout (and the fallback 16x16 textures)."""
+    rng = np.random.default_rng(21)
+    sc = pkg.scenes.config2(scale=0.2)
+    mats = []
+    for k, (d, n, m) in enumerate(sc.materials):
+        if k % 3 == 0:
+            mats.append((d, n[::2, ::2].copy(), m[::4, ::2].copy()))          # three different sizes, not square
+        elif k % 3 == 1:
+            mats.append(pkg.scenes.fallback_textures())                       # white / flat normal / white
+        else:
+            mats.append((d, n, m))
+    sc.materials = mats
+    o, r = build_pair(pkg, oracle, hip, sc)
+    ref = o.render_frame(sc.desc, sc.settings)
+    img = r.render_frame(sc.desc, sc.settings)
+    err = np.abs(r.read_output()[0] - o.read_output()[0])
+    assert err.max() <= TOL
+    assert np.abs(img.astype(np.int16) - ref.astype(np.int16)).max() <= 1
+    r.close()
+
+
+@pytest.mark.parametrize("tm", [0, 1, 2, 5])
+def test_post_process_kernel(pkg, oracle, hip, tm):
+    """PostProcessPass::run alone (post_process.hlsl:59-93) on an arbitrary HDR image, incl. 0, huge and negative values."""
+    rng = np.random.default_rng(tm)
+    hdr = np.abs(rng.standard_normal((64, 96, 4)).astype(np.float32)) * rng.choice([0.01, 1.0, 50.0], (64, 96, 1)).astype(np.float32)
+    hdr[0, 0] = 0.0
+    hdr[0, 1] = (-0.25, 1e6, 1e-8, 1.0)
+    r = hip.Renderer(16, 16, 0, 16)
+    out, ldr = r.post_process(hdr, (tm, 2.2, 1.3))
+    want = np.empty((64, 96, 3), np.float64)
+    from test_oracle_kat import tonemap64
+    for y in range(64):
+        for x in range(96):
+            want[y, x] = tonemap64(tm if tm in (1, 2) else 0, hdr[y, x, :3].astype(np.float64), 2.2, 1.3)[1]
+    assert np.abs(ldr - want).max() <= TOL
+    q = np.clip(np.floor(np.clip(want, 0, 1) * 255 + 0.5), 0, 255)
+    assert np.abs(out[..., :3].astype(np.float64) - q).max() <= 1 and (out[..., 3] == 255).all()
+    r.close()
+
+
+def test_full_size_random_gbuffer_properties(pkg, oracle, hip):
+    """BASELINE's full 4K size on a RANDOM G-buffer (no rasteriser involved): a stripe against the oracle, culling
+    on == off, and a two-shard run == the full run -- properties that do not need the oracle at 8.3 M pixels."""
+    sc = pkg.scenes.config3(scale=1.0, tex=128)
+    W, H = sc.width, sc.height
+    assert (W, H) == (3840, 2160)
+    rng = np.random.default_rng(99)
+    r = sc.upload(hip.Renderer(W, H, sc.shadow_size, sc.max_lights))
+    r.set_option("keep_float_output", 1)
+    from importlib import import_module
+    lpv = import_module("arctic_renderer_amd.renderer").frame_constants(sc.desc)[1]
+    attrs, mat = pkg.scenes.random_gbuffer(rng, H, W, len(sc.materials), coverage=0.97, light_proj_view=lpv)
+    smap = (0.3 + 0.5 * rng.random((sc.shadow_size, sc.shadow_size), dtype=np.float32)).astype(np.float32)
+    r.write_shadow_map(smap)
+    r.write_gbuffer(attrs, mat)
+    r.pass_shade(sc.desc, sc.settings)
+    ldr, _, rgba = r.read_output(want=("ldr", "rgba8"))
+    assert np.isfinite(ldr).all() and (rgba[..., 3] == 255).all()
+    assert (rgba[mat == 0xFFFFFFFF][:, :3] == 0).all()                      # no geometry -> black
+    # (1) a 12-row stripe against the float64 oracle
+    y0 = 1000
+    o = sc.upload(oracle.Oracle(W, H, sc.shadow_size, sc.max_lights))
+    o.write_shadow_map(smap)
+    ref = o.shade_gbuffer(sc.desc, sc.settings, attrs[y0:y0 + 12], mat[y0:y0 + 12], threads=oracle.hardware_threads(), want=("ldr", "rgba8"))
+    assert np.abs(ldr[y0:y0 + 12] - ref["ldr"]).max() <= TOL
+    assert np.abs(rgba[y0:y0 + 12].astype(np.int16) - ref["rgba8"].astype(np.int16)).max() <= 1
+    # (2) the exact culling changes nothing
+    r.set_option("culling", 0)
+    r.pass_shade(sc.desc, sc.settings)
+    assert np.abs(r.read_output(want=("ldr",))[0] - ldr).max() <= 2e-6
+    r.set_option("culling", 1)
+    r.close()
+    # (3) two row shards reproduce the full frame byte for byte
+    parts = []
+    for b, e in ((0, 1083), (1083, H)):
+        s = sc.upload(hip.Renderer(W, H, sc.shadow_size, sc.max_lights, row_begin=b, row_end=e))
+        s.write_shadow_map(smap)
+        s.write_gbuffer(attrs[b:e], mat[b:e])
+        s.pass_shade(sc.desc, sc.settings)
+        parts.append(s.read_output(want=("rgba8",))[2])
+        s.close()
+    np.testing.assert_array_equal(np.concatenate(parts, 0), rgba)
+
+
+def test_errors_and_state(pkg, hip):
+    sc = pkg.scenes.config1(scale=0.25)
+    r = hip.Renderer(sc.width, sc.height, 0, 4)
+    with pytest.raises(hip.ArcticError) as e:
+        r.pass_shade(sc.desc, sc.settings)                       # nothing to shade yet
+    assert e.value.code == -4
+    with pytest.raises(hip.ArcticError) as e:
+        r.create_mesh(sc.meshes[0][0], sc.meshes[0][1], 0)       # material 0 does not exist yet
+    assert e.value.code == -1
+    sc.upload(r)
+    with pytest.raises(hip.ArcticError):
+        r.create_mesh(sc.meshes[0][0], sc.meshes[0][1][:4], 0)   # not a triangle list
+    lights = pkg.scenes.random_lights(np.random.default_rng(1), 9, (-1, -1, -1), (1, 1, 1))
+    r.update_lights(lights)                                      # clamps to max_lights = 4 like the reference clamps to 16
+    r.set_option("count_light_evals", 1)
+    r.render_frame(sc.desc, sc.settings)
+    st = r.stats()
+    assert st[6] > 0 and st[5] == 4 * st[6]
+    r.create_hdri(np.zeros((4, 8, 4), np.float32))               # accepted and ignored (skybox out of scope)
+    r.resize(64, 48)
+    sc.desc.camera["aspect"] = 64 / 48
+    assert r.render_frame(sc.desc, sc.settings).shape == (48, 64, 4)
+    r.close()

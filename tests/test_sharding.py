@@ -1,0 +1,79 @@
+"""Row sharding + gather of the multi-GPU path, rehearsed on CPU with gloo (world_size 2 and 3).
+
+The shards are produced by the CPU oracle here (no GPU in this container); the GPU version of the same invariant
+(sharded frame == single-device frame, bit for bit) is tests/test_gpu_parity.py::test_row_shards_equal_full_frame."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_row_range_partitions_the_frame(pkg):
+    from importlib import import_module
+    sh = import_module("arctic_renderer_amd.sharding")
+    for h in (1, 7, 8, 270, 1080, 2160, 4320, 2161):
+        for w in (1, 2, 3, 4, 8):
+            if w > h:
+                continue
+            rows = [sh.row_range(h, r, w) for r in range(w)]
+            assert rows[0][0] == 0 and rows[-1][1] == h
+            assert all(a[1] == b[0] for a, b in zip(rows, rows[1:]))
+            sizes = [b - a for a, b in rows]
+            assert max(sizes) - min(sizes) <= 1
+    assert sh.row_range(2160, 3, 8) == (810, 1080) and sh.row_range(4320, 7, 8) == (3780, 4320)
+    with pytest.raises(ValueError):
+        sh.row_range(100, 4, 4)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, height_trim, out_path):
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as entry
+    from importlib import import_module
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pkg = entry.load_package()
+        sh = import_module("arctic_renderer_amd.sharding")
+        sc = pkg.scenes.config3(scale=0.04, tex=64)
+        height = sc.height - height_trim            # an odd height makes the shards unequal (send/recv path)
+        sc.desc.camera["aspect"] = sc.width / height
+        b, e = sh.row_range(height, rank, world)
+        o = O.Oracle(sc.width, height, sc.shadow_size, sc.max_lights, row_begin=b, row_end=e)
+        sc.upload(o)
+        shard = torch.from_numpy(o.render_frame(sc.desc, sc.settings, threads=2))
+        gathered = [torch.empty((sh.row_range(height, k, world)[1] - sh.row_range(height, k, world)[0], sc.width, 4), dtype=torch.uint8)
+                    for k in range(world)] if rank == 0 else None
+        sh.gather_rows(shard, gathered, rank, world)
+        if rank == 0:
+            np.save(out_path, sh.assemble(gathered).numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,trim", [(2, 0), (2, 3), (3, 1)], ids=["2-equal", "2-ragged", "3-ragged"])
+def test_gloo_gather_reassembles_the_single_process_frame(pkg, oracle, tmp_path, world, trim):
+    out = str(tmp_path / "frame.npy")
+    mp.spawn(_worker, args=(world, _free_port(), trim, out), nprocs=world, join=True)
+    got = np.load(out)
+    sc = pkg.scenes.config3(scale=0.04, tex=64)
+    height = sc.height - trim
+    sc.desc.camera["aspect"] = sc.width / height
+    ref = sc.upload(oracle.Oracle(sc.width, height, sc.shadow_size, sc.max_lights)).render_frame(sc.desc, sc.settings, threads=4)
+    assert got.shape == ref.shape
+    np.testing.assert_array_equal(got, ref)      # sharding must not change a single byte
