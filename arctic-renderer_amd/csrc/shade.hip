@@ -316,10 +316,16 @@ __device__ __forceinline__ float rrt_odt(float c) {
 }
 __device__ __forceinline__ f3 post_process(f3 c, int tm, float inv_gamma, float exposure) {
     f3 t;
-    if (tm == 1) {          // tm_exposure :44-47
+    if (tm == 1) {          // tm_exposure :44-47: 1 - exp(-c * exposure); for tiny arguments the subtraction cancels in
+                            // fp32 (1 - exp(-1e-8) = 0), so the series x - x^2/2 + x^3/6 takes over below 1/64
         const float LOG2E = 1.4426950408889634f;
-        t = mk(1.0f - __builtin_amdgcn_exp2f(-c.x * exposure * LOG2E), 1.0f - __builtin_amdgcn_exp2f(-c.y * exposure * LOG2E),
-               1.0f - __builtin_amdgcn_exp2f(-c.z * exposure * LOG2E));
+        const f3 x = mk(c.x * exposure, c.y * exposure, c.z * exposure);
+        auto one_minus_exp = [&](float v) {
+            const float direct = 1.0f - __builtin_amdgcn_exp2f(-v * LOG2E);
+            const float series = v * (1.0f + v * (-0.5f + v * (1.0f / 6.0f)));
+            return fabsf(v) < 0.015625f ? series : direct;
+        };
+        t = mk(one_minus_exp(x.x), one_minus_exp(x.y), one_minus_exp(x.z));
     } else if (tm == 2) {   // tm_aces :15-25, :50-57
         f3 i = mk(0.59719f * c.x + 0.35458f * c.y + 0.04823f * c.z, 0.07600f * c.x + 0.90834f * c.y + 0.01566f * c.z,
                   0.02840f * c.x + 0.13383f * c.y + 0.837f * c.z);
