@@ -16,16 +16,27 @@ constexpr int TILE = 8;
 constexpr int TILE_PIXELS = 64;
 constexpr uint32_t NO_MATERIAL = 0xFFFFFFFFu;
 
-// G-buffer = the interpolated VSOut (forward.hlsl:41-48) minus SV_POSITION, 76 B / pixel:
-//   p0 float4  world.xyz, material id (bits)
-//   p1 float4  light_space_position.xyzw
-//   p2 float4  uv.xy, t.xy
-//   p3 float4  t.z, b.xyz
-//   p4 float3  n.xyz            (12-byte stride)
+// G-buffer = the interpolated VSOut (forward.hlsl:41-48) minus SV_POSITION, 76 B / pixel, split by WHEN it is needed:
+//   first wave of loads, every pixel (28 B): texture coordinates, shadow lookup, material
+//     a float4  uv.xy, light_space_position.xy
+//     b float3  light_space_position.zw, material id (bits)          (12-byte stride)
+//   second wave of loads, only tiles with a lit pixel (48 B): position and tangent frame
+//     c float4  world.xyz, t.x
+//     d float4  t.yz, b.xy
+//     e float4  b.z, n.xyz
+// (a fully shadowed pixel is ambient * base: it never needs its normal or position, see k_material)
 struct GBuffer {
-    float4 *p0, *p1, *p2, *p3;
-    float *p4;
+    float4 *a;
+    float *b;
+    float4 *c, *d, *e;
 };
+__host__ __device__ inline void gbuffer_pack(const float *v /*18 attrs in VSOut order*/, uint32_t mat, float4 &A, float *B3, float4 &C, float4 &D, float4 &E) {
+    A = make_float4(v[0], v[1], v[14], v[15]);
+    B3[0] = v[16]; B3[1] = v[17]; B3[2] = __builtin_bit_cast(float, mat);
+    C = make_float4(v[11], v[12], v[13], v[2]);
+    D = make_float4(v[3], v[4], v[5], v[6]);
+    E = make_float4(v[7], v[8], v[9], v[10]);
+}
 
 // transformed vertex (the reference's VSOut), 96 B
 struct XVert {

@@ -375,11 +375,12 @@ __global__ __launch_bounds__(256) void k_resolve(const unsigned long long *__res
         mat = ob.material;
         src = t.src_tri;
     }
-    g.p0[idx] = make_float4(a[11], a[12], a[13], __uint_as_float(mat));
-    g.p1[idx] = make_float4(a[14], a[15], a[16], a[17]);
-    g.p2[idx] = make_float4(a[0], a[1], a[2], a[3]);
-    g.p3[idx] = make_float4(a[4], a[5], a[6], a[7]);
-    g.p4[idx * 3] = a[8]; g.p4[idx * 3 + 1] = a[9]; g.p4[idx * 3 + 2] = a[10];
+    {
+        float4 A, C, D, E; float B3[3];
+        gbuffer_pack(a, mat, A, B3, C, D, E);
+        g.a[idx] = A; g.c[idx] = C; g.d[idx] = D; g.e[idx] = E;
+        g.b[idx * 3] = B3[0]; g.b[idx * 3 + 1] = B3[1]; g.b[idx * 3 + 2] = B3[2];
+    }
     if (depth_out) depth_out[idx] = depth;
     if (src_out) src_out[idx] = src;
 }
@@ -413,23 +414,22 @@ __global__ __launch_bounds__(256) void k_gbuffer_tile(GBuffer g, float *attrs, u
             for (int k = 0; k < 18; ++k) a[k] = attrs[p * 18 + k];
             m = mat[p];
         }
-        g.p0[idx] = make_float4(a[11], a[12], a[13], __uint_as_float(m));
-        g.p1[idx] = make_float4(a[14], a[15], a[16], a[17]);
-        g.p2[idx] = make_float4(a[0], a[1], a[2], a[3]);
-        g.p3[idx] = make_float4(a[4], a[5], a[6], a[7]);
-        g.p4[idx * 3] = a[8]; g.p4[idx * 3 + 1] = a[9]; g.p4[idx * 3 + 2] = a[10];
+        float4 A, C, D, E; float B3[3];
+        gbuffer_pack(a, m, A, B3, C, D, E);
+        g.a[idx] = A; g.c[idx] = C; g.d[idx] = D; g.e[idx] = E;
+        g.b[idx * 3] = B3[0]; g.b[idx * 3 + 1] = B3[1]; g.b[idx * 3 + 2] = B3[2];
     } else if (in) {
         size_t p = (size_t)y * width + x;
-        float4 q0 = g.p0[idx], q1 = g.p1[idx], q2 = g.p2[idx], q3 = g.p3[idx];
+        float4 A = g.a[idx], C = g.c[idx], D = g.d[idx], E = g.e[idx];
+        float b0 = g.b[idx * 3], b1 = g.b[idx * 3 + 1], b2 = g.b[idx * 3 + 2];
         if (attrs) {
             float *a = attrs + p * 18;
-            a[0] = q2.x; a[1] = q2.y; a[2] = q2.z; a[3] = q2.w;
-            a[4] = q3.x; a[5] = q3.y; a[6] = q3.z; a[7] = q3.w;
-            a[8] = g.p4[idx * 3]; a[9] = g.p4[idx * 3 + 1]; a[10] = g.p4[idx * 3 + 2];
-            a[11] = q0.x; a[12] = q0.y; a[13] = q0.z;
-            a[14] = q1.x; a[15] = q1.y; a[16] = q1.z; a[17] = q1.w;
+            a[0] = A.x; a[1] = A.y; a[2] = C.w; a[3] = D.x; a[4] = D.y; a[5] = D.z; a[6] = D.w;
+            a[7] = E.x; a[8] = E.y; a[9] = E.z; a[10] = E.w;
+            a[11] = C.x; a[12] = C.y; a[13] = C.z;
+            a[14] = A.z; a[15] = A.w; a[16] = b0; a[17] = b1;
         }
-        if (mat) mat[p] = __float_as_uint(q0.w);
+        if (mat) mat[p] = __float_as_uint(b2);
     }
 }
 

@@ -83,7 +83,7 @@ struct ArcticRenderer {
         return ((band_blocks + LIT_SHARDS - 1) / LIT_SHARDS) * 256;
     }
     size_t n_tiles() const { return (size_t)tiles_x * tiles_y; }
-    GBuffer gbuffer() const { return GBuffer{d_p0.as<float4>(), d_p1.as<float4>(), d_p2.as<float4>(), d_p3.as<float4>(), d_p4.as<float>()}; }
+    GBuffer gbuffer() const { return GBuffer{d_p0.as<float4>(), d_p4.as<float>(), d_p1.as<float4>(), d_p2.as<float4>(), d_p3.as<float4>()}; }
 };
 
 #define HIPCHECK(r, expr)                                                                            \

@@ -345,11 +345,12 @@ __device__ __forceinline__ uint32_t unorm8(float x) {
     return (uint32_t)(x * 255.0f + 0.5f);
 }
 
-struct TileData { float4 q0, q1, q2, q3; float nx, ny, nz; };
-__device__ __forceinline__ TileData load_tile(const GBuffer &g, size_t idx) {
-    TileData t;
-    t.q0 = g.p0[idx]; t.q1 = g.p1[idx]; t.q2 = g.p2[idx]; t.q3 = g.p3[idx];
-    t.nx = g.p4[idx * 3]; t.ny = g.p4[idx * 3 + 1]; t.nz = g.p4[idx * 3 + 2];
+// first wave of G-buffer loads: what every pixel needs (28 B)
+struct TileHead { float4 a; float b0, b1, b2; };   // a = uv.xy, ls.xy; b = ls.z, ls.w, material id
+__device__ __forceinline__ TileHead load_head(const GBuffer &g, size_t idx) {
+    TileHead t;
+    t.a = g.a[idx];
+    t.b0 = g.b[idx * 3]; t.b1 = g.b[idx * 3 + 1]; t.b2 = g.b[idx * 3 + 2];
     return t;
 }
 
@@ -387,56 +388,57 @@ __global__ __launch_bounds__(256) void k_material(const ShadeParams sp) {
     const uint32_t ty = ((idx / bpr) * sp.n_bands + sp.band) * 8 + xcd, tx = (idx % bpr) * 4 + wave;   // band: see launch_shade
     const bool tile_ok = ty < sp.tiles_y && tx < sp.tiles_x;
     const uint32_t t = ty * sp.tiles_x + tx;
-    TileData cur;
-    if (tile_ok) cur = load_tile(sp.g, (size_t)t * 64 + lane);   // in flight while LDS is staged
+    TileHead cur;
+    if (tile_ok) cur = load_head(sp.g, (size_t)t * 64 + lane);   // in flight while LDS is staged
     lut[threadIdx.x] = sp.srgb_lut[threadIdx.x];
     for (uint32_t i = threadIdx.x; i < sp.n_materials * 3; i += 256) ldesc[i] = reinterpret_cast<const uint4 *>(sp.tex)[i];
     __syncthreads();
     if (!tile_ok) return;
 
+    const size_t gi = (size_t)t * 64 + lane;
     const uint32_t x = tx * 8 + (lane & 7);
     const int32_t y = (int32_t)(ty * 8 + (lane >> 3)) - (int32_t)sp.row0_in_tile;
     const bool in_frame = x < sp.width && y >= 0 && y < (int32_t)sp.rows;
-    const uint32_t mat = __float_as_uint(cur.q0.w);
+    const uint32_t mat = __float_as_uint(cur.b2);
     const bool covered = in_frame && mat < sp.n_materials;
     const size_t o = (size_t)y * sp.width + x;
 
-    f3 base = mk(0.0f, 0.0f, 0.0f), n = mk(0.0f, 0.0f, 1.0f);
-    float metal = 0.0f, rough = 1.0f, lit = 0.0f;
+    // ---- material fetch, forward.hlsl:98-124, and the shadow test: needs only uv, light-space position, material --------
+    Taps t0, t1, t2;
+    float lit = 0.0f;
     if (covered) {
-        // ---- material fetch, forward.hlsl:98-124 ----------------------------------------------------------------
-        const float u = cur.q2.x, v = cur.q2.y;
-        if (!(sp.debug & 2)) lit = 1.0f - calculate_shadow(sp.shadow_map, sp.shadow_size, cur.q1);
-        if (!(sp.debug & 1)) {
-        Taps t0, t1, t2;
+        const float u = cur.a.x, v = cur.a.y;
+        if (!(sp.debug & 2)) lit = 1.0f - calculate_shadow(sp.shadow_map, sp.shadow_size, make_float4(cur.a.z, cur.a.w, cur.b0, cur.b1));
         const TexRef d0 = lds_desc(ldesc + mat * 3);
         if (__ballot(d0.stride != 3u) == 0ull) fetch_taps3(d0, u, v, t0, t1, t2);   // the usual case: whole wave on interleaved materials
         else { t0 = fetch_taps(d0, u, v); t1 = fetch_taps(lds_desc(ldesc + mat * 3 + 1), u, v); t2 = fetch_taps(lds_desc(ldesc + mat * 3 + 2), u, v); }
-        base = mk(filt_srgb(t0, 0, lut), filt_srgb(t0, 1, lut), filt_srgb(t0, 2, lut));
-        float r = filt_unorm(t1, 0), g = 1.0f - filt_unorm(t1, 1), b = filt_unorm(t1, 2);   // normal.g = 1 - normal.g
-        r = r * 2.0f - 1.0f; g = g * 2.0f - 1.0f; b = b * 2.0f - 1.0f;
-        // mul(tbn, v), tbn columns t, b, n
-        const f3 T = mk(cur.q2.z, cur.q2.w, cur.q3.x), B = mk(cur.q3.y, cur.q3.z, cur.q3.w), N = mk(cur.nx, cur.ny, cur.nz);
-        n = normalize(T * r + B * g + N * b);
-        rough = filt_unorm(t2, 1);   // .g
-        metal = filt_unorm(t2, 2);   // .b
-        } else { base = mk(u, v, cur.q3.x + cur.nx); n = mk(cur.q3.y, cur.q3.z, cur.q3.w); }
     }
-    // exact culling 1: Lo of ps_main is a sum of terms each multiplied by (1 - shadow), so a fully shadowed pixel is
-    // ambient * base and needs neither the sun nor any point light.  Everything else goes to the lit-pixel stream.
+    // exact culling 1: Lo of ps_main is a sum of terms each multiplied by (1 - shadow) (point lights too: forward.hlsl:222,
+    // 230), so a fully shadowed pixel is ambient * base and needs neither the sun, nor any point light, nor its normal,
+    // tangent frame, position, metalness or roughness.  Everything else goes to the lit-pixel stream.
     const bool live = covered && (sp.culling ? lit != 0.0f : true);
+    const unsigned long long m = __ballot(live);
+    float4 gc, gd, ge;
+    if (m != 0ull) { gc = sp.g.c[gi]; gd = sp.g.d[gi]; ge = sp.g.e[gi]; }   // second wave of loads: lit tiles only (48 B / pixel)
+    f3 base = mk(0.0f, 0.0f, 0.0f);
+    if (covered) base = mk(filt_srgb(t0, 0, lut), filt_srgb(t0, 1, lut), filt_srgb(t0, 2, lut));
     if (in_frame && !live) store_pixel(sp, o, base * sp.ambient);   // uncovered: base = 0 -> black (the skybox is out of scope)
     // wave-wide compaction of the live pixels into this workgroup's SHARD of the stream (one atomicAdd per wave, on one
     // of LIT_SHARDS counters each on its own 128-byte line: a single counter would serialise at ~88 atomics/us)
-    const unsigned long long m = __ballot(live);
     if (m != 0ull) {
         const uint32_t shard = (ty * bpr + (tx >> 2)) % LIT_SHARDS;   // by screen position: lit regions spread over all shards
         uint32_t first = (uint32_t)__ffsll((long long)m) - 1, slot0 = 0;
         if (lane == first) slot0 = atomicAdd(sp.lit_count + (sp.band * LIT_SHARDS + shard) * LIT_COUNTER_STRIDE, (uint32_t)__popcll(m));
         slot0 = __shfl(slot0, (int)first);
         if (live) {
+            float r = filt_unorm(t1, 0), g = 1.0f - filt_unorm(t1, 1), b = filt_unorm(t1, 2);   // normal.g = 1 - normal.g
+            r = r * 2.0f - 1.0f; g = g * 2.0f - 1.0f; b = b * 2.0f - 1.0f;
+            // mul(tbn, v), tbn columns t, b, n
+            const f3 T = mk(gc.w, gd.x, gd.y), B = mk(gd.z, gd.w, ge.x), N = mk(ge.y, ge.z, ge.w);
+            const f3 n = normalize(T * r + B * g + N * b);
+            const float rough = filt_unorm(t2, 1), metal = filt_unorm(t2, 2);   // .g, .b (forward.hlsl:117,123)
             const size_t slot = (size_t)(sp.band * LIT_SHARDS + shard) * sp.lit_shard_cap + slot0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            sp.lit_r0[slot] = make_float4(cur.q0.x, cur.q0.y, cur.q0.z, lit);
+            sp.lit_r0[slot] = make_float4(gc.x, gc.y, gc.z, lit);
             sp.lit_r1[slot] = make_float4(n.x, n.y, n.z, rough);
             sp.lit_r2[slot] = make_float4(base.x, base.y, base.z, metal);
             sp.lit_px[slot] = (uint32_t)o;
