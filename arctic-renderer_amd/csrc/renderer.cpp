@@ -46,7 +46,8 @@ struct Mesh {
 
 struct ArcticRenderer {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;       // the stream every pass is enqueued on (own_stream unless the caller set one)
+    hipStream_t own_stream = nullptr;
     uint32_t width = 0, height = 0, shadow_size = 0, max_lights = 0, row_begin = 0, row_end = 0;
     uint32_t tiles_x = 0, tiles_y = 0, tile_y0 = 0, row0_in_tile = 0;
     std::vector<Mesh> meshes;
@@ -348,7 +349,8 @@ ArcticRenderer *arctic_create(const ArcticCreateInfo *info, char *err, uint64_t 
     };
     hipError_t e;
     if ((e = hipSetDevice(r->device)) != hipSuccess) return bail("hipSetDevice", e);
-    if ((e = hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    if ((e = hipStreamCreateWithFlags(&r->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    r->stream = r->own_stream;
     {
         hipDeviceProp_t prop;
         if ((e = hipGetDeviceProperties(&prop, r->device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
@@ -382,7 +384,8 @@ void arctic_destroy(ArcticRenderer *r) {
     if (r->launch.aux) { (void)hipStreamSynchronize(r->launch.aux); (void)hipStreamDestroy(r->launch.aux); }
     for (uint32_t k = 0; k < MAX_BANDS; ++k) if (r->launch.band_done[k]) (void)hipEventDestroy(r->launch.band_done[k]);
     if (r->launch.aux_done) (void)hipEventDestroy(r->launch.aux_done);
-    if (r->stream) { (void)hipStreamSynchronize(r->stream); (void)hipStreamDestroy(r->stream); }
+    if (r->stream) (void)hipStreamSynchronize(r->stream);
+    if (r->own_stream) { (void)hipStreamSynchronize(r->own_stream); (void)hipStreamDestroy(r->own_stream); }
     for (Mesh &m : r->meshes) { if (m.d_vertices) (void)hipFree(m.d_vertices); if (m.d_indices) (void)hipFree(m.d_indices); }
     for (void *p : r->tex_allocs) (void)hipFree(p);
     DevBuf *bufs[] = {&r->d_tex, &r->d_lut, &r->d_lights, &r->d_shadow, &r->d_vis, &r->d_p0, &r->d_p1, &r->d_p2, &r->d_p3, &r->d_p4,
@@ -410,6 +413,16 @@ int arctic_flush(ArcticRenderer *r) {
     int rc = select_device(r);
     if (rc) return rc;
     HIPCHECK(r, hipStreamSynchronize(r->stream));
+    return ARCTIC_OK;
+}
+
+int arctic_set_stream(ArcticRenderer *r, void *hip_stream) {
+    if (!r) return ARCTIC_E_INVALID;
+    int rc = select_device(r);
+    if (rc) return rc;
+    HIPCHECK(r, hipStreamSynchronize(r->stream));
+    r->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : r->own_stream;
+    r->launch.main = r->stream;
     return ARCTIC_OK;
 }
 

@@ -215,7 +215,6 @@ struct Pix {
     f3 n, wo, world;
     f3 F0, omF0;          // F0 = lerp(0.04, base, metal), 1 - F0                              (:181-182, :128)
     f3 kdb;               // (1 - metal) * base / PI: kD * base / PI = kdb - F * kdb            (:187-192)
-    float ndwo_s;         // n . wo, signed
     float a2, oma2;       // roughness^4, 1 - roughness^4                                        (:133-139)
     float k, omk;         // k = (roughness + 1)^2 / 8, 1 - k                                    (:147-148)
     float num;            // a2 * g(n.wo) / PI: the light-independent factor of NDF * G          (:131-163)
@@ -229,8 +228,7 @@ __device__ __forceinline__ Pix make_pix(f3 n, f3 wo, f3 world, f3 base, float me
     p.omF0 = mk(1.0f - p.F0.x, 1.0f - p.F0.y, 1.0f - p.F0.z);
     const float km = (1.0f - metal) * INV_PI;
     p.kdb = mk(base.x * km, base.y * km, base.z * km);
-    p.ndwo_s = dot(n, wo);
-    const float ndwo = fmaxf(p.ndwo_s, 0.0f);
+    const float ndwo = fmaxf(dot(n, wo), 0.0f);
     const float a = rough * rough, a2 = a * a;
     p.a2 = a2; p.oma2 = 1.0f - a2;
     const float r1 = rough + 1.0f;
@@ -251,8 +249,7 @@ __device__ __forceinline__ void accumulate_light(const Pix &p, f3 d, float nd, f
         inv = rsq(dot(d, d));
         sc = inv * inv;
     }
-    const float ndwi_s = nd * inv;                     // n . wi
-    const float ndwi = fmaxf(ndwi_s, 0.0f);
+    const float ndwi = fmaxf(nd * inv, 0.0f);          // max(n . wi, 0)
     // h = wo + wi formed component-wise like the HLSL (when wi is nearly opposite to wo the sum cancels; the same
     // cancellation keeps the result within rounding distance of the reference arithmetic), left unnormalised
     const f3 h = mk(__builtin_fmaf(d.x, inv, p.wo.x), __builtin_fmaf(d.y, inv, p.wo.y), __builtin_fmaf(d.z, inv, p.wo.z));
@@ -261,11 +258,12 @@ __device__ __forceinline__ void accumulate_light(const Pix &p, f3 d, float nd, f
     const float m = sat(__builtin_fmaf(hh * rh, -0.5f, 1.0f));
     const float m2 = m * m, p5 = m2 * m2 * m;
     // distribution_ggx's denominator n_dot_h^2 * (a2 - 1) + 1 (:137) cancels to ~a2 at a highlight; written as
-    // sin^2 * (1 - a2) + a2 with sin^2 = |n x h|^2 / |h|^2 it has no cancellation (same value in exact arithmetic)
-    const f3 cr = mk(__builtin_fmaf(p.n.y, h.z, -(p.n.z * h.y)), __builtin_fmaf(p.n.z, h.x, -(p.n.x * h.z)), __builtin_fmaf(p.n.x, h.y, -(p.n.y * h.x)));
-    const float sin2 = dot(cr, cr) * (rh * rh);
-    const float nh = p.ndwo_s + ndwi_s;                // n . h (only its sign is used)
-    const float dd = nh > 0.0f ? __builtin_fmaf(sin2, p.oma2, p.a2) : 1.0f;   // n . h <= 0: max(n.h, 0) = 0, denominator 1
+    // sin^2 * (1 - a2) + a2 it has no cancellation (same value in exact arithmetic).  sin^2 from e = n - h/|h|:
+    // |e|^2 = 2 - 2 cos, sin^2 = |e|^2 (1 - |e|^2 / 4), and n.h > 0 <=> |e|^2 < 2
+    const f3 e = mk(__builtin_fmaf(h.x, -rh, p.n.x), __builtin_fmaf(h.y, -rh, p.n.y), __builtin_fmaf(h.z, -rh, p.n.z));   // n - h/|h|
+    const float e2 = dot(e, e);
+    const float sin2 = e2 * __builtin_fmaf(e2, -0.25f, 1.0f);
+    const float dd = e2 < 2.0f ? __builtin_fmaf(sin2, p.oma2, p.a2) : 1.0f;   // n . h <= 0: max(n.h, 0) = 0, denominator 1
     const float den = (dd * dd) * __builtin_fmaf(ndwi, p.omk, p.k) * __builtin_fmaf(ndwi, p.four_ndwo, 0.0001f);
     const float spec = (p.num * ndwi) * rcp(den);      // NDF * G / (4 n.wo n.wi + 1e-4)
     sc *= ndwi;
@@ -286,18 +284,19 @@ __device__ __forceinline__ v2 rcp2(v2 a) { v2 r = {rcp(a.x), rcp(a.y)}; return r
 // accumulate_light<true> for two point lights: lane-wise identical arithmetic, each v2 holds {light a, light b}
 __device__ __forceinline__ void accumulate_pair(const Pix &p, v2 dx, v2 dy, v2 dz, v2 nd, v2 cr, v2 cg, v2 cb, v2 &ar, v2 &ag, v2 &ab) {
     const v2 inv = rsq2(fma2(dz, dz, fma2(dy, dy, dx * dx)));
-    const v2 ndwi_s = nd * inv;
-    const v2 ndwi = max02(ndwi_s);
+    const v2 ndwi = max02(nd * inv);
     const v2 hx = fma2(dx, inv, splat(p.wo.x)), hy = fma2(dy, inv, splat(p.wo.y)), hz = fma2(dz, inv, splat(p.wo.z));
     const v2 hh = fma2(hz, hz, fma2(hy, hy, hx * hx)), rh = rsq2(hh);
     const v2 m = sat2(fma2(hh * rh, splat(-0.5f), splat(1.0f)));
     const v2 m2 = m * m, p5 = m2 * m2 * m;
-    const v2 cx = fma2(splat(p.n.y), hz, -(splat(p.n.z) * hy)), cy = fma2(splat(p.n.z), hx, -(splat(p.n.x) * hz)),
-             cz = fma2(splat(p.n.x), hy, -(splat(p.n.y) * hx));
-    const v2 sin2 = fma2(cz, cz, fma2(cy, cy, cx * cx)) * (rh * rh);
-    const v2 nh = splat(p.ndwo_s) + ndwi_s;
+    // sin^2 of the angle between the unit vectors n and h/|h| from their difference e: |e|^2 = 2 - 2 cos, so
+    // sin^2 = |e|^2 (1 - |e|^2 / 4) and n.h > 0 <=> |e|^2 < 2.  No cancellation near the highlight (e is small there
+    // and carries full relative precision), unlike 1 - (n.h)^2.
+    const v2 ex = fma2(hx, -rh, splat(p.n.x)), ey = fma2(hy, -rh, splat(p.n.y)), ez = fma2(hz, -rh, splat(p.n.z));
+    const v2 e2 = fma2(ez, ez, fma2(ey, ey, ex * ex));
+    const v2 sin2 = e2 * fma2(e2, splat(-0.25f), splat(1.0f));
     v2 dd = fma2(sin2, splat(p.oma2), splat(p.a2));
-    dd.x = nh.x > 0.0f ? dd.x : 1.0f; dd.y = nh.y > 0.0f ? dd.y : 1.0f;
+    dd.x = e2.x < 2.0f ? dd.x : 1.0f; dd.y = e2.y < 2.0f ? dd.y : 1.0f;   // n . h <= 0: max(n.h, 0) = 0, denominator 1
     const v2 den = (dd * dd) * fma2(ndwi, splat(p.omk), splat(p.k)) * fma2(ndwi, splat(p.four_ndwo), splat(0.0001f));
     const v2 spec = (splat(p.num) * ndwi) * rcp2(den);
     const v2 sc = inv * inv * ndwi;

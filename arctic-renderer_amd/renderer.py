@@ -75,6 +75,10 @@ class Renderer:
     def flush(self):
         self._check(self.L.arctic_flush(self.h))
 
+    def set_stream(self, hip_stream):
+        """enqueue everything on a caller-owned HIP stream (int handle, e.g. torch.cuda.current_stream().cuda_stream); 0/None = own stream."""
+        self._check(self.L.arctic_set_stream(self.h, C.c_void_p(hip_stream) if hip_stream else None))
+
     def create_material(self, diffuse, normal, metal_rough):
         """three (h, w, 4) uint8 images; returns the material index."""
         d, n, m = (np.ascontiguousarray(t, dtype=np.uint8) for t in (diffuse, normal, metal_rough))

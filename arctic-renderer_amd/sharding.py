@@ -22,21 +22,35 @@ def row_range(height, rank, world):
     return begin, begin + base + (1 if rank < extra else 0)
 
 
-def gather_rows(shard, gathered, rank, world, root=0, group=None):
-    """gather the (rows_r, width, 4) uint8 shards on `root`; `gathered` is the root's list of per-rank
-    buffers (None elsewhere).  Shards may differ by one row, so this is send/recv into the root
-    rather than an equal-count ncclGather; when all counts are equal dist.gather is used."""
+class _Works:
+    """several point-to-point requests waited on as one."""
+
+    def __init__(self, reqs):
+        self.reqs = reqs
+
+    def wait(self):
+        for q in self.reqs:
+            q.wait()
+
+
+def gather_rows(shard, gathered, rank, world, root=0, group=None, async_op=False):
+    """gather the (rows_r, width, 4) uint8 shards on `root`; `gathered` is the root's list of per-rank buffers (None
+    elsewhere).  Equal shards: one dist.gather (ncclGather); shards differing by a row: send/recv into the root.
+    async_op=True returns an object with .wait() (None when there is nothing to wait for)."""
     if world == 1:
-        return shard
+        return None if async_op else shard
     if _all_equal_rows(shard, world, group):   # decided collectively: every rank must take the same branch
-        dist.gather(shard, gather_list=gathered if rank == root else None, dst=root, group=group)
-    elif rank == root:
+        w = dist.gather(shard, gather_list=gathered if rank == root else None, dst=root, group=group, async_op=async_op)
+        return w if async_op else gathered
+    if rank == root:
         gathered[root].copy_(shard)
         reqs = [dist.irecv(gathered[k], src=k, group=group) for k in range(world) if k != root]
-        for q in reqs:
-            q.wait()
     else:
-        dist.send(shard, dst=root, group=group)
+        reqs = [dist.isend(shard, dst=root, group=group)]
+    works = _Works(reqs)
+    if async_op:
+        return works
+    works.wait()
     return gathered
 
 

@@ -84,18 +84,38 @@ def main():
             f"{len(sc.lights)} point lights, shadow {sc.shadow_size}^2; setup {time.time() - t0:.1f}s")
 
     rows = row_end - row_begin
-    out = torch.empty((rows, sc.width, 4), dtype=torch.uint8, device="cuda")
-    gathered = [torch.empty((sharding.row_range(sc.height, k, world)[1] - sharding.row_range(sc.height, k, world)[0], sc.width, 4),
-                            dtype=torch.uint8, device="cuda") for k in range(world)] if (world > 1 and rank == 0) else None
+    # N > 1: the library runs on torch's stream, so the RCCL gather is stream-ordered after the shading pass with no
+    # host synchronisation; two output buffers let the gather of frame k overlap the shading of frame k + 1
+    # (each buffer is reused only after its own gather has completed).
+    n_buf = 2 if world > 1 else 1
+    outs = [torch.empty((rows, sc.width, 4), dtype=torch.uint8, device="cuda") for _ in range(n_buf)]
+    shard_rows = [sharding.row_range(sc.height, k, world)[1] - sharding.row_range(sc.height, k, world)[0] for k in range(world)]
+    gathered = [[torch.empty((n, sc.width, 4), dtype=torch.uint8, device="cuda") for n in shard_rows] for _ in range(n_buf)] \
+        if (world > 1 and rank == 0) else [None] * n_buf
+    pending = [None] * n_buf
+    if world > 1:
+        r.set_stream(torch.cuda.current_stream().cuda_stream)
+    state = {"k": 0}
 
     def step():
-        r.pass_shade(sc.desc, sc.settings, out.data_ptr())
+        b = state["k"] % n_buf
+        state["k"] += 1
+        if pending[b] is not None:
+            pending[b].wait()
+            pending[b] = None
+        r.pass_shade(sc.desc, sc.settings, outs[b].data_ptr())
         if world > 1:
-            r.flush()                                   # the gather runs on torch's stream
-            sharding.gather_rows(out, gathered, rank, world)
+            pending[b] = sharding.gather_rows(outs[b], gathered[b], rank, world, async_op=True)
+
+    def drain():
+        for b in range(n_buf):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
 
     for _ in range(args.warmup):
         step()
+    drain()
     r.flush()
     torch.cuda.synchronize()
     if world > 1:
@@ -103,6 +123,7 @@ def main():
     t_start = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()
     r.flush()
     torch.cuda.synchronize()
     if world > 1:
@@ -113,6 +134,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    if world > 1:
+        r.set_stream(None)
     # shaded pixels = pixels with geometry (100 % in this scene); counted, not assumed
     _, mat, _, _ = r.read_gbuffer(want=("material",))
     shaded_local = int((mat != 0xFFFFFFFF).sum())

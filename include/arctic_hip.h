@@ -138,6 +138,11 @@ int arctic_resize(ArcticRenderer *r, uint32_t width, uint32_t height);
 /* replaces bool Renderer::flush() (renderer.hpp:122-125): device idle */
 int arctic_flush(ArcticRenderer *r);
 
+/* run everything on a HIP stream the caller owns (a hipStream_t passed as void*), e.g. the stream a following RCCL
+ * gather is enqueued on, so that no host synchronisation is needed between the frame and the collective.
+ * NULL returns to the handle's own stream.  The previous stream is drained first. */
+int arctic_set_stream(ArcticRenderer *r, void *hip_stream);
+
 /* ---- scene upload -------------------------------------------------------- */
 
 /* replaces bool Renderer::create_material(void*,w,h, void*,w,h, void*,w,h)

@@ -40,7 +40,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, height_trim, out_path):
+def _worker(rank, world, port, height_trim, out_path, use_async=False):
     sys.path.insert(0, ROOT)
     import __graft_entry__ as entry
     from importlib import import_module
@@ -59,17 +59,22 @@ def _worker(rank, world, port, height_trim, out_path):
         shard = torch.from_numpy(o.render_frame(sc.desc, sc.settings, threads=2))
         gathered = [torch.empty((sh.row_range(height, k, world)[1] - sh.row_range(height, k, world)[0], sc.width, 4), dtype=torch.uint8)
                     for k in range(world)] if rank == 0 else None
-        sh.gather_rows(shard, gathered, rank, world)
+        if use_async:
+            w = sh.gather_rows(shard, gathered, rank, world, async_op=True)
+            w.wait()
+        else:
+            sh.gather_rows(shard, gathered, rank, world)
         if rank == 0:
             np.save(out_path, sh.assemble(gathered).numpy())
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,trim", [(2, 0), (2, 3), (3, 1)], ids=["2-equal", "2-ragged", "3-ragged"])
-def test_gloo_gather_reassembles_the_single_process_frame(pkg, oracle, tmp_path, world, trim):
+@pytest.mark.parametrize("world,trim,use_async", [(2, 0, False), (2, 3, False), (3, 1, True), (2, 0, True)],
+                         ids=["2-equal", "2-ragged", "3-ragged-async", "2-equal-async"])
+def test_gloo_gather_reassembles_the_single_process_frame(pkg, oracle, tmp_path, world, trim, use_async):
     out = str(tmp_path / "frame.npy")
-    mp.spawn(_worker, args=(world, _free_port(), trim, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), trim, out, use_async), nprocs=world, join=True)
     got = np.load(out)
     sc = pkg.scenes.config3(scale=0.04, tex=64)
     height = sc.height - trim
