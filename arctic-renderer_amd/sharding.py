@@ -39,6 +39,15 @@ def gather_rows(shard, gathered, rank, world, root=0, group=None, async_op=False
     async_op=True returns an object with .wait() (None when there is nothing to wait for)."""
     if world == 1:
         return None if async_op else shard
+    if shard.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal of the multi-rank path on a box with one GPU (gloo has no device gather): stage through the host
+        torch.cuda.current_stream().synchronize()
+        host = [torch.empty(g.shape, dtype=g.dtype) for g in gathered] if rank == root else None
+        gather_rows(shard.cpu(), host, rank, world, root, group)
+        if rank == root:
+            for g, h in zip(gathered, host):
+                g.copy_(h)
+        return None if async_op else gathered
     if _all_equal_rows(shard, world, group):   # decided collectively: every rank must take the same branch
         w = dist.gather(shard, gather_list=gathered if rank == root else None, dst=root, group=group, async_op=async_op)
         return w if async_op else gathered

@@ -64,10 +64,16 @@ def main():
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product has no CPU path")
+    backend = os.environ.get("ARCTIC_BENCH_BACKEND", "nccl")    # "gloo" + ARCTIC_BENCH_SHARE_GPU=1: rehearse N ranks on one GPU
+    if os.environ.get("ARCTIC_BENCH_SHARE_GPU") == "1":
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     pkg = entry.load_package()
     sharding = __import__("arctic_renderer_amd.sharding", fromlist=["x"])
@@ -130,7 +136,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t_start
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -140,7 +146,7 @@ def main():
     _, mat, _, _ = r.read_gbuffer(want=("material",))
     shaded_local = int((mat != 0xFFFFFFFF).sum())
     if world > 1:
-        t = torch.tensor([shaded_local], dtype=torch.int64, device="cuda")
+        t = torch.tensor([shaded_local], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t)
         shaded = int(t.item())
     else:
