@@ -79,7 +79,14 @@ struct GeomParams {
     int32_t tiles_x;             // tile columns of the target
     int32_t tile_y0;             // first tile row stored (row shard); 0 for the shadow map
     int32_t pitch;               // shadow pass: row pitch of the row-major depth map (= S)
+    int32_t band_tiles;          // interleaved shard: tile rows per band (0 = contiguous shard), else see row_* below
+    int32_t shard_index, shard_count;
 };
+// tile-row bookkeeping of a shard.  ty_rel = global tile row - tile_y0.  Contiguous shard: local == ty_rel.  Interleaved
+// shard: bands of band_tiles tile rows are dealt round-robin, shard r owns bands r, r + n, ...; local rows are packed.
+__host__ __device__ inline bool row_owned(int ty_rel, int band_tiles, int n, int r) { return band_tiles == 0 || ((ty_rel / band_tiles) % n) == r; }
+__host__ __device__ inline int row_local(int ty_rel, int band_tiles, int n) { return band_tiles == 0 ? ty_rel : ((ty_rel / band_tiles) / n) * band_tiles + ty_rel % band_tiles; }
+__host__ __device__ inline int row_global(int lt, int band_tiles, int n, int r) { return band_tiles == 0 ? lt : ((lt / band_tiles) * n + r) * band_tiles + lt % band_tiles; }
 
 // texture descriptor, 16 B; three consecutive per material: diffuse (sRGB), normal, metal-rough
 // When a material's three images have equal size they are stored INTERLEAVED, texel by texel {diffuse, normal,

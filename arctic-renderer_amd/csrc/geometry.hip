@@ -325,7 +325,9 @@ __global__ __launch_bounds__(256) void k_raster(const SetupRec *__restrict__ rec
         uint32_t zb = __float_as_uint(z);
         if (zb < *p) atomicMin(p, zb);
     } else {
-        size_t idx = ((size_t)(ty - gpp->tile_y0) * gpp->tiles_x + tx) * 64 + lane;
+        const int ty_rel = ty - gpp->tile_y0;
+        if (!row_owned(ty_rel, gpp->band_tiles, gpp->shard_count, gpp->shard_index)) return;   // another shard's band
+        size_t idx = ((size_t)row_local(ty_rel, gpp->band_tiles, gpp->shard_count) * gpp->tiles_x + tx) * 64 + lane;
         unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | r;   // ties: first drawn (smallest id) wins
         if (key < vis[idx]) atomicMin(&vis[idx], key);
     }
@@ -351,7 +353,8 @@ __global__ __launch_bounds__(256) void k_resolve(const unsigned long long *__res
     if (key != ~0ull) {
         const SetupRec &t = recs[(uint32_t)key];
         depth = __uint_as_float((uint32_t)(key >> 32));
-        int32_t tx = (int32_t)(tile % (uint32_t)gpp->tiles_x), ty = (int32_t)(tile / (uint32_t)gpp->tiles_x) + gpp->tile_y0;
+        int32_t tx = (int32_t)(tile % (uint32_t)gpp->tiles_x);
+        int32_t ty = row_global((int)(tile / (uint32_t)gpp->tiles_x), gpp->band_tiles, gpp->shard_count, gpp->shard_index) + gpp->tile_y0;
         int32_t px = tx * 8 + (int32_t)(lane & 7), py = ty * 8 + (int32_t)(lane >> 3);
         Edges e;
         make_edges(t, e);

@@ -50,6 +50,7 @@ struct ArcticRenderer {
     hipStream_t own_stream = nullptr;
     uint32_t width = 0, height = 0, shadow_size = 0, max_lights = 0, row_begin = 0, row_end = 0;
     uint32_t tiles_x = 0, tiles_y = 0, tile_y0 = 0, row0_in_tile = 0;
+    uint32_t band_rows = 0, shard_index = 0, shard_count = 1, owned_rows = 0;   // interleaved shard (band_rows > 0)
     std::vector<Mesh> meshes;
     std::vector<TexDesc> tex;        // 3 per material (device pointers)
     std::vector<void *> tex_allocs;
@@ -76,7 +77,7 @@ struct ArcticRenderer {
         err = buf;
         return code;
     }
-    uint32_t rows() const { return row_end - row_begin; }
+    uint32_t rows() const { return band_rows ? owned_rows : row_end - row_begin; }
     // records per shard of the lit-pixel stream: workgroup (ty, col) goes to shard (ty * bpr + col) % LIT_SHARDS
     uint32_t lit_shard_cap() const {
         uint32_t bpr = (tiles_x + 3) / 4, row_groups = (tiles_y + 7) / 8, nb = std::max(1u, std::min(launch.n_bands, row_groups));
@@ -105,6 +106,13 @@ int alloc_targets(ArcticRenderer *r) {
     r->row0_in_tile = r->row_begin - r->tile_y0 * TILE;
     r->tiles_x = (r->width + TILE - 1) / TILE;
     r->tiles_y = (r->row_end + TILE - 1) / TILE - r->tile_y0;
+    if (r->band_rows) {   // interleaved shard: count the tile rows and pixel rows this shard owns
+        const int bt = (int)(r->band_rows / TILE), all = (int)((r->height + TILE - 1) / TILE);
+        uint32_t own_t = 0, own_r = 0;
+        for (int ty = 0; ty < all; ++ty)
+            if (row_owned(ty, bt, (int)r->shard_count, (int)r->shard_index)) { ++own_t; own_r += std::min<uint32_t>(TILE, r->height - (uint32_t)ty * TILE); }
+        r->tiles_y = own_t; r->owned_rows = own_r;
+    }
     size_t px = r->n_tiles() * TILE_PIXELS, out_px = (size_t)r->rows() * r->width;
     HIPCHECK(r, r->d_vis.ensure(px * 8));
     HIPCHECK(r, r->d_p0.ensure(px * 16));
@@ -194,6 +202,7 @@ int run_geometry(ArcticRenderer *r, const ArcticScene *sc, bool shadow_pass, uin
         gp.sc_x0 = 0; gp.sc_x1 = (int32_t)r->width; gp.sc_y0 = (int32_t)r->row_begin; gp.sc_y1 = (int32_t)r->row_end;
         gp.cull_front = 0;                                       // forward_pass.cpp:143-144
         gp.tiles_x = (int32_t)r->tiles_x; gp.tile_y0 = (int32_t)r->tile_y0; gp.pitch = 0;
+        gp.band_tiles = (int32_t)(r->band_rows / TILE); gp.shard_index = (int32_t)r->shard_index; gp.shard_count = (int32_t)r->shard_count;
     }
     HIPCHECK(r, r->d_gp.ensure(sizeof gp));
     HIPCHECK(r, hipMemcpyAsync(r->d_gp.p, &gp, sizeof gp, hipMemcpyHostToDevice, r->stream));
@@ -333,6 +342,13 @@ ArcticRenderer *arctic_create(const ArcticCreateInfo *info, char *err, uint64_t 
     uint32_t rb = info->row_begin, re = info->row_end;
     if (rb == 0 && re == 0) re = info->height;
     if (re > info->height || rb >= re) { say("arctic_create: bad row shard"); return nullptr; }
+    if (info->band_rows) {
+        if (info->band_rows % TILE != 0 || info->shard_count == 0 || info->shard_index >= info->shard_count || info->row_begin || info->row_end) {
+            say("arctic_create: bad interleaved shard (band_rows must be a multiple of 8, shard_index < shard_count, row_begin = row_end = 0)");
+            return nullptr;
+        }
+        if ((uint64_t)info->shard_index * info->band_rows >= info->height) { say("arctic_create: interleaved shard owns no rows"); return nullptr; }
+    }
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) { say("arctic_create: no HIP device (this library has no CPU path)"); return nullptr; }
     if (info->device < 0 || info->device >= n_dev) { say("arctic_create: device ordinal out of range"); return nullptr; }
@@ -340,6 +356,7 @@ ArcticRenderer *arctic_create(const ArcticCreateInfo *info, char *err, uint64_t 
     r->device = info->device;
     r->width = info->width; r->height = info->height; r->shadow_size = info->shadow_size; r->max_lights = info->max_lights;
     r->row_begin = rb; r->row_end = re;
+    r->band_rows = info->band_rows; r->shard_index = info->shard_index; r->shard_count = info->band_rows ? info->shard_count : 1;
     auto bail = [&](const char *what, hipError_t e) {
         char buf[256];
         std::snprintf(buf, sizeof buf, "arctic_create: %s: %s", what, hipGetErrorString(e));
@@ -405,6 +422,7 @@ int arctic_resize(ArcticRenderer *r, uint32_t width, uint32_t height) {
     if (rc) return rc;
     HIPCHECK(r, hipStreamSynchronize(r->stream));
     r->width = width; r->height = height; r->row_begin = 0; r->row_end = height;
+    r->band_rows = 0; r->shard_index = 0; r->shard_count = 1;
     return alloc_targets(r);
 }
 

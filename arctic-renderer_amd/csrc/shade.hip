@@ -447,13 +447,13 @@ __global__ __launch_bounds__(256) void k_material(const ShadeParams sp) {
 
 // ---- kernel 2: the sun + point lights over the lit-pixel stream, tonemap, store ----------------------------------
 // LDS (dynamic): the point lights as PAIRS, 12 floats per pair {x0,x1, y0,y1, z0,z1, r0,r1, g0,g1, b0,b1}; every lane reads
-// the same address, so a pair costs three broadcast ds_read_b128.  An odd count is padded with a black light.
+// the same address, so a pair costs three broadcast ds_read_b128.  The count is padded to a multiple of 4 with black lights.
 // Persistent: gridDim.x workgroups; wave w works on shard w % LIT_SHARDS of the stream and takes every
 // (n_waves / LIT_SHARDS)-th 64-pixel group of it.
 __global__ __launch_bounds__(256) void k_light(const ShadeParams sp) {
     extern __shared__ __align__(16) float smem[];
     float4 *llights = reinterpret_cast<float4 *>(smem);
-    const uint32_t n_pairs = (sp.n_lights + 1) >> 1;
+    const uint32_t n_quads = (sp.n_lights + 3) >> 2, n_pairs = 2 * n_quads;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (uint32_t i = threadIdx.x; i < 2 * n_pairs; i += 256) {
@@ -482,22 +482,29 @@ __global__ __launch_bounds__(256) void k_light(const ShadeParams sp) {
             const f3 d = mk(-sp.sun_dir[0], -sp.sun_dir[1], -sp.sun_dir[2]);
             accumulate_light<false>(px, d, dot(n, d), mk(sp.sun_color[0], sp.sun_color[1], sp.sun_color[2]), sun);
         }
-        v2 ar = {sun.x, 0.0f}, ag = {sun.y, 0.0f}, ab = {sun.z, 0.0f};
+        v2 ar = {sun.x, 0.0f}, ag = {sun.y, 0.0f}, ab = {sun.z, 0.0f}, ar2 = {0.0f, 0.0f}, ag2 = ar2, ab2 = ar2;
         const v2 wx = splat(world.x), wy = splat(world.y), wz = splat(world.z);
-        for (uint32_t p = 0; p < n_pairs; ++p) {
-            const float4 A = llights[3 * p], Bq = llights[3 * p + 1], C = llights[3 * p + 2];
-            const v2 dx = (v2){A.x, A.y} - wx, dy = (v2){A.z, A.w} - wy, dz = (v2){Bq.x, Bq.y} - wz;
-            const v2 nd = fma2(splat(n.z), dz, fma2(splat(n.y), dy, splat(n.x) * dx));
-            // exact culling 2: n.wi <= 0 zeroes a light (forward.hlsl:191-192); skip the pair when that holds for both
+        // two pairs (four lights) per trip: the two evaluations are independent, which gives the scheduler instructions to
+        // put between dependent packed operations (n_quads = ceil(n_pairs / 2); the LDS image is padded with black lights)
+        for (uint32_t q = 0; q < n_quads; ++q) {
+            const float4 A0 = llights[6 * q], B0 = llights[6 * q + 1], C0 = llights[6 * q + 2];
+            const float4 A1 = llights[6 * q + 3], B1 = llights[6 * q + 4], C1 = llights[6 * q + 5];
+            const v2 dx0 = (v2){A0.x, A0.y} - wx, dy0 = (v2){A0.z, A0.w} - wy, dz0 = (v2){B0.x, B0.y} - wz;
+            const v2 dx1 = (v2){A1.x, A1.y} - wx, dy1 = (v2){A1.z, A1.w} - wy, dz1 = (v2){B1.x, B1.y} - wz;
+            const v2 nd0 = fma2(splat(n.z), dz0, fma2(splat(n.y), dy0, splat(n.x) * dx0));
+            const v2 nd1 = fma2(splat(n.z), dz1, fma2(splat(n.y), dy1, splat(n.x) * dx1));
+            // exact culling 2: n.wi <= 0 zeroes a light (forward.hlsl:191-192); skip the trip when that holds for all four
             // lights in every lane of the wave
-            if (sp.culling && __ballot(nd.x > 0.0f || nd.y > 0.0f) == 0ull) continue;
-            accumulate_pair(px, dx, dy, dz, nd, (v2){Bq.z, Bq.w}, (v2){C.x, C.y}, (v2){C.z, C.w}, ar, ag, ab);
+            if (sp.culling && __ballot(nd0.x > 0.0f || nd0.y > 0.0f || nd1.x > 0.0f || nd1.y > 0.0f) == 0ull) continue;
+            accumulate_pair(px, dx0, dy0, dz0, nd0, (v2){B0.z, B0.w}, (v2){C0.x, C0.y}, (v2){C0.z, C0.w}, ar, ag, ab);
+            accumulate_pair(px, dx1, dy1, dz1, nd1, (v2){B1.z, B1.w}, (v2){C1.x, C1.y}, (v2){C1.z, C1.w}, ar2, ag2, ab2);
             if (sp.light_evals) {
                 const unsigned long long active = __ballot(1);
-                const uint32_t k = (2 * p + 1 < sp.n_lights) ? 2u : 1u;
+                const uint32_t k = min(4u, sp.n_lights - 4 * q);
                 if (lane == (uint32_t)__ffsll((long long)active) - 1) atomicAdd(sp.light_evals, (unsigned long long)__popcll(active) * k);
             }
         }
+        ar += ar2; ag += ag2; ab += ab2;
         store_pixel(sp, o, mk(ar.x + ar.y, ag.x + ag.y, ab.x + ab.y) * r0.w + base * sp.ambient);   // r0.w = 1 - shadow
     }
 }
@@ -530,7 +537,7 @@ hipError_t launch_shade(const ShadeParams &sp0, const ShadeLaunch &L) {
     hipError_t e = hipMemsetAsync(sp.lit_count, 0, (size_t)n_bands * LIT_SHARDS * LIT_COUNTER_STRIDE * sizeof(uint32_t), L.main);
     if (e != hipSuccess) return e;
     const size_t lds_a = (256 + (size_t)sp.n_materials * 12) * sizeof(float);
-    const size_t lds_b = std::max<size_t>(48, (size_t)((sp.n_lights + 1) / 2) * 48);
+    const size_t lds_b = std::max<size_t>(96, (size_t)((sp.n_lights + 3) / 4) * 96);
     for (uint32_t k = 0; k < n_bands; ++k) {
         sp.band = k;
         const uint32_t groups = (row_groups - k + n_bands - 1) / n_bands;

@@ -26,21 +26,26 @@ def _ptr(a):
 
 
 class Renderer:
-    def __init__(self, width, height, shadow_size=4000, max_lights=16, device=0, row_begin=0, row_end=0):
+    def __init__(self, width, height, shadow_size=4000, max_lights=16, device=0, row_begin=0, row_end=0, band_rows=0,
+                 shard=(0, 1)):
         """Renderer(window, w, h) + init() (renderer.hpp:94-100); no window.  shadow_size defaults to
         ShadowMapPass::SIZE (shadow_map_pass.hpp:23), max_lights to MAX_NUM_POINT_LIGHTS (renderer.hpp:22)."""
         self.L = binding.lib()
-        info = CCreateInfo(width, height, shadow_size, max_lights, device, row_begin, row_end)
+        info = CCreateInfo(width, height, shadow_size, max_lights, device, row_begin, row_end, band_rows, shard[0], shard[1])
         err = C.create_string_buffer(512)
         self.h = self.L.arctic_create(C.byref(info), err, 512)
         if not self.h:
             raise ArcticError(-3 if b"no HIP device" in err.value else -2, err.value.decode())
         self.width, self.height, self.shadow_size, self.max_lights, self.device = width, height, shadow_size, max_lights, device
         self.row_begin, self.row_end = (row_begin, row_end) if row_end else (0, height)
+        self.band_rows, self.shard = band_rows, shard
 
     # ---- helpers -------------------------------------------------------------------------------
     @property
     def rows(self):
+        if self.band_rows:
+            from .sharding import owned_rows
+            return len(owned_rows(self.height, self.shard[0], self.shard[1], self.band_rows))
         return self.row_end - self.row_begin
 
     def _check(self, rc):
@@ -71,6 +76,7 @@ class Renderer:
     def resize(self, width, height):
         self._check(self.L.arctic_resize(self.h, width, height))
         self.width, self.height, self.row_begin, self.row_end = width, height, 0, height
+        self.band_rows, self.shard = 0, (0, 1)
 
     def flush(self):
         self._check(self.L.arctic_flush(self.h))
@@ -122,6 +128,16 @@ class Renderer:
     def pass_gbuffer(self, desc):
         s = self._scene(desc)
         self._check(self.L.arctic_pass_gbuffer(self.h, C.byref(s)))
+
+    def prepared_pass_shade(self, desc, settings):
+        """returns shade(d_out_ptr): the same call as pass_shade with the C structs built once (per-frame host cost of a
+        tight loop is then one ctypes call)."""
+        s, st = self._scene(desc), self._settings(settings)
+        fn, h, check, ps, pst = self.L.arctic_pass_shade, self.h, self._check, C.byref(s), C.byref(st)
+
+        def shade(d_out_ptr=None, _keep=(s, st, desc)):
+            check(fn(h, ps, pst, C.c_void_p(d_out_ptr) if d_out_ptr else None))
+        return shade
 
     def pass_shade(self, desc, settings, d_out_ptr=None):
         s, st = self._scene(desc), self._settings(settings)

@@ -43,7 +43,8 @@ class CSettings(C.Structure):
 class CCreateInfo(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("shadow_size", C.c_uint32),
                 ("max_lights", C.c_uint32), ("device", C.c_int32), ("row_begin", C.c_uint32),
-                ("row_end", C.c_uint32)]
+                ("row_end", C.c_uint32), ("band_rows", C.c_uint32), ("shard_index", C.c_uint32),
+                ("shard_count", C.c_uint32)]
 
 
 class SceneDesc:

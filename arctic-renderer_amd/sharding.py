@@ -22,6 +22,27 @@ def row_range(height, rank, world):
     return begin, begin + base + (1 if rank < extra else 0)
 
 
+def owned_rows(height, rank, world, band_rows=16):
+    """row indices of the INTERLEAVED shard of rank `rank`: bands of band_rows rows dealt round-robin (band b -> rank
+    b % world).  Lit (expensive) regions are spatially clustered, so contiguous row ranges would leave some ranks with all
+    the light evaluations; interleaving gives every rank its share."""
+    import numpy as np
+    if band_rows <= 0 or band_rows % 8:
+        raise ValueError("band_rows must be a positive multiple of 8")
+    y = np.arange(height)
+    return y[(y // band_rows) % world == rank]
+
+
+def assemble_banded(gathered, height, band_rows=16):
+    """root only: the full frame from interleaved shards (one indexed copy per rank)."""
+    world = len(gathered)
+    frame = torch.empty((height,) + tuple(gathered[0].shape[1:]), dtype=gathered[0].dtype, device=gathered[0].device)
+    for k, g in enumerate(gathered):
+        idx = torch.as_tensor(owned_rows(height, k, world, band_rows), device=g.device)
+        frame.index_copy_(0, idx, g)
+    return frame
+
+
 class _Works:
     """several point-to-point requests waited on as one."""
 

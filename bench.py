@@ -11,9 +11,10 @@ at 3840x2160, 1 directional + 64 point lights, 4000^2 shadow map, ACES -- synthe
 assets are not available offline), produced once, untimed, by the library's own shadow-map raster
 and G-buffer prepass.
 
-N > 1: the frame is sharded by rows (rank r shades rows [r*H/N, (r+1)*H/N)), every step ends with
-the RCCL gather of the finished RGBA8 shards on rank 0 (the path's one real exchange step), total
-work is fixed -> "scaling": "strong".
+N > 1: the frame is sharded by rows, in interleaved bands of 16 rows dealt round-robin to the ranks
+(lit regions are spatially clustered; contiguous ranges would be unbalanced); every step issues the
+RCCL gather of the finished RGBA8 shards to rank 0 (the path's one real exchange step), which
+overlaps the next step's shading through double buffering; total work is fixed -> "scaling": "strong".
 
 The JSON line also carries
   roofline     achieved = 80 B x shaded pixels / mean time of the pass's two kernels (HIP events on
@@ -79,9 +80,11 @@ def main():
     sharding = __import__("arctic_renderer_amd.sharding", fromlist=["x"])
     t0 = time.time()
     sc = pkg.scenes.CONFIGS[args.config](scale=args.scale)
-    row_begin, row_end = sharding.row_range(sc.height, rank, world)
-    r = sc.upload(pkg.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights, device=local,
-                               row_begin=row_begin, row_end=row_end))
+    BAND = 16   # N > 1: rows are dealt to the ranks in interleaved bands of 16 (lit regions are clustered: load balance)
+    if world > 1:
+        r = sc.upload(pkg.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights, device=local, band_rows=BAND, shard=(rank, world)))
+    else:
+        r = sc.upload(pkg.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights, device=local))
     r.pass_shadow_map(sc.desc)      # untimed: the producers of the hot path's inputs
     r.pass_gbuffer(sc.desc)
     r.flush()
@@ -89,35 +92,45 @@ def main():
         log(f"[bench] {sc.name}: {sc.width}x{sc.height}, {sc.n_triangles} triangles, {len(sc.materials)} materials, "
             f"{len(sc.lights)} point lights, shadow {sc.shadow_size}^2; setup {time.time() - t0:.1f}s")
 
-    rows = row_end - row_begin
+    rows = r.rows
     # N > 1: the library runs on torch's stream, so the RCCL gather is stream-ordered after the shading pass with no
     # host synchronisation; two output buffers let the gather of frame k overlap the shading of frame k + 1
     # (each buffer is reused only after its own gather has completed).
     n_buf = 2 if world > 1 else 1
     outs = [torch.empty((rows, sc.width, 4), dtype=torch.uint8, device="cuda") for _ in range(n_buf)]
-    shard_rows = [sharding.row_range(sc.height, k, world)[1] - sharding.row_range(sc.height, k, world)[0] for k in range(world)]
+    shard_rows = [len(sharding.owned_rows(sc.height, k, world, BAND)) for k in range(world)] if world > 1 else [rows]
     gathered = [[torch.empty((n, sc.width, 4), dtype=torch.uint8, device="cuda") for n in shard_rows] for _ in range(n_buf)] \
         if (world > 1 and rank == 0) else [None] * n_buf
     pending = [None] * n_buf
+    # the root de-interleaves the gathered shards into the final frame (one indexed copy per rank, stream-ordered)
+    frame = torch.empty((sc.height, sc.width, 4), dtype=torch.uint8, device="cuda") if (world > 1 and rank == 0) else None
+    row_idx = [torch.as_tensor(sharding.owned_rows(sc.height, k, world, BAND), device="cuda") for k in range(world)] if frame is not None else None
+    out_ptrs = [o.data_ptr() for o in outs]
     if world > 1:
         r.set_stream(torch.cuda.current_stream().cuda_stream)
     state = {"k": 0}
+    shade = r.prepared_pass_shade(sc.desc, sc.settings)
 
     def step():
         b = state["k"] % n_buf
         state["k"] += 1
         if pending[b] is not None:
-            pending[b].wait()
-            pending[b] = None
-        r.pass_shade(sc.desc, sc.settings, outs[b].data_ptr())
+            finish(b)
+        shade(out_ptrs[b])
         if world > 1:
             pending[b] = sharding.gather_rows(outs[b], gathered[b], rank, world, async_op=True)
+
+    def finish(b):
+        pending[b].wait()
+        pending[b] = None
+        if frame is not None:
+            for k in range(world):
+                frame.index_copy_(0, row_idx[k], gathered[b][k])
 
     def drain():
         for b in range(n_buf):
             if pending[b] is not None:
-                pending[b].wait()
-                pending[b] = None
+                finish(b)
 
     for _ in range(args.warmup):
         step()
@@ -190,7 +203,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[{args.config - 1}]: {sc.name}, {sc.width}x{sc.height}, 1 dir + {len(sc.lights)} point lights, "
                                    f"shadow {sc.shadow_size}^2 PCF 5x5, tonemap {sc.settings[0]}, {len(sc.materials)} materials; shading pass over a resident G-buffer",
-                       "triangles": sc.n_triangles, "shaded_pixels": shaded, "sharding": f"rows/{world}" if world > 1 else "none",
+                       "triangles": sc.n_triangles, "shaded_pixels": shaded, "sharding": f"{BAND}-row bands round-robin over {world} ranks, RCCL gather to rank 0" if world > 1 else "none",
                        "scale": args.scale},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,

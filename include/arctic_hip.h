@@ -113,6 +113,12 @@ typedef struct ArcticCreateInfo {
     int32_t  device;         /* HIP device ordinal */
     uint32_t row_begin;      /* screen-space shard: this handle renders rows [row_begin,row_end) ... */
     uint32_t row_end;        /* ... of the width x height frame; 0,0 = whole frame */
+    /* or an INTERLEAVED shard (load balance: lit regions are spatially clustered): with band_rows > 0 (a multiple of 8;
+     * row_begin = row_end = 0) the handle owns the rows y with (y / band_rows) % shard_count == shard_index, and its
+     * output holds those rows packed in ascending order. */
+    uint32_t band_rows;
+    uint32_t shard_index;
+    uint32_t shard_count;
 } ArcticCreateInfo;
 
 typedef struct ArcticRenderer ArcticRenderer; /* opaque */

@@ -24,7 +24,7 @@ def build_pair(pkg, oracle, hip, sc, **kw):
     return o, r
 
 
-SCENES = [(1, 0.5), (2, 0.25), (3, 0.1), (3, 0.2)]
+SCENES = [(1, 0.5), (2, 0.25), (3, 0.1), (3, 0.2), (4, 0.06), (5, 0.03)]   # configs 4/5: 256 and 1024 point lights
 
 
 @pytest.fixture(scope="module", params=SCENES, ids=[f"config{c}-x{s}" for c, s in SCENES])
@@ -119,6 +119,28 @@ def test_row_shards_equal_full_frame(pkg, oracle, hip):
             r.close()
         np.testing.assert_array_equal(np.concatenate(parts, 0), ref)
     full.close()
+
+
+def test_interleaved_band_shards_equal_full_frame(pkg, hip):
+    """the load-balanced sharding the multi-GPU bench uses: bands of 16 rows dealt round-robin over the ranks."""
+    from importlib import import_module
+    sh = import_module("arctic_renderer_amd.sharding")
+    import torch
+    sc = pkg.scenes.config3(scale=0.1)                      # 384 x 216: the last band is partial (216 = 13.5 x 16)
+    full = sc.upload(hip.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights))
+    ref = full.render_frame(sc.desc, sc.settings)
+    full.close()
+    for world, band in ((3, 16), (8, 16), (2, 8)):
+        parts = []
+        for rank in range(world):
+            r = sc.upload(hip.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights, band_rows=band, shard=(rank, world)))
+            rows = sh.owned_rows(sc.height, rank, world, band)
+            assert r.rows == len(rows)
+            img = r.render_frame(sc.desc, sc.settings)
+            np.testing.assert_array_equal(img, ref[rows])
+            parts.append(torch.from_numpy(img))
+            r.close()
+        np.testing.assert_array_equal(sh.assemble_banded(parts, sc.height, band).numpy(), ref)
 
 
 def test_materials_with_unequal_texture_sizes(pkg, oracle, hip):

@@ -32,6 +32,21 @@ def test_row_range_partitions_the_frame(pkg):
         sh.row_range(100, 4, 4)
 
 
+def test_owned_rows_partition_and_assemble(pkg):
+    from importlib import import_module
+    sh = import_module("arctic_renderer_amd.sharding")
+    for h, world, band in ((2160, 8, 16), (216, 3, 16), (100, 4, 8), (4320, 8, 32)):
+        rows = [sh.owned_rows(h, r, world, band) for r in range(world)]
+        allr = np.sort(np.concatenate(rows))
+        np.testing.assert_array_equal(allr, np.arange(h))                     # a partition of the frame
+        assert max(map(len, rows)) - min(map(len, rows)) <= band
+        frame = torch.arange(h * 5 * 4, dtype=torch.int64).reshape(h, 5, 4).to(torch.uint8)
+        parts = [frame[torch.as_tensor(r)] for r in rows]
+        assert torch.equal(sh.assemble_banded(parts, h, band), frame)
+    with pytest.raises(ValueError):
+        sh.owned_rows(100, 0, 2, 12)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
