@@ -128,6 +128,7 @@ struct ShadeParams {
     float4 *lit_r0, *lit_r1, *lit_r2;   // (world.xyz, 1-shadow) (n.xyz, roughness) (base.xyz, metalness)
     uint32_t *lit_px;                   // pixel index y*width + x inside the shard
     uint32_t *lit_count;                // LIT_SHARDS counters, LIT_COUNTER_STRIDE apart
+    int32_t hdr16;                      // 1: round ps_main's colour through binary16 like the reference's RGBA16F target
     int32_t debug;                      // timing experiments only: 1 skip material textures, 2 skip shadow test
     uint32_t lit_shard_cap;             // records per shard of one band: ceil(band workgroups / LIT_SHARDS) * 256, cannot overflow
     uint32_t band, n_bands;             // set by launch_shade
@@ -153,9 +154,9 @@ hipError_t launch_setup(const ObjectRec *objs, const uint32_t *block_obj, const 
                         SetupRec *recs, uint32_t *tile_count, hipStream_t s);
 hipError_t launch_scan(const uint32_t *in, uint32_t *out /*n+1, exclusive*/, uint32_t n, uint32_t *scratch, hipStream_t s);
 uint32_t scan_scratch_elems(uint32_t n);
-hipError_t launch_raster_vis(const SetupRec *recs, const uint32_t *tile_offset, uint32_t n_recs, uint32_t n_items,
+hipError_t launch_raster_vis(const SetupRec *recs, const uint32_t *tile_offset, uint32_t n_slots, uint32_t grid_blocks,
                              const GeomParams *gp, unsigned long long *vis, hipStream_t s);
-hipError_t launch_raster_depth(const SetupRec *recs, const uint32_t *tile_offset, uint32_t n_recs, uint32_t n_items,
+hipError_t launch_raster_depth(const SetupRec *recs, const uint32_t *tile_offset, uint32_t n_slots, uint32_t grid_blocks,
                                const GeomParams *gp, uint32_t *depth_bits, hipStream_t s);
 hipError_t launch_resolve(const unsigned long long *vis, const SetupRec *recs, const ObjectRec *objs, const XVert *xv,
                           const GeomParams *gp, uint32_t n_tiles, GBuffer g, float *depth_out, uint32_t *src_out, hipStream_t s);

@@ -298,38 +298,42 @@ __device__ __forceinline__ uint32_t find_record(const uint32_t *__restrict__ til
     return lo;
 }
 
+// Persistent: the number of work items is only known on the device (tile_offset[n_slots], the total of the scan), so a
+// fixed grid strides over them and the host never waits for a count.  n_slots = capacity of the record array; slots past
+// the last record have zero tiles and offset == total, which the search skips by construction.
 template <bool DEPTH_ONLY>
 __global__ __launch_bounds__(256) void k_raster(const SetupRec *__restrict__ recs, const uint32_t *__restrict__ tile_offset,
-                                                uint32_t n_recs, uint32_t n_items, const GeomParams *__restrict__ gpp,
+                                                uint32_t n_slots, const GeomParams *__restrict__ gpp,
                                                 unsigned long long *__restrict__ vis, uint32_t *__restrict__ depth_bits) {
-    uint32_t item = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (item >= n_items) return;
-    uint32_t lane = threadIdx.x & 63;
-    uint32_t r = find_record(tile_offset, n_recs, item);
-    r = __builtin_amdgcn_readfirstlane(r);
-    const SetupRec &t = recs[r];
-    uint32_t local = item - tile_offset[r];
-    int32_t tx0 = t.px0 >> 3, ty0 = t.py0 >> 3;
-    uint32_t ntx = (uint32_t)((t.px1 >> 3) - tx0 + 1);
-    int32_t tx = tx0 + (int32_t)(local % ntx), ty = ty0 + (int32_t)(local / ntx);
-    int32_t px = tx * 8 + (int32_t)(lane & 7), py = ty * 8 + (int32_t)(lane >> 3);
-    if (px < t.px0 || px > t.px1 || py < t.py0 || py > t.py1) return;
-    Edges e;
-    make_edges(t, e);
-    float inv_area = 1.0f / (float)t.area2;
-    float l1, l2, z;
-    if (!fragment(t, e, inv_area, px, py, l1, l2, z)) return;
-    if (!(z < 1.0f)) return;   // depth LESS against the 1.0 clear
-    if (DEPTH_ONLY) {
-        uint32_t *p = depth_bits + (size_t)py * gpp->pitch + px;
-        uint32_t zb = __float_as_uint(z);
-        if (zb < *p) atomicMin(p, zb);
-    } else {
-        const int ty_rel = ty - gpp->tile_y0;
-        if (!row_owned(ty_rel, gpp->band_tiles, gpp->shard_count, gpp->shard_index)) return;   // another shard's band
-        size_t idx = ((size_t)row_local(ty_rel, gpp->band_tiles, gpp->shard_count) * gpp->tiles_x + tx) * 64 + lane;
-        unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | r;   // ties: first drawn (smallest id) wins
-        if (key < vis[idx]) atomicMin(&vis[idx], key);
+    const uint32_t n_items = tile_offset[n_slots];
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t item = blockIdx.x * 4 + (threadIdx.x >> 6); item < n_items; item += gridDim.x * 4) {
+        uint32_t r = find_record(tile_offset, n_slots, item);
+        r = __builtin_amdgcn_readfirstlane(r);
+        const SetupRec &t = recs[r];
+        uint32_t local = item - tile_offset[r];
+        int32_t tx0 = t.px0 >> 3, ty0 = t.py0 >> 3;
+        uint32_t ntx = (uint32_t)((t.px1 >> 3) - tx0 + 1);
+        int32_t tx = tx0 + (int32_t)(local % ntx), ty = ty0 + (int32_t)(local / ntx);
+        int32_t px = tx * 8 + (int32_t)(lane & 7), py = ty * 8 + (int32_t)(lane >> 3);
+        if (px < t.px0 || px > t.px1 || py < t.py0 || py > t.py1) continue;
+        Edges e;
+        make_edges(t, e);
+        float inv_area = 1.0f / (float)t.area2;
+        float l1, l2, z;
+        if (!fragment(t, e, inv_area, px, py, l1, l2, z)) continue;
+        if (!(z < 1.0f)) continue;   // depth LESS against the 1.0 clear
+        if (DEPTH_ONLY) {
+            uint32_t *p = depth_bits + (size_t)py * gpp->pitch + px;
+            uint32_t zb = __float_as_uint(z);
+            if (zb < *p) atomicMin(p, zb);
+        } else {
+            const int ty_rel = ty - gpp->tile_y0;
+            if (!row_owned(ty_rel, gpp->band_tiles, gpp->shard_count, gpp->shard_index)) continue;   // another shard's band
+            size_t idx = ((size_t)row_local(ty_rel, gpp->band_tiles, gpp->shard_count) * gpp->tiles_x + tx) * 64 + lane;
+            unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | r;   // ties: first drawn (smallest id) wins
+            if (key < vis[idx]) atomicMin(&vis[idx], key);
+        }
     }
 }
 
@@ -477,17 +481,17 @@ hipError_t launch_scan(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *
     return hipGetLastError();
 }
 
-hipError_t launch_raster_vis(const SetupRec *recs, const uint32_t *tile_offset, uint32_t n_recs, uint32_t n_items,
+hipError_t launch_raster_vis(const SetupRec *recs, const uint32_t *tile_offset, uint32_t n_slots, uint32_t grid_blocks,
                              const GeomParams *gp, unsigned long long *vis, hipStream_t s) {
-    if (n_items == 0) return hipSuccess;
-    k_raster<false><<<div_up(n_items, 4), 256, 0, s>>>(recs, tile_offset, n_recs, n_items, gp, vis, nullptr);
+    if (n_slots == 0) return hipSuccess;
+    k_raster<false><<<grid_blocks, 256, 0, s>>>(recs, tile_offset, n_slots, gp, vis, nullptr);
     return hipGetLastError();
 }
 
-hipError_t launch_raster_depth(const SetupRec *recs, const uint32_t *tile_offset, uint32_t n_recs, uint32_t n_items,
+hipError_t launch_raster_depth(const SetupRec *recs, const uint32_t *tile_offset, uint32_t n_slots, uint32_t grid_blocks,
                                const GeomParams *gp, uint32_t *depth_bits, hipStream_t s) {
-    if (n_items == 0) return hipSuccess;
-    k_raster<true><<<div_up(n_items, 4), 256, 0, s>>>(recs, tile_offset, n_recs, n_items, gp, nullptr, depth_bits);
+    if (n_slots == 0) return hipSuccess;
+    k_raster<true><<<grid_blocks, 256, 0, s>>>(recs, tile_offset, n_slots, gp, nullptr, depth_bits);
     return hipGetLastError();
 }
 

@@ -35,6 +35,21 @@ struct DevBuf {
     template <class T> T *as() const { return static_cast<T *>(p); }
 };
 
+// per-pass host->device tables (frame constants, object records, block tables): written into pinned memory and sent with
+// ONE asynchronous copy; the pinned buffer is reused only after the copy that last read it has completed (event), so
+// uploading never waits for the kernels of the previous pass or frame.
+struct PassTables {
+    void *h = nullptr;          // pinned staging
+    size_t h_cap = 0;
+    DevBuf d;                   // device arena
+    hipEvent_t copied = nullptr;
+    bool pending = false;
+    // device views into the arena (valid after upload)
+    const GeomParams *gp = nullptr;
+    const ObjectRec *objs = nullptr;
+    const uint32_t *vblock_obj = nullptr, *vblock_first = nullptr, *tblock_obj = nullptr, *tblock_first = nullptr;
+};
+
 struct Mesh {
     float *d_vertices = nullptr;
     uint32_t *d_indices = nullptr;
@@ -61,11 +76,13 @@ struct ArcticRenderer {
     DevBuf d_lit0, d_lit1, d_lit2, d_litpx, d_litcount;   // lit-pixel stream between k_material and k_light
     bool have_gbuffer = false, have_output = false;
     // per-frame geometry scratch
-    DevBuf d_objs, d_vblock_obj, d_vblock_first, d_tblock_obj, d_tblock_first, d_xverts, d_sub_count, d_sub_offset,
-        d_recs, d_tile_count, d_tile_offset, d_scan, d_gp, d_stage;
+    PassTables tables[2];   // [0] forward pass, [1] shadow pass
+    DevBuf d_xverts, d_sub_count, d_sub_offset, d_recs, d_tile_count, d_tile_offset, d_scan, d_stage;
     uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int keep_float = 0, count_evals = 0, culling = 1, debug = 0;
+    int keep_float = 0, count_evals = 0, culling = 1, debug = 0, hdr16 = 0;
     ShadeLaunch launch{};           // streams, events, band count and k_light's persistent grid
+    uint32_t raster_blocks = 2048;  // persistent grid of k_raster
+    uint32_t *h_counts = nullptr;   // pinned: [0] records, [1] work items (forward), [2], [3] the same for the shadow pass
     std::string err;
 
     int fail(int code, const char *fmt, ...) {
@@ -136,9 +153,9 @@ int alloc_targets(ArcticRenderer *r) {
     return ARCTIC_OK;
 }
 
-// Scene.objects -> ObjectRec[] + block tables; returns counts through the out params
-int upload_objects(ArcticRenderer *r, const ArcticScene *sc, uint32_t &n_objs, uint32_t &n_xverts, uint32_t &n_src_tris,
-                   uint32_t &n_vblocks, uint32_t &n_tblocks) {
+// Scene.objects -> frame constants + ObjectRec[] + block tables in one asynchronous upload
+int upload_pass_tables(ArcticRenderer *r, PassTables &T, const GeomParams &gp, const ArcticScene *sc, uint32_t &n_objs,
+                       uint32_t &n_xverts, uint32_t &n_src_tris, uint32_t &n_vblocks, uint32_t &n_tblocks) {
     std::vector<ObjectRec> objs;
     std::vector<uint32_t> vb_obj, vb_first, tb_obj, tb_first;
     uint64_t xv = 0, tri = 0;
@@ -166,26 +183,43 @@ int upload_objects(ArcticRenderer *r, const ArcticScene *sc, uint32_t &n_objs, u
     if (xv > 0xFFFFFFF0ull || tri > 0xFFFFFFF0ull) return r->fail(ARCTIC_E_CAPACITY, "scene too large: %llu vertices, %llu triangles", (unsigned long long)xv, (unsigned long long)tri);
     n_objs = (uint32_t)objs.size(); n_xverts = (uint32_t)xv; n_src_tris = (uint32_t)tri;
     n_vblocks = (uint32_t)vb_obj.size(); n_tblocks = (uint32_t)tb_obj.size();
-    if (n_objs == 0) return ARCTIC_OK;
-    auto up = [&](DevBuf &b, const void *src, size_t bytes) -> hipError_t {
-        hipError_t e = b.ensure(bytes);
-        if (e != hipSuccess) return e;
-        return hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, r->stream);
-    };
-    HIPCHECK(r, up(r->d_objs, objs.data(), objs.size() * sizeof(ObjectRec)));
-    HIPCHECK(r, up(r->d_vblock_obj, vb_obj.data(), vb_obj.size() * 4));
-    HIPCHECK(r, up(r->d_vblock_first, vb_first.data(), vb_first.size() * 4));
-    HIPCHECK(r, up(r->d_tblock_obj, tb_obj.data(), tb_obj.size() * 4));
-    HIPCHECK(r, up(r->d_tblock_first, tb_first.data(), tb_first.size() * 4));
-    HIPCHECK(r, hipStreamSynchronize(r->stream));   // the host vectors die at return
-    HIPCHECK(r, r->d_xverts.ensure((size_t)n_xverts * sizeof(XVert)));
-    HIPCHECK(r, r->d_sub_count.ensure((size_t)n_src_tris * 4 + 4));
-    HIPCHECK(r, r->d_sub_offset.ensure((size_t)n_src_tris * 4 + 8));
+    // arena layout (16-byte aligned sections)
+    auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    const size_t o_gp = 0, o_objs = align16(sizeof(GeomParams)), o_vo = align16(o_objs + objs.size() * sizeof(ObjectRec)),
+                 o_vf = align16(o_vo + vb_obj.size() * 4), o_to = align16(o_vf + vb_first.size() * 4),
+                 o_tf = align16(o_to + tb_obj.size() * 4), total = align16(o_tf + tb_first.size() * 4) + 16;
+    if (T.pending) { HIPCHECK(r, hipEventSynchronize(T.copied)); T.pending = false; }
+    if (total > T.h_cap) {
+        if (T.h) HIPCHECK(r, hipHostFree(T.h));
+        T.h = nullptr; T.h_cap = 0;
+        HIPCHECK(r, hipHostMalloc(&T.h, total * 2));
+        T.h_cap = total * 2;
+    }
+    if (!T.copied) HIPCHECK(r, hipEventCreateWithFlags(&T.copied, hipEventDisableTiming));
+    HIPCHECK(r, T.d.ensure(total));
+    char *h = static_cast<char *>(T.h);
+    std::memcpy(h + o_gp, &gp, sizeof gp);
+    if (!objs.empty()) std::memcpy(h + o_objs, objs.data(), objs.size() * sizeof(ObjectRec));
+    if (!vb_obj.empty()) { std::memcpy(h + o_vo, vb_obj.data(), vb_obj.size() * 4); std::memcpy(h + o_vf, vb_first.data(), vb_first.size() * 4); }
+    if (!tb_obj.empty()) { std::memcpy(h + o_to, tb_obj.data(), tb_obj.size() * 4); std::memcpy(h + o_tf, tb_first.data(), tb_first.size() * 4); }
+    HIPCHECK(r, hipMemcpyAsync(T.d.p, T.h, total, hipMemcpyHostToDevice, r->stream));
+    HIPCHECK(r, hipEventRecord(T.copied, r->stream));
+    T.pending = true;
+    const char *d = T.d.as<char>();
+    T.gp = reinterpret_cast<const GeomParams *>(d + o_gp);
+    T.objs = reinterpret_cast<const ObjectRec *>(d + o_objs);
+    T.vblock_obj = reinterpret_cast<const uint32_t *>(d + o_vo); T.vblock_first = reinterpret_cast<const uint32_t *>(d + o_vf);
+    T.tblock_obj = reinterpret_cast<const uint32_t *>(d + o_to); T.tblock_first = reinterpret_cast<const uint32_t *>(d + o_tf);
+    if (n_objs) {
+        HIPCHECK(r, r->d_xverts.ensure((size_t)n_xverts * sizeof(XVert)));
+        HIPCHECK(r, r->d_sub_count.ensure((size_t)n_src_tris * 4 + 4));
+        HIPCHECK(r, r->d_sub_offset.ensure((size_t)n_src_tris * 4 + 8));
+    }
     return ARCTIC_OK;
 }
 
 // vertex -> clip/setup -> raster, shared by the forward prepass and the shadow pass
-int run_geometry(ArcticRenderer *r, const ArcticScene *sc, bool shadow_pass, uint64_t &n_recs_out, uint64_t &n_items_out) {
+int run_geometry(ArcticRenderer *r, const ArcticScene *sc, bool shadow_pass) {
     GeomParams gp;
     std::memset(&gp, 0, sizeof gp);
     sun_proj_view(sc->sun.position, sc->sun.rotation, gp.light_from_world);
@@ -204,46 +238,43 @@ int run_geometry(ArcticRenderer *r, const ArcticScene *sc, bool shadow_pass, uin
         gp.tiles_x = (int32_t)r->tiles_x; gp.tile_y0 = (int32_t)r->tile_y0; gp.pitch = 0;
         gp.band_tiles = (int32_t)(r->band_rows / TILE); gp.shard_index = (int32_t)r->shard_index; gp.shard_count = (int32_t)r->shard_count;
     }
-    HIPCHECK(r, r->d_gp.ensure(sizeof gp));
-    HIPCHECK(r, hipMemcpyAsync(r->d_gp.p, &gp, sizeof gp, hipMemcpyHostToDevice, r->stream));
-    HIPCHECK(r, hipStreamSynchronize(r->stream));
-    const GeomParams *d_gp = r->d_gp.as<GeomParams>();
-
+    PassTables &T = r->tables[shadow_pass ? 1 : 0];
     uint32_t n_objs, n_xverts, n_src, n_vblocks, n_tblocks;
-    int rc = upload_objects(r, sc, n_objs, n_xverts, n_src, n_vblocks, n_tblocks);
+    int rc = upload_pass_tables(r, T, gp, sc, n_objs, n_xverts, n_src, n_vblocks, n_tblocks);
     if (rc != ARCTIC_OK) return rc;
-    n_recs_out = n_items_out = 0;
+    const GeomParams *d_gp = T.gp;
+    r->h_counts[shadow_pass ? 2 : 0] = r->h_counts[shadow_pass ? 3 : 1] = 0;
     if (n_objs == 0 || n_src == 0) return ARCTIC_OK;
-    const ObjectRec *objs = r->d_objs.as<ObjectRec>();
-    HIPCHECK(r, launch_vertex(objs, r->d_vblock_obj.as<uint32_t>(), r->d_vblock_first.as<uint32_t>(), n_vblocks, d_gp,
-                              r->d_xverts.as<XVert>(), shadow_pass ? 1 : 0, r->stream));
-    // pass 1: count, scan
-    HIPCHECK(r, launch_setup(objs, r->d_tblock_obj.as<uint32_t>(), r->d_tblock_first.as<uint32_t>(), n_tblocks, d_gp,
+    const ObjectRec *objs = T.objs;
+    HIPCHECK(r, launch_vertex(objs, T.vblock_obj, T.vblock_first, n_vblocks, d_gp, r->d_xverts.as<XVert>(), shadow_pass ? 1 : 0, r->stream));
+    // Record slots: a triangle clipped against 6 planes yields at most 7 triangles, so 7 * n_src slots can never overflow and
+    // neither the record count nor the work-item count has to come back to the host: the frame stays asynchronous.
+    const uint64_t slots64 = 7ull * n_src;
+    if (slots64 > 0x7FFFFFF0ull) return r->fail(ARCTIC_E_CAPACITY, "scene too large: %u triangles", n_src);
+    const uint32_t n_slots = (uint32_t)slots64;
+    HIPCHECK(r, r->d_scan.ensure(((size_t)scan_scratch_elems(n_src) + scan_scratch_elems(n_slots)) * 4 + 4096));
+    HIPCHECK(r, r->d_recs.ensure((size_t)n_slots * sizeof(SetupRec)));
+    HIPCHECK(r, r->d_tile_count.ensure((size_t)n_slots * 4 + 4));
+    HIPCHECK(r, r->d_tile_offset.ensure((size_t)n_slots * 4 + 8));
+    // pass 1: count the triangles each source triangle yields, scan
+    HIPCHECK(r, launch_setup(objs, T.tblock_obj, T.tblock_first, n_tblocks, d_gp,
                              r->d_xverts.as<XVert>(), nullptr, r->d_sub_count.as<uint32_t>(), nullptr, nullptr, r->stream));
-    HIPCHECK(r, r->d_scan.ensure(((size_t)scan_scratch_elems(n_src) + scan_scratch_elems(7 * (size_t)n_src > 0xFFFFFFF0ull ? 0xFFFFFFF0u : 7 * n_src)) * 4 + 4096));
     HIPCHECK(r, launch_scan(r->d_sub_count.as<uint32_t>(), r->d_sub_offset.as<uint32_t>(), n_src, r->d_scan.as<uint32_t>(), r->stream));
-    uint32_t n_recs = 0;
-    HIPCHECK(r, hipMemcpyAsync(&n_recs, r->d_sub_offset.as<uint32_t>() + n_src, 4, hipMemcpyDeviceToHost, r->stream));
-    HIPCHECK(r, hipStreamSynchronize(r->stream));
-    n_recs_out = n_recs;
-    if (n_recs == 0) return ARCTIC_OK;
-    // pass 2: emit compacted records + tiles per record, scan
-    HIPCHECK(r, r->d_recs.ensure((size_t)n_recs * sizeof(SetupRec)));
-    HIPCHECK(r, r->d_tile_count.ensure((size_t)n_recs * 4 + 4));
-    HIPCHECK(r, r->d_tile_offset.ensure((size_t)n_recs * 4 + 8));
-    HIPCHECK(r, launch_setup(objs, r->d_tblock_obj.as<uint32_t>(), r->d_tblock_first.as<uint32_t>(), n_tblocks, d_gp,
+    // pass 2: emit the compacted records + tiles per record (unused slots stay 0), scan
+    HIPCHECK(r, hipMemsetAsync(r->d_tile_count.p, 0, (size_t)n_slots * 4, r->stream));
+    HIPCHECK(r, launch_setup(objs, T.tblock_obj, T.tblock_first, n_tblocks, d_gp,
                              r->d_xverts.as<XVert>(), r->d_sub_offset.as<uint32_t>(), nullptr, r->d_recs.as<SetupRec>(),
                              r->d_tile_count.as<uint32_t>(), r->stream));
-    HIPCHECK(r, launch_scan(r->d_tile_count.as<uint32_t>(), r->d_tile_offset.as<uint32_t>(), n_recs, r->d_scan.as<uint32_t>(), r->stream));
-    uint32_t n_items = 0;
-    HIPCHECK(r, hipMemcpyAsync(&n_items, r->d_tile_offset.as<uint32_t>() + n_recs, 4, hipMemcpyDeviceToHost, r->stream));
-    HIPCHECK(r, hipStreamSynchronize(r->stream));
-    n_items_out = n_items;
+    HIPCHECK(r, launch_scan(r->d_tile_count.as<uint32_t>(), r->d_tile_offset.as<uint32_t>(), n_slots, r->d_scan.as<uint32_t>(), r->stream));
+    // counts for arctic_stats(): copied to pinned memory, looked at only when asked for
+    uint32_t *h = r->h_counts + (shadow_pass ? 2 : 0);
+    HIPCHECK(r, hipMemcpyAsync(h, r->d_sub_offset.as<uint32_t>() + n_src, 4, hipMemcpyDeviceToHost, r->stream));
+    HIPCHECK(r, hipMemcpyAsync(h + 1, r->d_tile_offset.as<uint32_t>() + n_slots, 4, hipMemcpyDeviceToHost, r->stream));
     if (shadow_pass)
-        HIPCHECK(r, launch_raster_depth(r->d_recs.as<SetupRec>(), r->d_tile_offset.as<uint32_t>(), n_recs, n_items, d_gp,
+        HIPCHECK(r, launch_raster_depth(r->d_recs.as<SetupRec>(), r->d_tile_offset.as<uint32_t>(), n_slots, r->raster_blocks, d_gp,
                                         r->d_shadow.as<uint32_t>(), r->stream));
     else
-        HIPCHECK(r, launch_raster_vis(r->d_recs.as<SetupRec>(), r->d_tile_offset.as<uint32_t>(), n_recs, n_items, d_gp,
+        HIPCHECK(r, launch_raster_vis(r->d_recs.as<SetupRec>(), r->d_tile_offset.as<uint32_t>(), n_slots, r->raster_blocks, d_gp,
                                       r->d_vis.as<unsigned long long>(), r->stream));
     return ARCTIC_OK;
 }
@@ -252,15 +283,15 @@ int pass_shadow_map(ArcticRenderer *r, const ArcticScene *sc) {
     if (r->shadow_size == 0) return ARCTIC_OK;
     size_t n = (size_t)r->shadow_size * r->shadow_size;
     HIPCHECK(r, launch_fill_u32(r->d_shadow.as<uint32_t>(), 0x3F800000u, n, r->stream));   // clear to 1.0 (shadow_map_pass.cpp:124-131)
-    return run_geometry(r, sc, true, r->stats[2], r->stats[3]);
+    return run_geometry(r, sc, true);
 }
 
 int pass_gbuffer(ArcticRenderer *r, const ArcticScene *sc) {
     HIPCHECK(r, launch_fill_u64(r->d_vis.as<unsigned long long>(), ~0ull, r->n_tiles() * TILE_PIXELS, r->stream));
-    int rc = run_geometry(r, sc, false, r->stats[0], r->stats[1]);
+    int rc = run_geometry(r, sc, false);
     if (rc != ARCTIC_OK) return rc;
-    HIPCHECK(r, launch_resolve(r->d_vis.as<unsigned long long>(), r->d_recs.as<SetupRec>(), r->d_objs.as<ObjectRec>(),
-                               r->d_xverts.as<XVert>(), r->d_gp.as<GeomParams>(), (uint32_t)r->n_tiles(), r->gbuffer(),
+    HIPCHECK(r, launch_resolve(r->d_vis.as<unsigned long long>(), r->d_recs.as<SetupRec>(), r->tables[0].objs,
+                               r->d_xverts.as<XVert>(), r->tables[0].gp, (uint32_t)r->n_tiles(), r->gbuffer(),
                                r->d_depth.as<float>(), r->d_src.as<uint32_t>(), r->stream));
     r->have_gbuffer = true;
     return ARCTIC_OK;
@@ -296,6 +327,7 @@ int fill_shade_params(ArcticRenderer *r, const ArcticScene *sc, const ArcticSett
     sp.light_evals = r->count_evals ? r->d_counter.as<unsigned long long>() : nullptr;
     sp.culling = r->culling;
     sp.debug = r->debug;
+    sp.hdr16 = r->hdr16;
     sp.lit_r0 = r->d_lit0.as<float4>(); sp.lit_r1 = r->d_lit1.as<float4>(); sp.lit_r2 = r->d_lit2.as<float4>();
     sp.lit_px = r->d_litpx.as<uint32_t>(); sp.lit_count = r->d_litcount.as<uint32_t>();
     sp.lit_shard_cap = r->lit_shard_cap();
@@ -373,6 +405,9 @@ ArcticRenderer *arctic_create(const ArcticCreateInfo *info, char *err, uint64_t 
         if ((e = hipGetDeviceProperties(&prop, r->device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
         r->launch.light_blocks = (uint32_t)std::max(1, prop.multiProcessorCount) * 4;   // k_light: persistent, 4 workgroups of 4 waves per CU
         r->launch.n_bands = 1;
+        r->raster_blocks = (uint32_t)std::max(1, prop.multiProcessorCount) * 8;
+        if ((e = hipHostMalloc((void **)&r->h_counts, 64)) != hipSuccess) return bail("hipHostMalloc", e);
+        std::memset(r->h_counts, 0, 64);
         r->launch.main = r->stream;
         if ((e = hipStreamCreateWithFlags(&r->launch.aux, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate aux", e);
         for (uint32_t k = 0; k < MAX_BANDS; ++k)
@@ -398,6 +433,7 @@ ArcticRenderer *arctic_create(const ArcticCreateInfo *info, char *err, uint64_t 
 void arctic_destroy(ArcticRenderer *r) {
     if (!r) return;
     (void)hipSetDevice(r->device);
+    if (r->h_counts) (void)hipHostFree(r->h_counts);
     if (r->launch.aux) { (void)hipStreamSynchronize(r->launch.aux); (void)hipStreamDestroy(r->launch.aux); }
     for (uint32_t k = 0; k < MAX_BANDS; ++k) if (r->launch.band_done[k]) (void)hipEventDestroy(r->launch.band_done[k]);
     if (r->launch.aux_done) (void)hipEventDestroy(r->launch.aux_done);
@@ -406,9 +442,9 @@ void arctic_destroy(ArcticRenderer *r) {
     for (Mesh &m : r->meshes) { if (m.d_vertices) (void)hipFree(m.d_vertices); if (m.d_indices) (void)hipFree(m.d_indices); }
     for (void *p : r->tex_allocs) (void)hipFree(p);
     DevBuf *bufs[] = {&r->d_tex, &r->d_lut, &r->d_lights, &r->d_shadow, &r->d_vis, &r->d_p0, &r->d_p1, &r->d_p2, &r->d_p3, &r->d_p4,
-                      &r->d_depth, &r->d_src, &r->d_rgba8, &r->d_ldr, &r->d_hdr, &r->d_counter, &r->d_lit0, &r->d_lit1, &r->d_lit2, &r->d_litpx, &r->d_litcount, &r->d_objs, &r->d_vblock_obj,
-                      &r->d_vblock_first, &r->d_tblock_obj, &r->d_tblock_first, &r->d_xverts, &r->d_sub_count, &r->d_sub_offset,
-                      &r->d_recs, &r->d_tile_count, &r->d_tile_offset, &r->d_scan, &r->d_gp, &r->d_stage};
+                      &r->d_depth, &r->d_src, &r->d_rgba8, &r->d_ldr, &r->d_hdr, &r->d_counter, &r->d_lit0, &r->d_lit1, &r->d_lit2, &r->d_litpx, &r->d_litcount, &r->d_xverts, &r->d_sub_count, &r->d_sub_offset,
+                      &r->d_recs, &r->d_tile_count, &r->d_tile_offset, &r->d_scan, &r->d_stage, &r->tables[0].d, &r->tables[1].d};
+    for (PassTables &T : r->tables) { if (T.h) (void)hipHostFree(T.h); if (T.copied) (void)hipEventDestroy(T.copied); }
     for (DevBuf *b : bufs) b->release();
     delete r;
 }
@@ -718,6 +754,8 @@ int arctic_frame_constants(const ArcticScene *scene, float *proj_view, float *li
 
 int arctic_stats(ArcticRenderer *r, uint64_t *out, uint32_t n) {
     if (!r || !out) return ARCTIC_E_INVALID;
+    if (select_device(r) == ARCTIC_OK && r->stream) (void)hipStreamSynchronize(r->stream);
+    if (r->h_counts) for (int i = 0; i < 4; ++i) r->stats[i] = r->h_counts[i];
     for (uint32_t i = 0; i < n && i < 8; ++i) out[i] = r->stats[i];
     return ARCTIC_OK;
 }
@@ -729,6 +767,7 @@ int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value) {
     case ARCTIC_OPT_COUNT_LIGHT_EVALS: r->count_evals = value != 0; break;
     case ARCTIC_OPT_CULLING: r->culling = value != 0; break;
     case ARCTIC_OPT_DEBUG: r->debug = (int)value; break;
+    case ARCTIC_OPT_HDR16: r->hdr16 = value != 0; break;
     case ARCTIC_OPT_BANDS:
         if (value < 1 || value > (int64_t)MAX_BANDS) return r->fail(ARCTIC_E_INVALID, "set_option: bands must be 1..%u", MAX_BANDS);
         r->launch.n_bands = (uint32_t)value;

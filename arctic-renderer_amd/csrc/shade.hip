@@ -362,7 +362,12 @@ __device__ __forceinline__ TexRef lds_desc(const uint4 *d) {
     return t;
 }
 
+// the reference renders ps_main into an R16G16B16A16_FLOAT target (forward_pass.cpp:149) that post_process then reads:
+// hdr16 reproduces that rounding (round-to-nearest-even to binary16, finite overflow to +inf like the ROP's conversion)
+__device__ __forceinline__ float through_half(float x) { return (float)(_Float16)x; }
+
 __device__ __forceinline__ void store_pixel(const ShadeParams &sp, size_t o, f3 color) {
+    if (sp.hdr16) color = mk(through_half(color.x), through_half(color.y), through_half(color.z));
     const f3 l = post_process(color, sp.tm_method, sp.inv_gamma, sp.exposure);
     reinterpret_cast<uint32_t *>(sp.out_rgba8)[o] = unorm8(l.x) | (unorm8(l.y) << 8) | (unorm8(l.z) << 16) | 0xFF000000u;
     if (sp.out_ldr) { sp.out_ldr[o * 3] = l.x; sp.out_ldr[o * 3 + 1] = l.y; sp.out_ldr[o * 3 + 2] = l.z; }

@@ -359,6 +359,7 @@ struct Oracle {
     std::vector<uint8_t> rgba8;     // rows*width*4
     float srgb_lut[256];
     uint64_t stats[6] = {0, 0, 0, 0, 0, 0};
+    int hdr16 = 0;        // 1: ps_main's colour passes through binary16 (the reference's RGBA16F target) before post_process
     int precision = 64;   // arithmetic of the BRDF/tonemap: 64 = float64 (parity arbiter), 32 = literal fp32 (CPU baseline)
     std::string err;
     uint32_t rows() const { return row_end - row_begin; }
@@ -691,6 +692,27 @@ template <class R> inline Vec3<R> post_process(Vec3<R> c, const Settings &st) { 
     R ig = R(1) / (R)st.gamma;                                                                                // :34-37
     return vec3<R>(std::pow(std::fabs(c.x), ig), std::pow(std::fabs(c.y), ig), std::pow(std::fabs(c.z), ig));
 }
+// fp32 -> binary16 -> fp32, round to nearest even: the R16G16B16A16_FLOAT colour target of the reference
+// (forward_pass.cpp:149, renderer.cpp:128-144) that sits between ps_main and post_process
+inline float through_half(float f) {
+    uint32_t x; std::memcpy(&x, &f, 4);
+    uint32_t sign = x & 0x80000000u, a = x & 0x7FFFFFFFu;
+    if (a >= 0x7F800000u) return f;                               // inf / nan
+    if (a >= 0x477FF000u) { uint32_t inf = sign | 0x7F800000u; float r; std::memcpy(&r, &inf, 4); return r; }   // rounds past 65504
+    if (a < 0x33000001u) { float r; std::memcpy(&r, &sign, 4); return r; }                                      // below half the smallest subnormal
+    uint32_t r;
+    if (a < 0x38800000u) {                                        // binary16 subnormal: quantum 2^-24
+        float q = std::nearbyint(std::fabs(f) * 16777216.0f) / 16777216.0f;   // default rounding mode = nearest even
+        std::memcpy(&r, &q, 4);
+        r |= sign;
+    } else {
+        uint32_t lsb = (a >> 13) & 1u;
+        r = sign | ((a + 0x0FFFu + lsb) & 0xFFFFE000u);
+    }
+    float out; std::memcpy(&out, &r, 4);
+    return out;
+}
+
 // float -> UNORM8 store of the RGBA8 target (renderer.cpp:161-175): D3D rule = saturate (NaN -> 0), *255, +0.5, truncate
 inline uint8_t to_unorm8(float x) {
     if (!(x > 0.0f)) return 0;
@@ -716,6 +738,7 @@ void shade_rows(Oracle &o, const Scene &sc, const Settings &st, const float *att
                 c = ps_main<R>(o, attrs + p * 18, m, eye, sun_dir, sun_color, sc.ambient, smap);
                 ++count;
             }
+            if (o.hdr16) c = vec3<R>((R)through_half((float)c.x), (R)through_half((float)c.y), (R)through_half((float)c.z));
             Vec3<R> l = post_process<R>(c, st);
             if (hdr) { hdr[p * 3] = (float)c.x; hdr[p * 3 + 1] = (float)c.y; hdr[p * 3 + 2] = (float)c.z; }
             if (ldr) { ldr[p * 3] = (float)l.x; ldr[p * 3 + 1] = (float)l.y; ldr[p * 3 + 2] = (float)l.z; }
@@ -919,6 +942,13 @@ int oracle_fetch_surface(void *h, uint32_t mat, float u, float v, const float tb
     return 0;
 }
 uint8_t oracle_to_unorm8(float x) { return to_unorm8(x); }
+int oracle_set_hdr16(void *h, int on) {
+    Oracle *o = static_cast<Oracle *>(h);
+    if (!o) return -1;
+    o->hdr16 = on != 0;
+    return 0;
+}
+float oracle_through_half(float x) { return through_half(x); }
 // 64 (default): BRDF + tonemap in float64, the parity arbiter; 32: the literal fp32 restatement (timed CPU baseline)
 int oracle_set_precision(void *h, int bits) {
     Oracle *o = static_cast<Oracle *>(h);

@@ -87,6 +87,9 @@ def lib():
         L.oracle_to_unorm8.argtypes = [f32]
         L.oracle_hardware_threads.restype = i32
         L.oracle_set_precision.argtypes = [vp, i32]
+        L.oracle_set_hdr16.argtypes = [vp, i32]
+        L.oracle_through_half.restype = f32
+        L.oracle_through_half.argtypes = [f32]
         _lib = L
     return _lib
 
@@ -114,6 +117,11 @@ class Oracle:
     def set_precision(self, bits):
         """64 (default): BRDF/tonemap in float64 = the parity arbiter; 32: literal fp32 restatement (CPU baseline)."""
         assert self.L.oracle_set_precision(self.h, bits) == 0
+        return self
+
+    def set_hdr16(self, on):
+        """route ps_main's colour through binary16 like the reference's RGBA16F target (forward_pass.cpp:149)."""
+        assert self.L.oracle_set_hdr16(self.h, int(on)) == 0
         return self
 
     def close(self):
@@ -265,6 +273,10 @@ def calculate_shadow(shadow_map, ls):
 
 def to_unorm8(x):
     return lib().oracle_to_unorm8(float(x))
+
+
+def through_half(x):
+    return lib().oracle_through_half(float(x))
 
 
 def hardware_threads():

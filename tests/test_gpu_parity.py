@@ -252,3 +252,27 @@ def test_errors_and_state(pkg, hip):
     sc.desc.camera["aspect"] = 64 / 48
     assert r.render_frame(sc.desc, sc.settings).shape == (48, 64, 4)
     r.close()
+
+
+def test_reference_quantised_mode(pkg, oracle, hip):
+    """ps_main's colour rounded through binary16 like the reference's RGBA16F target.  The rounding is a
+    discontinuity, so an fp32-level difference may land on the neighbouring half value for a few pixels: the bar is
+    <= 1 LSB on RGBA8 with a mismatch-rate bound, and half an fp16 ulp on the float image."""
+    sc = pkg.scenes.config3(scale=0.15)
+    o, r = build_pair(pkg, oracle, hip, sc)
+    o.set_hdr16(1)
+    r.set_option("hdr16", 1)
+    ref = o.render_frame(sc.desc, sc.settings)
+    img = r.render_frame(sc.desc, sc.settings)
+    oldr, ohdr, _ = o.read_output()
+    hldr, hhdr, _ = r.read_output()
+    assert np.array_equal(ohdr, ohdr.astype(np.float16).astype(np.float32))     # the oracle's HDR image is on the fp16 grid
+    err = np.abs(hldr - oldr)
+    assert np.quantile(err, 0.999) <= TOL and err.max() <= 1e-3
+    d = np.abs(img.astype(np.int16) - ref.astype(np.int16))
+    assert d.max() <= 1 and (d != 0).mean() < 5e-3
+    # and it differs measurably from the fp32 pipeline (the mode is not a no-op)
+    r.set_option("hdr16", 0)
+    r.pass_shade(sc.desc, sc.settings)
+    assert np.abs(r.read_output()[0] - hldr).max() > 1e-5
+    r.close()

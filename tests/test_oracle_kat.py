@@ -221,3 +221,13 @@ def test_look_at_general(oracle, pkg):
     orth = np.diag([2 / 32, 2 / 32, -1 / 49.9, 1.0])
     orth[2, 3] = -0.1 / 49.9
     np.testing.assert_allclose(lpv.T, orth @ look(np.array([-10, 32, -2.48]), (-70.0, 12.0)), rtol=2e-5, atol=2e-5)
+
+
+def test_binary16_rounding_of_the_hdr_target(oracle):
+    """the reference's colour target is R16G16B16A16_FLOAT (forward_pass.cpp:149): round-to-nearest-even to binary16."""
+    rng = np.random.default_rng(4)
+    xs = np.concatenate([np.abs(rng.standard_normal(3000)).astype(np.float32) * s for s in (1e-8, 1e-5, 1e-3, 1.0, 100.0, 3e4)]
+                        + [np.array([0.0, 65504.0, 65519.9, 6e-8, 5.96e-8, 2.98e-8, 2.99e-8, 1.0009766, 1.00048828125], np.float32)])
+    got = np.array([oracle.through_half(float(x)) for x in xs], np.float32)
+    np.testing.assert_array_equal(got, xs.astype(np.float16).astype(np.float32))
+    assert np.isinf(oracle.through_half(65520.0))
