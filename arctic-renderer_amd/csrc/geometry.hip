@@ -127,8 +127,10 @@ __device__ bool setup_triangle(const CV &a, const CV &b, const CV &c, const Geom
     return t.px0 <= t.px1 && t.py0 <= t.py1;
 }
 
+// raster work items are 16x16-pixel blocks (one wave, a 2x2 pixel quad per lane): the per-item record search and record
+// fetch are latency, so fewer, fatter items
 __device__ __forceinline__ uint32_t tiles_of(const SetupRec &t) {
-    return (uint32_t)((t.px1 >> 3) - (t.px0 >> 3) + 1) * (uint32_t)((t.py1 >> 3) - (t.py0 >> 3) + 1);
+    return (uint32_t)((t.px1 >> 4) - (t.px0 >> 4) + 1) * (uint32_t)((t.py1 >> 4) - (t.py0 >> 4) + 1);
 }
 
 // edge i: vertex i -> vertex (i+1)%3, inside-positive; bias implements the top-left rule
@@ -320,27 +322,40 @@ __global__ __launch_bounds__(256) void k_raster(const SetupRec *__restrict__ rec
         r = __builtin_amdgcn_readfirstlane(r);
         const SetupRec &t = recs[r];
         uint32_t local = item - tile_offset[r];
-        int32_t tx0 = t.px0 >> 3, ty0 = t.py0 >> 3;
-        uint32_t ntx = (uint32_t)((t.px1 >> 3) - tx0 + 1);
-        int32_t tx = tx0 + (int32_t)(local % ntx), ty = ty0 + (int32_t)(local / ntx);
-        int32_t px = tx * 8 + (int32_t)(lane & 7), py = ty * 8 + (int32_t)(lane >> 3);
-        if (px < t.px0 || px > t.px1 || py < t.py0 || py > t.py1) continue;
+        int32_t bx0 = t.px0 >> 4, by0 = t.py0 >> 4;
+        uint32_t nbx = (uint32_t)((t.px1 >> 4) - bx0 + 1);
+        const int32_t qx = (bx0 + (int32_t)(local % nbx)) * 16 + (int32_t)(lane & 7) * 2;   // this lane's 2x2 quad
+        const int32_t qy = (by0 + (int32_t)(local / nbx)) * 16 + (int32_t)(lane >> 3) * 2;
+        if (qx > t.px1 || qx + 1 < t.px0 || qy > t.py1 || qy + 1 < t.py0) continue;
         Edges e;
         make_edges(t, e);
-        float inv_area = 1.0f / (float)t.area2;
-        float l1, l2, z;
-        if (!fragment(t, e, inv_area, px, py, l1, l2, z)) continue;
-        if (!(z < 1.0f)) continue;   // depth LESS against the 1.0 clear
-        if (DEPTH_ONLY) {
-            uint32_t *p = depth_bits + (size_t)py * gpp->pitch + px;
-            uint32_t zb = __float_as_uint(z);
-            if (zb < *p) atomicMin(p, zb);
-        } else {
-            const int ty_rel = ty - gpp->tile_y0;
-            if (!row_owned(ty_rel, gpp->band_tiles, gpp->shard_count, gpp->shard_index)) continue;   // another shard's band
-            size_t idx = ((size_t)row_local(ty_rel, gpp->band_tiles, gpp->shard_count) * gpp->tiles_x + tx) * 64 + lane;
-            unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | r;   // ties: first drawn (smallest id) wins
-            if (key < vis[idx]) atomicMin(&vis[idx], key);
+        const float inv_area = 1.0f / (float)t.area2;
+        // edge functions at the quad's first pixel; one pixel right adds -dy*256, one pixel down adds dx*256 (exact integers)
+        const int64_t e0 = edge_eval(e, 0, qx, qy), e1 = edge_eval(e, 1, qx, qy), e2 = edge_eval(e, 2, qx, qy);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int dx = k & 1, dy = k >> 1;
+            const int32_t px = qx + dx, py = qy + dy;
+            if (px < t.px0 || px > t.px1 || py < t.py0 || py > t.py1) continue;
+            const int64_t f0 = e0 + (dy ? e.dx[0] * 256 : 0) - (dx ? e.dy[0] * 256 : 0);
+            const int64_t f1 = e1 + (dy ? e.dx[1] * 256 : 0) - (dx ? e.dy[1] * 256 : 0);
+            const int64_t f2 = e2 + (dy ? e.dx[2] * 256 : 0) - (dx ? e.dy[2] * 256 : 0);
+            if ((f0 + e.bias[0]) < 0 || (f1 + e.bias[1]) < 0 || (f2 + e.bias[2]) < 0) continue;
+            const float l1 = (float)f2 * inv_area, l2 = (float)f0 * inv_area;
+            float z = fmaf(l2, t.z[2] - t.z[0], fmaf(l1, t.z[1] - t.z[0], t.z[0]));
+            z = fminf(fmaxf(z, 0.0f), 1.0f);
+            if (!(z < 1.0f)) continue;   // depth LESS against the 1.0 clear
+            if (DEPTH_ONLY) {
+                uint32_t *p = depth_bits + (size_t)py * gpp->pitch + px;
+                uint32_t zb = __float_as_uint(z);
+                if (zb < *p) atomicMin(p, zb);
+            } else {
+                const int ty_rel = (py >> 3) - gpp->tile_y0;
+                if (!row_owned(ty_rel, gpp->band_tiles, gpp->shard_count, gpp->shard_index)) continue;   // another shard's band
+                size_t idx = ((size_t)row_local(ty_rel, gpp->band_tiles, gpp->shard_count) * gpp->tiles_x + (px >> 3)) * 64 + (py & 7) * 8 + (px & 7);
+                unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | r;   // ties: first drawn (smallest id) wins
+                if (key < vis[idx]) atomicMin(&vis[idx], key);
+            }
         }
     }
 }
