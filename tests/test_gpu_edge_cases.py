@@ -1,0 +1,113 @@
+"""Edge cases through the C-ABI (GPU): empty and degenerate inputs, extreme sizes, ragged frames -- each still compared
+with the oracle under the same bars as tests/test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def tri_mesh(pkg, pts, uv=None, normal=(0, 0, 1)):
+    v = np.zeros(len(pts), pkg.scene.VERTEX_DTYPE)
+    v["position"] = pts
+    v["normal"], v["tangent"], v["bitangent"] = normal, (1, 0, 0), (0, 1, 0)
+    v["tex_coords"] = uv if uv is not None else np.asarray(pts, np.float32)[:, :2]
+    return v
+
+
+def camera_scene(pkg, objects, w, h, lights=None):
+    S = pkg.scene
+    return S.SceneDesc(camera=dict(eye=(0, 0, 4.0), rotation=(0.0, -90.0), aspect=w / h, fov_y=60.0, z_near_far=(0.1, 100.0)),
+                       ambient=0.1, sun=dict(position=(2, 10, 6), rotation=(-55.0, -110.0), color=(8, 8, 8)), objects=objects,
+                       point_lights=lights)
+
+
+def both(pkg, oracle, hip, w, h, shadow, mats, meshes, objs, lights, settings=(0, 2.2, 1.0)):
+    outs = []
+    for cls in (oracle.Oracle, hip.Renderer):
+        r = cls(w, h, shadow, 16)
+        for m in mats:
+            r.create_material(*m)
+        for v, i, mat in meshes:
+            r.create_mesh(v, i, mat)
+        r.update_lights(lights)
+        if cls is hip.Renderer:
+            r.set_option("keep_float_output", 1)
+        desc = camera_scene(pkg, pkg.scene.make_objects(objs), w, h, lights)
+        img = r.render_frame(desc, settings)
+        outs.append((img, r.read_output()[0], r.read_gbuffer(), r))
+    return outs
+
+
+def check(outs):
+    (oi, ol, og, o), (hi, hl, hg, r) = outs
+    for a, b in zip(og, hg):
+        np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert np.abs(ol - hl).max() <= TOL
+    assert np.abs(oi.astype(np.int16) - hi.astype(np.int16)).max() <= 1
+    r.close()
+    o.close()
+
+
+def test_empty_scene_is_black(pkg, oracle, hip):
+    outs = both(pkg, oracle, hip, 40, 24, 64, [pkg.scenes.fallback_textures()], [], [], np.zeros(0, pkg.scene.LIGHT_DTYPE))
+    assert (outs[1][0][..., :3] == 0).all() and (outs[1][0][..., 3] == 255).all()
+    check(outs)
+
+
+def test_ragged_frame_sizes(pkg, oracle, hip):
+    """width / height that are not multiples of the 8-pixel tile, down to a single pixel."""
+    rng = np.random.default_rng(8)
+    mats = [pkg.scenes.make_material_textures(rng, 32)]
+    quad = tri_mesh(pkg, [(-3, -2, 0), (3, -2, 0), (3, 2, 0), (-3, 2, 0)])
+    lights = pkg.scenes.random_lights(rng, 3, (-2, -2, 0.5), (2, 2, 3))
+    for w, h in ((1, 1), (7, 5), (9, 17), (33, 8), (130, 71)):
+        check(both(pkg, oracle, hip, w, h, 96, mats, [(quad, [0, 1, 2, 0, 2, 3], 0)], [(np.eye(4), 0)], lights))
+
+
+def test_degenerate_and_huge_triangles(pkg, oracle, hip):
+    rng = np.random.default_rng(9)
+    mats = [pkg.scenes.make_material_textures(rng, 16)]
+    pts = [(-1, -1, 0), (1, -1, 0), (0, 1, 0),                 # ordinary
+           (0.5, 0.5, 1), (0.5, 0.5, 1), (0.5, 0.5, 1),        # zero area: three equal vertices
+           (-2, 0, 1), (0, 0, 1), (2, 0, 1),                   # zero area: collinear
+           (-4000, -3000, -50), (4000, -3000, -50), (0, 5000, -50),   # far bigger than the guard band
+           (-0.001, -0.001, 2), (0.001, -0.001, 2), (0, 0.001, 2)]    # smaller than a pixel
+    idx = list(range(15))
+    lights = pkg.scenes.random_lights(rng, 2, (-2, -2, 0.5), (2, 2, 3))
+    check(both(pkg, oracle, hip, 96, 64, 128, mats, [(tri_mesh(pkg, pts), idx, 0)], [(np.eye(4), 0)], lights, settings=(2, 2.2, 1.0)))
+
+
+def test_one_texel_textures_and_wrapping_uv(pkg, oracle, hip):
+    """1x1 and 2x3 textures, texture coordinates far outside [0,1] and negative (WRAP)."""
+    rng = np.random.default_rng(10)
+    one = tuple(np.array([[c]], np.uint8) for c in ((200, 100, 50, 255), (140, 120, 250, 255), (255, 180, 255, 255)))
+    small = tuple(rng.integers(0, 256, (3, 2, 4), dtype=np.uint8) for _ in range(3))
+    uv = np.array([(-37.25, 12.5), (41.0, 12.5), (41.0, -19.75), (-37.25, -19.75)], np.float32)
+    quad = tri_mesh(pkg, [(-3, -2, 0), (3, -2, 0), (3, 2, 0), (-3, 2, 0)], uv=uv)
+    lights = pkg.scenes.random_lights(rng, 1, (-1, -1, 1), (1, 1, 2))
+    for mat in (one, small):
+        check(both(pkg, oracle, hip, 64, 48, 0, [mat], [(quad, [0, 1, 2, 0, 2, 3], 0)], [(np.eye(4), 0)], lights))
+
+
+def test_sixteen_lights_and_light_cap(pkg, oracle, hip):
+    """the reference's own maximum (16, renderer.hpp:22): more lights than the cap are dropped the same way on both sides."""
+    rng = np.random.default_rng(12)
+    mats = [pkg.scenes.make_material_textures(rng, 32)]
+    quad = tri_mesh(pkg, [(-3, -2, 0), (3, -2, 0), (3, 2, 0), (-3, 2, 0)])
+    lights = pkg.scenes.random_lights(rng, 23, (-3, -2, 0.2), (3, 2, 3))       # 23 > 16: clamped (renderer.cpp:587-588)
+    check(both(pkg, oracle, hip, 80, 56, 128, mats, [(quad, [0, 1, 2, 0, 2, 3], 0)], [(np.eye(4), 0)], lights, settings=(1, 1.8, 0.6)))
+
+
+def test_object_transforms_and_shared_meshes(pkg, oracle, hip):
+    """several objects instancing one mesh with different TRS matrices (Object{trs, mesh_idx}, scene.hpp:69-73), one of
+    them pointing at a mesh index that does not exist (skipped on both sides)."""
+    rng = np.random.default_rng(13)
+    S = pkg.scene
+    mats = [pkg.scenes.make_material_textures(rng, 32), pkg.scenes.fallback_textures()]
+    sphere = pkg.scenes.uv_sphere(0.6, 24, 12)
+    box = pkg.scenes.box(0.8, 0.8, 0.8, 2)
+    objs = [(S.translation(-1.5, 0, 0) @ S.rotation_y(30), 0), (S.translation(1.5, 0.3, -1) @ S.scaling(1.5, 0.5, 1.0), 0),
+            (S.translation(0, -0.8, 0.5) @ S.rotation_y(-50), 1), (np.eye(4), 7)]
+    lights = pkg.scenes.random_lights(rng, 5, (-3, -2, 0.5), (3, 2, 3))
+    check(both(pkg, oracle, hip, 128, 96, 256, mats, [sphere + (0,), box + (1,)], objs, lights, settings=(2, 2.2, 1.0)))
