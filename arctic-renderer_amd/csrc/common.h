@@ -138,6 +138,7 @@ struct ShadeLaunch {
     hipStream_t main, aux;
     hipEvent_t band_done[MAX_BANDS], aux_done;
     uint32_t n_bands, light_blocks;
+    uint32_t lights_per_trip;   // k_light variant: 4 (two packed pairs per loop trip, 121 VGPRs) or 2 (one pair, 96 VGPRs)
     hipEvent_t mid;   // optional: recorded between k_material and k_light (single band), for per-kernel timing
 };
 constexpr uint32_t LIT_SHARDS = 256, LIT_COUNTER_STRIDE = 32;

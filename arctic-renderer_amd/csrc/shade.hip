@@ -218,7 +218,7 @@ struct Pix {
     float a2, oma2;       // roughness^4, 1 - roughness^4                                        (:133-139)
     float k, omk;         // k = (roughness + 1)^2 / 8, 1 - k                                    (:147-148)
     float num;            // a2 * g(n.wo) / PI: the light-independent factor of NDF * G          (:131-163)
-    float four_ndwo;      // 4 * max(n.wo, 0)                                                    (:172)
+    float q2, q1, q0;     // (x (1 - k) + k) (4 n.wo x + 1e-4) = q2 x^2 + q1 x + q0, x = n.wi: G's and the BRDF's denominators (:153,:172)
 };
 
 __device__ __forceinline__ Pix make_pix(f3 n, f3 wo, f3 world, f3 base, float metal, float rough) {
@@ -235,7 +235,8 @@ __device__ __forceinline__ Pix make_pix(f3 n, f3 wo, f3 world, f3 base, float me
     p.k = r1 * r1 * 0.125f;
     p.omk = 1.0f - p.k;
     p.num = a2 * INV_PI * ndwo * rcp(ndwo * p.omk + p.k);
-    p.four_ndwo = 4.0f * ndwo;
+    const float four_ndwo = 4.0f * ndwo;
+    p.q2 = p.omk * four_ndwo; p.q1 = p.k * four_ndwo + 0.0001f * p.omk; p.q0 = 0.0001f * p.k;
     return p;
 }
 
@@ -255,7 +256,7 @@ __device__ __forceinline__ void accumulate_light(const Pix &p, f3 d, float nd, f
     const f3 h = mk(__builtin_fmaf(d.x, inv, p.wo.x), __builtin_fmaf(d.y, inv, p.wo.y), __builtin_fmaf(d.z, inv, p.wo.z));
     const float hh = dot(h, h), rh = rsq(hh);          // |h|^2, 1 / |h|
     // (h . wo) / |h| = |h| / 2 for unit wo, wi:  clamp(1 - max(h.wo, 0), 0, 1)  (:128, :183)
-    const float m = sat(__builtin_fmaf(hh * rh, -0.5f, 1.0f));
+    const float m = __builtin_fmaf(hh * rh, -0.5f, 1.0f);   // in [0,1] by construction (|h| <= 2): the HLSL clamp only catches rounding
     const float m2 = m * m, p5 = m2 * m2 * m;
     // distribution_ggx's denominator n_dot_h^2 * (a2 - 1) + 1 (:137) cancels to ~a2 at a highlight; written as
     // sin^2 * (1 - a2) + a2 it has no cancellation (same value in exact arithmetic).  sin^2 from e = n - h/|h|:
@@ -263,8 +264,9 @@ __device__ __forceinline__ void accumulate_light(const Pix &p, f3 d, float nd, f
     const f3 e = mk(__builtin_fmaf(h.x, -rh, p.n.x), __builtin_fmaf(h.y, -rh, p.n.y), __builtin_fmaf(h.z, -rh, p.n.z));   // n - h/|h|
     const float e2 = dot(e, e);
     const float sin2 = e2 * __builtin_fmaf(e2, -0.25f, 1.0f);
-    const float dd = e2 < 2.0f ? __builtin_fmaf(sin2, p.oma2, p.a2) : 1.0f;   // n . h <= 0: max(n.h, 0) = 0, denominator 1
-    const float den = (dd * dd) * __builtin_fmaf(ndwi, p.omk, p.k) * __builtin_fmaf(ndwi, p.four_ndwo, 0.0001f);
+    // (when n.h <= 0 the HLSL's max(n.h, 0) makes this 1, but then n.wo <= 0 or n.wi <= 0 and the term is multiplied by 0 anyway)
+    const float dd = __builtin_fmaf(sin2, p.oma2, p.a2);
+    const float den = (dd * dd) * __builtin_fmaf(__builtin_fmaf(p.q2, ndwi, p.q1), ndwi, p.q0);
     const float spec = (p.num * ndwi) * rcp(den);      // NDF * G / (4 n.wo n.wi + 1e-4)
     sc *= ndwi;
     const f3 F = mk(__builtin_fmaf(p.omF0.x, p5, p.F0.x), __builtin_fmaf(p.omF0.y, p5, p.F0.y), __builtin_fmaf(p.omF0.z, p5, p.F0.z));
@@ -287,7 +289,7 @@ __device__ __forceinline__ void accumulate_pair(const Pix &p, v2 dx, v2 dy, v2 d
     const v2 ndwi = max02(nd * inv);
     const v2 hx = fma2(dx, inv, splat(p.wo.x)), hy = fma2(dy, inv, splat(p.wo.y)), hz = fma2(dz, inv, splat(p.wo.z));
     const v2 hh = fma2(hz, hz, fma2(hy, hy, hx * hx)), rh = rsq2(hh);
-    const v2 m = sat2(fma2(hh * rh, splat(-0.5f), splat(1.0f)));
+    const v2 m = fma2(hh * rh, splat(-0.5f), splat(1.0f));
     const v2 m2 = m * m, p5 = m2 * m2 * m;
     // sin^2 of the angle between the unit vectors n and h/|h| from their difference e: |e|^2 = 2 - 2 cos, so
     // sin^2 = |e|^2 (1 - |e|^2 / 4) and n.h > 0 <=> |e|^2 < 2.  No cancellation near the highlight (e is small there
@@ -295,9 +297,8 @@ __device__ __forceinline__ void accumulate_pair(const Pix &p, v2 dx, v2 dy, v2 d
     const v2 ex = fma2(hx, -rh, splat(p.n.x)), ey = fma2(hy, -rh, splat(p.n.y)), ez = fma2(hz, -rh, splat(p.n.z));
     const v2 e2 = fma2(ez, ez, fma2(ey, ey, ex * ex));
     const v2 sin2 = e2 * fma2(e2, splat(-0.25f), splat(1.0f));
-    v2 dd = fma2(sin2, splat(p.oma2), splat(p.a2));
-    dd.x = e2.x < 2.0f ? dd.x : 1.0f; dd.y = e2.y < 2.0f ? dd.y : 1.0f;   // n . h <= 0: max(n.h, 0) = 0, denominator 1
-    const v2 den = (dd * dd) * fma2(ndwi, splat(p.omk), splat(p.k)) * fma2(ndwi, splat(p.four_ndwo), splat(0.0001f));
+    const v2 dd = fma2(sin2, splat(p.oma2), splat(p.a2));
+    const v2 den = (dd * dd) * fma2(fma2(splat(p.q2), ndwi, splat(p.q1)), ndwi, splat(p.q0));
     const v2 spec = (splat(p.num) * ndwi) * rcp2(den);
     const v2 sc = inv * inv * ndwi;
     const v2 Fx = fma2(splat(p.omF0.x), p5, splat(p.F0.x)), Fy = fma2(splat(p.omF0.y), p5, splat(p.F0.y)), Fz = fma2(splat(p.omF0.z), p5, splat(p.F0.z));
@@ -455,6 +456,7 @@ __global__ __launch_bounds__(256) void k_material(const ShadeParams sp) {
 // the same address, so a pair costs three broadcast ds_read_b128.  The count is padded to a multiple of 4 with black lights.
 // Persistent: gridDim.x workgroups; wave w works on shard w % LIT_SHARDS of the stream and takes every
 // (n_waves / LIT_SHARDS)-th 64-pixel group of it.
+template <int LIGHTS_PER_TRIP>
 __global__ __launch_bounds__(256) void k_light(const ShadeParams sp) {
     extern __shared__ __align__(16) float smem[];
     float4 *llights = reinterpret_cast<float4 *>(smem);
@@ -491,6 +493,7 @@ __global__ __launch_bounds__(256) void k_light(const ShadeParams sp) {
         const v2 wx = splat(world.x), wy = splat(world.y), wz = splat(world.z);
         // two pairs (four lights) per trip: the two evaluations are independent, which gives the scheduler instructions to
         // put between dependent packed operations (n_quads = ceil(n_pairs / 2); the LDS image is padded with black lights)
+        if (LIGHTS_PER_TRIP == 4)
         for (uint32_t q = 0; q < n_quads; ++q) {
             const float4 A0 = llights[6 * q], B0 = llights[6 * q + 1], C0 = llights[6 * q + 2];
             const float4 A1 = llights[6 * q + 3], B1 = llights[6 * q + 4], C1 = llights[6 * q + 5];
@@ -506,6 +509,19 @@ __global__ __launch_bounds__(256) void k_light(const ShadeParams sp) {
             if (sp.light_evals) {
                 const unsigned long long active = __ballot(1);
                 const uint32_t k = min(4u, sp.n_lights - 4 * q);
+                if (lane == (uint32_t)__ffsll((long long)active) - 1) atomicAdd(sp.light_evals, (unsigned long long)__popcll(active) * k);
+            }
+        }
+        if (LIGHTS_PER_TRIP == 2)
+        for (uint32_t p = 0; p < n_pairs; ++p) {
+            const float4 A = llights[3 * p], Bq = llights[3 * p + 1], C = llights[3 * p + 2];
+            const v2 dx = (v2){A.x, A.y} - wx, dy = (v2){A.z, A.w} - wy, dz = (v2){Bq.x, Bq.y} - wz;
+            const v2 nd = fma2(splat(n.z), dz, fma2(splat(n.y), dy, splat(n.x) * dx));
+            if (sp.culling && __ballot(nd.x > 0.0f || nd.y > 0.0f) == 0ull) continue;
+            accumulate_pair(px, dx, dy, dz, nd, (v2){Bq.z, Bq.w}, (v2){C.x, C.y}, (v2){C.z, C.w}, ar, ag, ab);
+            if (sp.light_evals) {
+                const unsigned long long active = __ballot(1);
+                const uint32_t k = min(2u, sp.n_lights > 2 * p ? sp.n_lights - 2 * p : 0u);
                 if (lane == (uint32_t)__ffsll((long long)active) - 1) atomicAdd(sp.light_evals, (unsigned long long)__popcll(active) * k);
             }
         }
@@ -555,7 +571,8 @@ hipError_t launch_shade(const ShadeParams &sp0, const ShadeLaunch &L) {
             if ((e = hipStreamWaitEvent(L.aux, L.band_done[k], 0)) != hipSuccess) return e;
             ls = L.aux;
         }
-        k_light<<<std::max(1u, std::min(L.light_blocks, groups * 8 * bpr)), 256, lds_b, ls>>>(sp);
+        if (L.lights_per_trip == 2) k_light<2><<<std::max(1u, std::min(L.light_blocks, groups * 8 * bpr)), 256, lds_b, ls>>>(sp);
+        else k_light<4><<<std::max(1u, std::min(L.light_blocks, groups * 8 * bpr)), 256, lds_b, ls>>>(sp);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if (n_bands > 1) {   // rejoin: later work on the main stream sees the finished frame
