@@ -89,12 +89,12 @@ __host__ __device__ inline int row_local(int ty_rel, int band_tiles, int n) { re
 __host__ __device__ inline int row_global(int lt, int band_tiles, int n, int r) { return band_tiles == 0 ? lt : ((lt / band_tiles) * n + r) * band_tiles + lt % band_tiles; }
 
 // texture descriptor, 16 B; three consecutive per material: diffuse (sRGB), normal, metal-rough
-// When a material's three images have equal size they are stored INTERLEAVED, texel by texel {diffuse, normal,
-// metal-rough} (12 B), so one bilinear footprint = four 12-byte loads instead of twelve 4-byte ones; bit 31 of w marks
-// it, and descriptor k then points at dword k of the first texel.
+// When a material's three images have equal size they are stored PACKED: one image of 8-byte texels holding exactly the
+// eight channels ps_main reads (diffuse rgb, normal rgb, metal-rough gb; layout in shade.hip), so one bilinear footprint =
+// four aligned 8-byte loads instead of twelve 4-byte ones.  Bit 31 of w marks it; descriptors 1 and 2 are then unused.
 struct TexDesc {
-    const uint32_t *texels;  // RGBA8 little endian (r = low byte), row-major; tightly packed, or every 3rd dword
-    uint32_t w, h;           // w bit 31: interleaved
+    const uint32_t *texels;  // RGBA8 little endian (r = low byte), row-major, tightly packed -- or the packed image
+    uint32_t w, h;           // w bit 31: packed
 };
 constexpr uint32_t TEX_INTERLEAVED = 0x80000000u;
 

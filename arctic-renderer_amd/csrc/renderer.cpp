@@ -497,22 +497,19 @@ int arctic_create_material(ArcticRenderer *r, const void *diffuse, uint32_t dw, 
     const uint32_t w[3] = {dw, nw, mw}, h[3] = {dh, nh, mh};
     TexDesc td[3];
     if (dw == nw && dw == mw && dh == nh && dh == mh) {
-        // equal sizes (the usual glTF case): interleave {diffuse, normal, metal-rough} per texel
+        // equal sizes (the usual glTF case): pack the eight channels ps_main reads into 8-byte texels (layout: shade.hip)
         size_t n = (size_t)dw * dh;
-        std::vector<uint32_t> packed(n * 3);
-        const uint32_t *a = static_cast<const uint32_t *>(diffuse), *b = static_cast<const uint32_t *>(normal), *c = static_cast<const uint32_t *>(mr);
+        std::vector<uint32_t> packed(n * 2);
+        const uint8_t *a = static_cast<const uint8_t *>(diffuse), *b = static_cast<const uint8_t *>(normal), *c = static_cast<const uint8_t *>(mr);
         for (size_t i = 0; i < n; ++i) {
-            uint32_t t[3];
-            std::memcpy(&t[0], reinterpret_cast<const char *>(a) + 4 * i, 4);   // caller buffers need not be 4-byte aligned
-            std::memcpy(&t[1], reinterpret_cast<const char *>(b) + 4 * i, 4);
-            std::memcpy(&t[2], reinterpret_cast<const char *>(c) + 4 * i, 4);
-            packed[3 * i] = t[0]; packed[3 * i + 1] = t[1]; packed[3 * i + 2] = t[2];
+            packed[2 * i] = (uint32_t)a[4 * i] | ((uint32_t)a[4 * i + 1] << 8) | ((uint32_t)a[4 * i + 2] << 16) | ((uint32_t)b[4 * i] << 24);
+            packed[2 * i + 1] = (uint32_t)b[4 * i + 1] | ((uint32_t)b[4 * i + 2] << 8) | ((uint32_t)c[4 * i + 1] << 16) | ((uint32_t)c[4 * i + 2] << 24);
         }
         void *p = nullptr;
-        HIPCHECK(r, hipMalloc(&p, n * 12));
+        HIPCHECK(r, hipMalloc(&p, n * 8));
         r->tex_allocs.push_back(p);
-        HIPCHECK(r, hipMemcpy(p, packed.data(), n * 12, hipMemcpyHostToDevice));   // synchronous like rhi.cpp:480-519
-        for (int i = 0; i < 3; ++i) { td[i].texels = static_cast<const uint32_t *>(p) + i; td[i].w = dw | TEX_INTERLEAVED; td[i].h = dh; }
+        HIPCHECK(r, hipMemcpy(p, packed.data(), n * 8, hipMemcpyHostToDevice));   // synchronous like rhi.cpp:480-519
+        for (int i = 0; i < 3; ++i) { td[i].texels = static_cast<const uint32_t *>(p); td[i].w = dw | TEX_INTERLEAVED; td[i].h = dh; }
     } else {
         for (int i = 0; i < 3; ++i) {
             void *p = nullptr;

@@ -63,38 +63,40 @@ __device__ __forceinline__ void wrap_axis(float u, uint32_t n, int &i0, int &i1,
 
 struct Taps { uint32_t t00, t10, t01, t11; float w00, w10, w01, w11; };
 
-// one texture of a material: `stride` dwords between horizontally adjacent texels (1 = plain RGBA8 image, 3 = the
-// material's three equally sized images interleaved texel by texel: {diffuse, normal, metal-rough})
-struct TexRef { const uint32_t *texels; uint32_t w, h, stride; };
+// one texture of a material.  packed = 0: plain RGBA8 image.  packed = 1: the material's three equally sized images
+// are stored as ONE image of 8-byte texels holding exactly the eight channels ps_main reads (forward.hlsl:98-124):
+//   word 0 = diffuse.r | diffuse.g << 8 | diffuse.b << 16 | normal.r << 24
+//   word 1 = normal.g | normal.b << 8 | metal_rough.g << 16 | metal_rough.b << 24
+struct TexRef { const uint32_t *texels; uint32_t w, h, packed; };
 
 __device__ __forceinline__ Taps fetch_taps(const TexRef &d, float u, float v) {
     int x0, x1, y0, y1;
     float fx, fy;
     wrap_axis(u, d.w, x0, x1, fx);
     wrap_axis(v, d.h, y0, y1, fy);
-    const uint32_t *r0 = d.texels + (size_t)y0 * d.w * d.stride, *r1 = d.texels + (size_t)y1 * d.w * d.stride;
+    const uint32_t *r0 = d.texels + (size_t)y0 * d.w, *r1 = d.texels + (size_t)y1 * d.w;
     Taps t;
-    t.t00 = r0[x0 * d.stride]; t.t10 = r0[x1 * d.stride]; t.t01 = r1[x0 * d.stride]; t.t11 = r1[x1 * d.stride];
+    t.t00 = r0[x0]; t.t10 = r0[x1]; t.t01 = r1[x0]; t.t11 = r1[x1];
     float gx = 1.0f - fx, gy = 1.0f - fy;
     t.w00 = gx * gy; t.w10 = fx * gy; t.w01 = gx * fy; t.w11 = fx * fy;
     return t;
 }
 
-// interleaved material: ONE footprint, four 12-byte loads fetch all three textures' taps
-typedef uint32_t uint3u __attribute__((ext_vector_type(3), aligned(4)));
+// packed material: ONE footprint, four 8-byte loads fetch all three textures' taps; the words are re-cut so that each
+// Taps again carries its channels at the byte positions of the plain RGBA8 texel (r = byte 0, g = byte 1, b = byte 2)
 __device__ __forceinline__ void fetch_taps3(const TexRef &d, float u, float v, Taps &a, Taps &b, Taps &c) {
     int x0, x1, y0, y1;
     float fx, fy;
     wrap_axis(u, d.w, x0, x1, fx);
     wrap_axis(v, d.h, y0, y1, fy);
-    const uint32_t *r0 = d.texels + (size_t)y0 * d.w * 3, *r1 = d.texels + (size_t)y1 * d.w * 3;
-    const uint3u q00 = *reinterpret_cast<const uint3u *>(r0 + x0 * 3), q10 = *reinterpret_cast<const uint3u *>(r0 + x1 * 3);
-    const uint3u q01 = *reinterpret_cast<const uint3u *>(r1 + x0 * 3), q11 = *reinterpret_cast<const uint3u *>(r1 + x1 * 3);
+    const uint2 *r0 = reinterpret_cast<const uint2 *>(d.texels) + (size_t)y0 * d.w, *r1 = reinterpret_cast<const uint2 *>(d.texels) + (size_t)y1 * d.w;
+    const uint2 q00 = r0[x0], q10 = r0[x1], q01 = r1[x0], q11 = r1[x1];
     float gx = 1.0f - fx, gy = 1.0f - fy;
     a.w00 = b.w00 = c.w00 = gx * gy; a.w10 = b.w10 = c.w10 = fx * gy; a.w01 = b.w01 = c.w01 = gx * fy; a.w11 = b.w11 = c.w11 = fx * fy;
-    a.t00 = q00.x; a.t10 = q10.x; a.t01 = q01.x; a.t11 = q11.x;
-    b.t00 = q00.y; b.t10 = q10.y; b.t01 = q01.y; b.t11 = q11.y;
-    c.t00 = q00.z; c.t10 = q10.z; c.t01 = q01.z; c.t11 = q11.z;
+    a.t00 = q00.x; a.t10 = q10.x; a.t01 = q01.x; a.t11 = q11.x;                                   // diffuse r,g,b in bytes 0..2
+    b.t00 = __builtin_amdgcn_alignbit(q00.y, q00.x, 24); b.t10 = __builtin_amdgcn_alignbit(q10.y, q10.x, 24);   // normal r,g,b
+    b.t01 = __builtin_amdgcn_alignbit(q01.y, q01.x, 24); b.t11 = __builtin_amdgcn_alignbit(q11.y, q11.x, 24);
+    c.t00 = q00.y >> 8; c.t10 = q10.y >> 8; c.t01 = q01.y >> 8; c.t11 = q11.y >> 8;             // metal-rough g, b in bytes 1, 2
 }
 __device__ __forceinline__ float ch(uint32_t t, int c) { return (float)((t >> (8 * c)) & 0xFFu); }
 __device__ __forceinline__ float filt_unorm(const Taps &t, int c) {
@@ -359,7 +361,7 @@ __device__ __forceinline__ TexRef lds_desc(const uint4 *d) {
     TexRef t;
     t.texels = reinterpret_cast<const uint32_t *>(((unsigned long long)v.y << 32) | v.x);
     t.w = v.z & 0x7FFFFFFFu; t.h = v.w;
-    t.stride = (v.z >> 31) ? 3u : 1u;   // TexDesc::w bit 31: interleaved material
+    t.packed = v.z >> 31;   // TexDesc::w bit 31
     return t;
 }
 
@@ -415,7 +417,7 @@ __global__ __launch_bounds__(256) void k_material(const ShadeParams sp) {
         const float u = cur.a.x, v = cur.a.y;
         if (!(sp.debug & 2)) lit = 1.0f - calculate_shadow(sp.shadow_map, sp.shadow_size, make_float4(cur.a.z, cur.a.w, cur.b0, cur.b1));
         const TexRef d0 = lds_desc(ldesc + mat * 3);
-        if (__ballot(d0.stride != 3u) == 0ull) fetch_taps3(d0, u, v, t0, t1, t2);   // the usual case: whole wave on interleaved materials
+        if (d0.packed) fetch_taps3(d0, u, v, t0, t1, t2);   // the usual case (equal-size images); waves mixing both kinds diverge
         else { t0 = fetch_taps(d0, u, v); t1 = fetch_taps(lds_desc(ldesc + mat * 3 + 1), u, v); t2 = fetch_taps(lds_desc(ldesc + mat * 3 + 2), u, v); }
     }
     // exact culling 1: Lo of ps_main is a sum of terms each multiplied by (1 - shadow) (point lights too: forward.hlsl:222,
