@@ -127,7 +127,8 @@ struct ShadeParams {
     // lit-pixel stream written by k_material, read by k_light (capacity = pixels of the shard)
     float4 *lit_r0, *lit_r1, *lit_r2;   // (world.xyz, 1-shadow) (n.xyz, roughness) (base.xyz, metalness)
     uint32_t *lit_px;                   // pixel index y*width + x inside the shard
-    uint32_t *lit_count;                // LIT_SHARDS counters, LIT_COUNTER_STRIDE apart
+    uint32_t *lit_count;                // LIT_SHARDS counters per band, LIT_COUNTER_STRIDE apart: this pass's set ...
+    uint32_t *lit_count_next;           // ... and the other set, which k_light clears for the next pass
     int32_t hdr16;                      // 1: round ps_main's colour through binary16 like the reference's RGBA16F target
     int32_t debug;                      // timing experiments only: 1 skip material textures, 2 skip shadow test
     uint32_t lit_shard_cap;             // records per shard of one band: ceil(band workgroups / LIT_SHARDS) * 256, cannot overflow

@@ -82,6 +82,7 @@ struct ArcticRenderer {
     int keep_float = 0, count_evals = 0, culling = 1, debug = 0, hdr16 = 0;
     ShadeLaunch launch{};           // streams, events, band count and k_light's persistent grid
     uint32_t raster_blocks = 2048;  // persistent grid of k_raster
+    int lit_parity = 0;             // which of the two stream-counter sets the next pass uses
     uint32_t cu_count = 256;
     uint32_t *h_counts = nullptr;   // pinned: [0] records, [1] work items (forward), [2], [3] the same for the shadow pass
     std::string err;
@@ -148,7 +149,9 @@ int alloc_targets(ArcticRenderer *r) {
         HIPCHECK(r, r->d_lit1.ensure(cap * 16));
         HIPCHECK(r, r->d_lit2.ensure(cap * 16));
         HIPCHECK(r, r->d_litpx.ensure(cap * 4));
-        HIPCHECK(r, r->d_litcount.ensure((size_t)MAX_BANDS * LIT_SHARDS * LIT_COUNTER_STRIDE * 4));
+        HIPCHECK(r, r->d_litcount.ensure((size_t)2 * MAX_BANDS * LIT_SHARDS * LIT_COUNTER_STRIDE * 4));
+        HIPCHECK(r, hipMemsetAsync(r->d_litcount.p, 0, (size_t)2 * MAX_BANDS * LIT_SHARDS * LIT_COUNTER_STRIDE * 4, r->stream));
+        r->lit_parity = 0;
     }
     r->have_gbuffer = r->have_output = false;
     return ARCTIC_OK;
@@ -330,7 +333,7 @@ int fill_shade_params(ArcticRenderer *r, const ArcticScene *sc, const ArcticSett
     sp.debug = r->debug;
     sp.hdr16 = r->hdr16;
     sp.lit_r0 = r->d_lit0.as<float4>(); sp.lit_r1 = r->d_lit1.as<float4>(); sp.lit_r2 = r->d_lit2.as<float4>();
-    sp.lit_px = r->d_litpx.as<uint32_t>(); sp.lit_count = r->d_litcount.as<uint32_t>();
+    sp.lit_px = r->d_litpx.as<uint32_t>(); sp.lit_count = sp.lit_count_next = nullptr;   // set per pass by shade_once
     sp.lit_shard_cap = r->lit_shard_cap();
     {
         size_t cap = (size_t)sp.lit_shard_cap * LIT_SHARDS * r->launch.n_bands;
@@ -340,12 +343,21 @@ int fill_shade_params(ArcticRenderer *r, const ArcticScene *sc, const ArcticSett
     return ARCTIC_OK;
 }
 
+// one shading pass; alternates the two stream-counter sets (k_light clears the set the NEXT pass will fill)
+hipError_t shade_once(ArcticRenderer *r, ShadeParams &sp, const ShadeLaunch &L) {
+    const size_t set = (size_t)MAX_BANDS * LIT_SHARDS * LIT_COUNTER_STRIDE;
+    sp.lit_count = r->d_litcount.as<uint32_t>() + (r->lit_parity ? set : 0);
+    sp.lit_count_next = r->d_litcount.as<uint32_t>() + (r->lit_parity ? 0 : set);
+    r->lit_parity ^= 1;
+    return launch_shade(sp, L);
+}
+
 int pass_shade(ArcticRenderer *r, const ArcticScene *sc, const ArcticSettings *st, void *d_out) {
     ShadeParams sp;
     int rc = fill_shade_params(r, sc, st, d_out, sp);
     if (rc != ARCTIC_OK) return rc;
     if (sp.light_evals) HIPCHECK(r, hipMemsetAsync(r->d_counter.p, 0, 8, r->stream));
-    HIPCHECK(r, launch_shade(sp, r->launch));
+    HIPCHECK(r, shade_once(r, sp, r->launch));
     if (sp.light_evals) {
         unsigned long long n = 0;
         std::vector<uint32_t> counts((size_t)r->launch.n_bands * LIT_SHARDS * LIT_COUNTER_STRIDE);
@@ -640,14 +652,14 @@ int arctic_time_shade_split(ArcticRenderer *r, const ArcticScene *scene, const A
     ShadeParams sp;
     if ((rc = fill_shade_params(r, scene, settings, nullptr, sp)) != ARCTIC_OK) return rc;
     sp.light_evals = nullptr;
-    for (uint32_t i = 0; i < warmup; ++i) HIPCHECK(r, launch_shade(sp, r->launch));
+    for (uint32_t i = 0; i < warmup; ++i) HIPCHECK(r, shade_once(r, sp, r->launch));
     std::vector<hipEvent_t> ev(3 * (size_t)iters);
     for (auto &e : ev) HIPCHECK(r, hipEventCreate(&e));
     for (uint32_t i = 0; i < iters; ++i) {
         ShadeLaunch L = r->launch;
         L.mid = split ? ev[3 * i + 1] : nullptr;
         HIPCHECK(r, hipEventRecord(ev[3 * i], r->stream));
-        HIPCHECK(r, launch_shade(sp, L));
+        HIPCHECK(r, shade_once(r, sp, L));
         HIPCHECK(r, hipEventRecord(ev[3 * i + 2], r->stream));
     }
     HIPCHECK(r, hipStreamSynchronize(r->stream));

@@ -472,6 +472,10 @@ __global__ __launch_bounds__(256) void k_light(const ShadeParams sp) {
         dst[0] = lp.x; dst[2] = lp.y; dst[4] = lp.z; dst[6] = lc.x; dst[8] = lc.y; dst[10] = lc.z;
     }
     __syncthreads();
+    // the stream counters are double-buffered: this pass reads the set k_material has just filled and clears the other
+    // one for the next pass's k_material -- no memset launch between passes
+    if (blockIdx.x == 0)
+        for (uint32_t i = threadIdx.x; i < sp.n_bands * LIT_SHARDS; i += 256) sp.lit_count_next[i * LIT_COUNTER_STRIDE] = 0;
     const f3 eye = mk(sp.eye[0], sp.eye[1], sp.eye[2]);
     const uint32_t w = blockIdx.x * 4 + wave, n_waves = gridDim.x * 4;
     const bool wide = n_waves >= LIT_SHARDS;
@@ -557,8 +561,7 @@ hipError_t launch_shade(const ShadeParams &sp0, const ShadeLaunch &L) {
     const uint32_t bpr = (sp.tiles_x + 3) / 4, row_groups = (sp.tiles_y + 7) / 8;
     const uint32_t n_bands = std::max(1u, std::min(L.n_bands, row_groups));
     sp.n_bands = n_bands;
-    hipError_t e = hipMemsetAsync(sp.lit_count, 0, (size_t)n_bands * LIT_SHARDS * LIT_COUNTER_STRIDE * sizeof(uint32_t), L.main);
-    if (e != hipSuccess) return e;
+    hipError_t e = hipSuccess;
     const size_t lds_a = (256 + (size_t)sp.n_materials * 12) * sizeof(float);
     const size_t lds_b = std::max<size_t>(96, (size_t)((sp.n_lights + 3) / 4) * 96);
     for (uint32_t k = 0; k < n_bands; ++k) {
