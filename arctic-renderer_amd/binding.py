@@ -28,6 +28,7 @@ SIGNATURES = {
     "arctic_resize": (_i32, [_vp, _u32, _u32]),
     "arctic_flush": (_i32, [_vp]),
     "arctic_set_stream": (_i32, [_vp, _vp]),
+    "arctic_use_own_stream": (_i32, [_vp]),
     "arctic_create_material": (_i32, [_vp, _vp, _u32, _u32, _vp, _u32, _u32, _vp, _u32, _u32]),
     "arctic_create_mesh": (_i32, [_vp, _vp, _u64, _vp, _u64, _u64]),
     "arctic_update_lights": (_i32, [_vp, _vp, _u64]),

@@ -454,7 +454,7 @@ void arctic_destroy(ArcticRenderer *r) {
     if (r->launch.aux) { (void)hipStreamSynchronize(r->launch.aux); (void)hipStreamDestroy(r->launch.aux); }
     for (uint32_t k = 0; k < MAX_BANDS; ++k) if (r->launch.band_done[k]) (void)hipEventDestroy(r->launch.band_done[k]);
     if (r->launch.aux_done) (void)hipEventDestroy(r->launch.aux_done);
-    if (r->stream) (void)hipStreamSynchronize(r->stream);
+    (void)hipStreamSynchronize(r->stream);
     if (r->own_stream) { (void)hipStreamSynchronize(r->own_stream); (void)hipStreamDestroy(r->own_stream); }
     for (Mesh &m : r->meshes) { if (m.d_vertices) (void)hipFree(m.d_vertices); if (m.d_indices) (void)hipFree(m.d_indices); }
     for (void *p : r->tex_allocs) (void)hipFree(p);
@@ -492,7 +492,17 @@ int arctic_set_stream(ArcticRenderer *r, void *hip_stream) {
     int rc = select_device(r);
     if (rc) return rc;
     HIPCHECK(r, hipStreamSynchronize(r->stream));
-    r->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : r->own_stream;
+    r->stream = static_cast<hipStream_t>(hip_stream);   // NULL = the default stream
+    r->launch.main = r->stream;
+    return ARCTIC_OK;
+}
+
+int arctic_use_own_stream(ArcticRenderer *r) {
+    if (!r) return ARCTIC_E_INVALID;
+    int rc = select_device(r);
+    if (rc) return rc;
+    HIPCHECK(r, hipStreamSynchronize(r->stream));
+    r->stream = r->own_stream;
     r->launch.main = r->stream;
     return ARCTIC_OK;
 }
@@ -768,7 +778,7 @@ int arctic_frame_constants(const ArcticScene *scene, float *proj_view, float *li
 
 int arctic_stats(ArcticRenderer *r, uint64_t *out, uint32_t n) {
     if (!r || !out) return ARCTIC_E_INVALID;
-    if (select_device(r) == ARCTIC_OK && r->stream) (void)hipStreamSynchronize(r->stream);
+    if (select_device(r) == ARCTIC_OK) (void)hipStreamSynchronize(r->stream);
     if (r->h_counts) for (int i = 0; i < 4; ++i) r->stats[i] = r->h_counts[i];
     for (uint32_t i = 0; i < n && i < 8; ++i) out[i] = r->stats[i];
     return ARCTIC_OK;

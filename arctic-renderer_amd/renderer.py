@@ -82,8 +82,12 @@ class Renderer:
         self._check(self.L.arctic_flush(self.h))
 
     def set_stream(self, hip_stream):
-        """enqueue everything on a caller-owned HIP stream (int handle, e.g. torch.cuda.current_stream().cuda_stream); 0/None = own stream."""
-        self._check(self.L.arctic_set_stream(self.h, C.c_void_p(hip_stream) if hip_stream else None))
+        """enqueue everything on a caller-owned HIP stream given as an int handle, e.g. torch.cuda.current_stream().cuda_stream
+        (0 = HIP's default stream, which is what torch normally runs on); None returns to the handle's private stream."""
+        if hip_stream is None:
+            self._check(self.L.arctic_use_own_stream(self.h))
+        else:
+            self._check(self.L.arctic_set_stream(self.h, C.c_void_p(hip_stream)))
 
     def create_material(self, diffuse, normal, metal_rough):
         """three (h, w, 4) uint8 images; returns the material index."""

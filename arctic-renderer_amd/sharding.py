@@ -68,7 +68,7 @@ def gather_rows(shard, gathered, rank, world, root=0, group=None, async_op=False
         if rank == root:
             for g, h in zip(gathered, host):
                 g.copy_(h)
-        return None if async_op else gathered
+        return _Works([]) if async_op else gathered
     if _all_equal_rows(shard, world, group):   # decided collectively: every rank must take the same branch
         w = dist.gather(shard, gather_list=gathered if rank == root else None, dst=root, group=group, async_op=async_op)
         return w if async_op else gathered

@@ -99,12 +99,14 @@ def main():
     n_buf = 2 if world > 1 else 1
     outs = [torch.empty((rows, sc.width, 4), dtype=torch.uint8, device="cuda") for _ in range(n_buf)]
     shard_rows = [len(sharding.owned_rows(sc.height, k, world, BAND)) for k in range(world)] if world > 1 else [rows]
-    gathered = [[torch.empty((n, sc.width, 4), dtype=torch.uint8, device="cuda") for n in shard_rows] for _ in range(n_buf)] \
-        if (world > 1 and rank == 0) else [None] * n_buf
+    # root: the shards land back to back in one staging buffer per in-flight frame (rank k's rows at [off_k, off_k + n_k)),
+    # and ONE indexed copy de-interleaves them into the final frame
+    offs = np.concatenate([[0], np.cumsum(shard_rows)]).astype(int)
+    staging = [torch.empty((sc.height, sc.width, 4), dtype=torch.uint8, device="cuda") for _ in range(n_buf)] if (world > 1 and rank == 0) else None
+    gathered = [[staging[b][offs[k]:offs[k + 1]] for k in range(world)] for b in range(n_buf)] if staging is not None else [None] * n_buf
     pending = [None] * n_buf
-    # the root de-interleaves the gathered shards into the final frame (one indexed copy per rank, stream-ordered)
-    frame = torch.empty((sc.height, sc.width, 4), dtype=torch.uint8, device="cuda") if (world > 1 and rank == 0) else None
-    row_idx = [torch.as_tensor(sharding.owned_rows(sc.height, k, world, BAND), device="cuda") for k in range(world)] if frame is not None else None
+    frame = torch.empty((sc.height, sc.width, 4), dtype=torch.uint8, device="cuda") if staging is not None else None
+    perm = torch.as_tensor(np.concatenate([sharding.owned_rows(sc.height, k, world, BAND) for k in range(world)]), device="cuda") if staging is not None else None
     out_ptrs = [o.data_ptr() for o in outs]
     if world > 1:
         r.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -124,8 +126,7 @@ def main():
         pending[b].wait()
         pending[b] = None
         if frame is not None:
-            for k in range(world):
-                frame.index_copy_(0, row_idx[k], gathered[b][k])
+            frame.index_copy_(0, perm, staging[b])
 
     def drain():
         for b in range(n_buf):
@@ -155,6 +156,15 @@ def main():
 
     if world > 1:
         r.set_stream(None)
+    if world > 1 and rank == 0 and os.environ.get("ARCTIC_BENCH_VERIFY") == "1":
+        # the multi-rank invariant, end to end: the gathered, de-interleaved frame == a single-device frame, byte for byte
+        full = sc.upload(pkg.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights, device=local))
+        ref = full.render_frame(sc.desc, sc.settings)
+        full.close()
+        same = bool((frame.cpu().numpy() == ref).all())
+        log(f"[bench] verify: {world}-rank frame identical to the single-device frame: {same}")
+        if not same:
+            raise SystemExit("multi-rank frame differs from the single-device frame")
     # shaded pixels = pixels with geometry (100 % in this scene); counted, not assumed
     _, mat, _, _ = r.read_gbuffer(want=("material",))
     shaded_local = int((mat != 0xFFFFFFFF).sum())

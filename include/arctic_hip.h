@@ -144,10 +144,12 @@ int arctic_resize(ArcticRenderer *r, uint32_t width, uint32_t height);
 /* replaces bool Renderer::flush() (renderer.hpp:122-125): device idle */
 int arctic_flush(ArcticRenderer *r);
 
-/* run everything on a HIP stream the caller owns (a hipStream_t passed as void*), e.g. the stream a following RCCL
- * gather is enqueued on, so that no host synchronisation is needed between the frame and the collective.
- * NULL returns to the handle's own stream.  The previous stream is drained first. */
+/* run everything on a HIP stream the caller owns (a hipStream_t passed as void*; NULL is HIP's default stream, which is
+ * what torch.cuda.current_stream() usually is), e.g. the stream a following RCCL gather is enqueued on, so that no host
+ * synchronisation is needed between the frame and the collective.  arctic_use_own_stream() returns to the handle's
+ * private stream.  The stream in use before the switch is drained first. */
 int arctic_set_stream(ArcticRenderer *r, void *hip_stream);
+int arctic_use_own_stream(ArcticRenderer *r);
 
 /* ---- scene upload -------------------------------------------------------- */
 
