@@ -133,6 +133,13 @@ def main():
             if pending[b] is not None:
                 finish(b)
 
+    # roofline: the shading pass is two kernels on one stream, each launch timed with HIP events on that stream
+    #   k_material  G-buffer read + material fetch + shadow + classification   (memory bound)
+    #   k_light     sun + point lights over the lit pixels + tonemap + store   (FP32 VALU bound)
+    # (measured first: it also brings clocks and caches to their steady state before the W warm-up steps)
+    iters = max(10, min(args.steps, 50))
+    ms, ms_mat, ms_light = r.time_shade_split(sc.desc, sc.settings, warmup=20, iters=iters)
+
     for _ in range(args.warmup):
         step()
     drain()
@@ -175,11 +182,6 @@ def main():
     else:
         shaded = shaded_local
 
-    # roofline: the shading pass is two kernels on one stream, timed with HIP events on that stream
-    #   k_material  G-buffer read + material fetch + shadow + classification   (memory bound)
-    #   k_light     sun + point lights over the lit pixels + tonemap + store   (FP32 VALU bound)
-    iters = max(10, min(args.steps, 50))
-    ms, ms_mat, ms_light = r.time_shade_split(sc.desc, sc.settings, warmup=3, iters=iters)
     pass_ms, mat_ms, light_ms = float(np.mean(ms)), float(np.mean(ms_mat)), float(np.mean(ms_light))
     achieved = shaded_local * BYTES_PER_PIXEL / (pass_ms * 1e-3) / 1e9
     # the same pass with the exact culling disabled: every covered pixel evaluates the sun and all n_lights
