@@ -129,6 +129,12 @@ struct ShadeParams {
     uint32_t *lit_px;                   // pixel index y*width + x inside the shard
     uint32_t *lit_count;                // LIT_SHARDS counters per band, LIT_COUNTER_STRIDE apart: this pass's set ...
     uint32_t *lit_count_next;           // ... and the other set, which k_light clears for the next pass
+    // skybox (skybox.hlsl:61-90): environment map for pixels without geometry; env == null -> black
+    const float4 *env;                  // RGBA32F equirect, row-major
+    uint32_t env_w, env_h;
+    float sky_fwd[3], sky_right[3], sky_up[3];   // ray through ndc (x,y) = fwd + x*right + y*up (right/up scaled by the frustum)
+    float ndc_sx, ndc_sy;               // 2/width, 2/height of the whole frame
+    int32_t band_tiles, shard_index, shard_count, tile_y0;   // local tile row -> global row (see row_global)
     int32_t hdr16;                      // 1: round ps_main's colour through binary16 like the reference's RGBA16F target
     int32_t debug;                      // timing experiments only: 1 skip material textures, 2 skip shadow test
     uint32_t lit_shard_cap;             // records per shard of one band: ceil(band workgroups / LIT_SHARDS) * 256, cannot overflow
@@ -175,5 +181,6 @@ void dir_from_rot(const float rot_deg[2], float out[3]);
 void camera_proj_view(const float eye[3], const float rot_deg[2], float aspect, float fov_y_deg, float zn, float zf, float out[16]);
 void sun_proj_view(const float pos[3], const float rot_deg[2], float out[16]);
 float srgb8_to_linear(int c);
+void camera_sky_basis(const float rot_deg[2], float aspect, float fov_y_deg, float fwd[3], float right[3], float up[3]);
 
 }  // namespace arctic

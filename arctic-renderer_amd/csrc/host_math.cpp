@@ -101,6 +101,22 @@ void sun_proj_view(const float pos[3], const float rot_deg[2], float out[16]) {
     mat_mul(proj, view, out);
 }
 
+// SkyboxPass (skybox_pass.cpp:104-138, skybox.hlsl:61-70): the cube is drawn with proj * mat3(lookAtRH) and its
+// interpolated object-space position is the lookup direction, i.e. the world-space ray through the pixel.  That ray for
+// ndc (x, y) is fwd + x * right + y * up with the camera basis of lookAtRH scaled by the frustum half-extents.
+void camera_sky_basis(const float rot_deg[2], float aspect, float fov_y_deg, float fwd[3], float right[3], float up[3]) {
+    dir_from_rot(rot_deg, fwd);
+    const float wup[3] = {0.0f, 1.0f, 0.0f};
+    float f[3] = {fwd[0], fwd[1], fwd[2]};
+    normalize3(f);
+    float s[3], u[3];
+    cross3(f, wup, s);
+    normalize3(s);
+    cross3(s, f, u);
+    const float t = std::tan(deg2rad(fov_y_deg) / 2.0f), tx = aspect * t;
+    for (int i = 0; i < 3; ++i) { fwd[i] = f[i]; right[i] = s[i] * tx; up[i] = u[i] * t; }
+}
+
 // R8G8B8A8_UNORM_SRGB decode of one channel (renderer.cpp:483-505), IEC 61966-2-1
 float srgb8_to_linear(int c) {
     float x = (float)c / 255.0f;

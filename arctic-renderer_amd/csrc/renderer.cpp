@@ -69,7 +69,8 @@ struct ArcticRenderer {
     std::vector<Mesh> meshes;
     std::vector<TexDesc> tex;        // 3 per material (device pointers)
     std::vector<void *> tex_allocs;
-    DevBuf d_tex, d_lut, d_lights, d_shadow;
+    DevBuf d_tex, d_lut, d_lights, d_shadow, d_env;
+    uint32_t env_w = 0, env_h = 0;
     uint32_t n_lights = 0;
     // frame targets
     DevBuf d_vis, d_p0, d_p1, d_p2, d_p3, d_p4, d_depth, d_src, d_rgba8, d_ldr, d_hdr, d_counter;
@@ -332,6 +333,11 @@ int fill_shade_params(ArcticRenderer *r, const ArcticScene *sc, const ArcticSett
     sp.culling = r->culling;
     sp.debug = r->debug;
     sp.hdr16 = r->hdr16;
+    sp.env = r->env_w ? r->d_env.as<float4>() : nullptr; sp.env_w = r->env_w; sp.env_h = r->env_h;
+    camera_sky_basis(sc->camera.rotation, sc->camera.aspect, sc->camera.fov_y, sp.sky_fwd, sp.sky_right, sp.sky_up);
+    sp.ndc_sx = 2.0f / (float)r->width; sp.ndc_sy = 2.0f / (float)r->height;
+    sp.band_tiles = (int32_t)(r->band_rows / TILE); sp.shard_index = (int32_t)r->shard_index; sp.shard_count = (int32_t)r->shard_count;
+    sp.tile_y0 = (int32_t)r->tile_y0;
     sp.lit_r0 = r->d_lit0.as<float4>(); sp.lit_r1 = r->d_lit1.as<float4>(); sp.lit_r2 = r->d_lit2.as<float4>();
     sp.lit_px = r->d_litpx.as<uint32_t>(); sp.lit_count = sp.lit_count_next = nullptr;   // set per pass by shade_once
     sp.lit_shard_cap = r->lit_shard_cap();
@@ -458,7 +464,7 @@ void arctic_destroy(ArcticRenderer *r) {
     if (r->own_stream) { (void)hipStreamSynchronize(r->own_stream); (void)hipStreamDestroy(r->own_stream); }
     for (Mesh &m : r->meshes) { if (m.d_vertices) (void)hipFree(m.d_vertices); if (m.d_indices) (void)hipFree(m.d_indices); }
     for (void *p : r->tex_allocs) (void)hipFree(p);
-    DevBuf *bufs[] = {&r->d_tex, &r->d_lut, &r->d_lights, &r->d_shadow, &r->d_vis, &r->d_p0, &r->d_p1, &r->d_p2, &r->d_p3, &r->d_p4,
+    DevBuf *bufs[] = {&r->d_tex, &r->d_lut, &r->d_lights, &r->d_shadow, &r->d_env, &r->d_vis, &r->d_p0, &r->d_p1, &r->d_p2, &r->d_p3, &r->d_p4,
                       &r->d_depth, &r->d_src, &r->d_rgba8, &r->d_ldr, &r->d_hdr, &r->d_counter, &r->d_lit0, &r->d_lit1, &r->d_lit2, &r->d_litpx, &r->d_litcount, &r->d_xverts, &r->d_sub_count, &r->d_sub_offset,
                       &r->d_recs, &r->d_tile_count, &r->d_tile_offset, &r->d_scan, &r->d_stage, &r->tables[0].d, &r->tables[1].d};
     for (PassTables &T : r->tables) { if (T.h) (void)hipHostFree(T.h); if (T.copied) (void)hipEventDestroy(T.copied); }
@@ -584,7 +590,14 @@ int arctic_update_lights(ArcticRenderer *r, const ArcticPointLight *lights, uint
 int arctic_create_hdri(ArcticRenderer *r, const float *rgba32f, uint32_t w, uint32_t h) {
     if (!r) return ARCTIC_E_INVALID;
     if (!rgba32f || !w || !h) return r->fail(ARCTIC_E_INVALID, "create_hdri: null image or zero size");
-    return ARCTIC_OK;   // skybox is outside this path
+    if ((w | h) & 0xFFFF0000u) return r->fail(ARCTIC_E_CAPACITY, "create_hdri: image side above 65535");
+    int rc = select_device(r);
+    if (rc) return rc;
+    HIPCHECK(r, hipStreamSynchronize(r->stream));
+    HIPCHECK(r, r->d_env.ensure((size_t)w * h * 16));
+    HIPCHECK(r, hipMemcpy(r->d_env.p, rgba32f, (size_t)w * h * 16, hipMemcpyHostToDevice));
+    r->env_w = w; r->env_h = h;
+    return ARCTIC_OK;
 }
 
 int arctic_pass_shadow_map(ArcticRenderer *r, const ArcticScene *scene) {

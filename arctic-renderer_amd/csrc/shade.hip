@@ -377,6 +377,37 @@ __device__ __forceinline__ void store_pixel(const ShadeParams &sp, size_t o, f3 
     if (sp.out_hdr) { sp.out_hdr[o * 3] = color.x; sp.out_hdr[o * 3 + 1] = color.y; sp.out_hdr[o * 3 + 2] = color.z; }
 }
 
+// ---- skybox.hlsl:61-90: pixels without geometry take the environment map along their view ray --------------------------
+// (the reference draws a cube at z = w after the forward pass, depth LESS_EQUAL: it survives exactly where nothing was drawn.)
+// The lookup coordinates are computed in float64: they feed a bilinear filter over an HDR image whose texel-to-texel contrast
+// can be thousands, so fp32 atan2/asin noise (1e-7 in uv = 2e-4 texel) would show; sky pixels are few, fp64 is affordable.
+__device__ __forceinline__ void wrap_axis64(double u, uint32_t n, int &i0, int &i1, float &f) {
+    const double uw = u - floor(u);
+    const double x = uw * (double)n - 0.5;
+    const double xf = floor(x);
+    f = (float)(x - xf);
+    i0 = (int)xf;
+    i1 = i0 + 1;
+    if (i0 < 0) i0 += (int)n;
+    if (i1 >= (int)n) i1 -= (int)n;
+}
+__device__ __noinline__ f3 sample_environment(const float4 *__restrict__ env, uint32_t w, uint32_t h, float fx_, float fy_, float fz_) {
+    double x = fx_, y = fy_, z = fz_;
+    const double inv = 1.0 / sqrt(x * x + y * y + z * z);            // dir = normalize(dir)
+    x *= inv; y *= inv; z *= inv;
+    const double u = atan2(z, x) * (double)0.1591f + 0.5;             // uv = (atan2(z,x), asin(y)) * INV_ATAN + 0.5
+    const double v = -(asin(fmin(fmax(y, -1.0), 1.0)) * (double)0.3183f + 0.5);   // uv.y = -uv.y
+    int x0, x1, y0, y1;
+    float fx, fy;
+    wrap_axis64(u, w, x0, x1, fx);
+    wrap_axis64(v, h, y0, y1, fy);
+    const float4 a = env[(size_t)y0 * w + x0], b = env[(size_t)y0 * w + x1], c = env[(size_t)y1 * w + x0], d = env[(size_t)y1 * w + x1];
+    const float gx = 1.0f - fx, gy = 1.0f - fy;
+    const float w00 = gx * gy, w10 = fx * gy, w01 = gx * fy, w11 = fx * fy;
+    return mk(w00 * a.x + w10 * b.x + w01 * c.x + w11 * d.x, w00 * a.y + w10 * b.y + w01 * c.y + w11 * d.y,
+              w00 * a.z + w10 * b.z + w01 * c.z + w11 * d.z);
+}
+
 // ---- kernel 1: material fetch + shadow + classification ---------------------------------------------------------
 // LDS (dynamic): [0,256) sRGB LUT | texture descriptors, 4 dwords each
 __global__ __launch_bounds__(256) void k_material(const ShadeParams sp) {
@@ -429,7 +460,18 @@ __global__ __launch_bounds__(256) void k_material(const ShadeParams sp) {
     if (m != 0ull) { gc = sp.g.c[gi]; gd = sp.g.d[gi]; ge = sp.g.e[gi]; }   // second wave of loads: lit tiles only (48 B / pixel)
     f3 base = mk(0.0f, 0.0f, 0.0f);
     if (covered) base = mk(filt_srgb(t0, 0, lut), filt_srgb(t0, 1, lut), filt_srgb(t0, 2, lut));
-    if (in_frame && !live) store_pixel(sp, o, base * sp.ambient);   // uncovered: base = 0 -> black (the skybox is out of scope)
+    if (in_frame && !live) {
+        f3 c = base * sp.ambient;   // covered and fully shadowed: ambient * base
+        if (!covered && sp.env) {   // no geometry: the skybox
+            const int gy = (row_global((int)ty, sp.band_tiles, sp.shard_count, sp.shard_index) + sp.tile_y0) * 8 + (int)(lane >> 3);
+            const float nx = __builtin_fmaf((float)x + 0.5f, sp.ndc_sx, -1.0f), ny = __builtin_fmaf(-((float)gy + 0.5f), sp.ndc_sy, 1.0f);
+            c = sample_environment(sp.env, sp.env_w, sp.env_h,
+                                   __builtin_fmaf(sp.sky_up[0], ny, __builtin_fmaf(sp.sky_right[0], nx, sp.sky_fwd[0])),
+                                   __builtin_fmaf(sp.sky_up[1], ny, __builtin_fmaf(sp.sky_right[1], nx, sp.sky_fwd[1])),
+                                   __builtin_fmaf(sp.sky_up[2], ny, __builtin_fmaf(sp.sky_right[2], nx, sp.sky_fwd[2])));
+        }
+        store_pixel(sp, o, c);
+    }
     // wave-wide compaction of the live pixels into this workgroup's SHARD of the stream (one atomicAdd per wave, on one
     // of LIT_SHARDS counters each on its own 128-byte line: a single counter would serialise at ~88 atomics/us)
     if (m != 0ull) {

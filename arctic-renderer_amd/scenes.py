@@ -204,6 +204,7 @@ class SyntheticScene:
         self.materials = materials   # list of (diffuse, normal, mr)
         self.meshes = meshes         # list of (vertices, indices, material_idx)
         self.desc, self.lights, self.settings = desc, lights, settings
+        self.environment = None      # optional (h, w, 4) float32 equirect map for the skybox (stbi_loadf stand-in)
 
     @property
     def n_triangles(self):
@@ -217,7 +218,35 @@ class SyntheticScene:
         for v, i, mat in self.meshes:
             renderer.create_mesh(v, i, mat)
         renderer.update_lights(self.lights)
+        if self.environment is not None:
+            renderer.create_hdri(self.environment)
         return renderer
+
+
+def synthetic_hdri(w=512, h=256, seed=SEED + 9, sun_peak=60.0):
+    """equirect RGBA32F environment (what stbi_loadf hands create_hdri, renderer.cpp:113-119): sky gradient over a dark
+    ground, value-noise clouds and a small very bright sun disc, so the bilinear filter sees real HDR contrast."""
+    rng = np.random.default_rng(seed)
+    v = (np.arange(h, dtype=np.float32) + 0.5) / h
+    u = (np.arange(w, dtype=np.float32) + 0.5) / w
+    elev = (0.5 - v)[:, None] * np.float32(np.pi)                    # +pi/2 at the top row
+    az = (u[None, :] - 0.5) * np.float32(2 * np.pi)
+    t = np.clip(np.sin(elev), -1, 1)
+    sky = np.stack([0.25 + 0.35 * (1 - t), 0.45 + 0.3 * (1 - t), 0.9 + 0.0 * t], -1)
+    ground = np.stack([0.12 + 0 * t, 0.10 + 0 * t, 0.08 + 0 * t], -1)
+    img = np.where((t > 0)[..., None], sky, ground).astype(np.float32) * np.ones((h, w, 1), np.float32)
+    g = rng.random((h // 16 + 2, w // 16 + 2)).astype(np.float32)
+    yy, xx = np.meshgrid(np.arange(h) / 16.0, np.arange(w) / 16.0, indexing="ij")
+    y0, x0 = yy.astype(int), xx.astype(int)
+    fy, fx = (yy - y0).astype(np.float32), (xx - x0).astype(np.float32)
+    noise = (g[y0, x0] * (1 - fx) + g[y0, x0 + 1] * fx) * (1 - fy) + (g[y0 + 1, x0] * (1 - fx) + g[y0 + 1, x0 + 1] * fx) * fy
+    img *= (0.7 + 0.6 * noise)[..., None]
+    sun_el, sun_az = np.float32(np.deg2rad(35.0)), np.float32(np.deg2rad(40.0))
+    cosang = np.sin(elev) * np.sin(sun_el) + np.cos(elev) * np.cos(sun_el) * np.cos(az - sun_az)
+    img += (np.float32(sun_peak) * np.exp((np.clip(cosang, -1, 1) - 1) * 900.0))[..., None] * np.array([1.0, 0.9, 0.7], np.float32)
+    out = np.ones((h, w, 4), np.float32)
+    out[..., :3] = img
+    return np.ascontiguousarray(out)
 
 
 DEFAULT_SUN = dict(position=(-10.0, 32.0, -2.48), rotation=(-70.0, 12.0), color=(8.0, 8.0, 8.0))   # src/app.hpp:51-55
@@ -337,7 +366,9 @@ def config4(scale=1.0, tex=None):
 
 def config5(scale=1.0, tex=None):
     w, h = _dims(7680, 4320, scale)
-    return atrium(w, h, max(64, int(4096 * scale)), 1024, scale, tex, name="config5-sponza-standin-1024")
+    sc = atrium(w, h, max(64, int(4096 * scale)), 1024, scale, tex, name="config5-sponza-standin-1024")
+    sc.environment = synthetic_hdri(max(64, int(2048 * scale)) // 2 * 2, max(32, int(1024 * scale)) // 2 * 2)   # "HDR env" of BASELINE configs[4]
+    return sc
 
 
 CONFIGS = {1: config1, 2: config2, 3: config3, 4: config4, 5: config5}

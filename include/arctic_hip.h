@@ -173,16 +173,17 @@ int arctic_create_mesh(ArcticRenderer *r,
  * renderer.cpp:585-603): clamps to max_lights like the reference clamps to 16. */
 int arctic_update_lights(ArcticRenderer *r, const ArcticPointLight *lights, uint64_t n);
 
-/* replaces bool Renderer::create_hdri(float*,w,h) (renderer.hpp:118).  The
- * skybox is outside this path: accepted, validated, ignored. */
+/* replaces bool Renderer::create_hdri(float*,w,h) (renderer.hpp:118, renderer.cpp:555-583): RGBA32F equirect
+ * environment map.  Pixels without geometry then take it along their view ray (skybox.hlsl:61-90);
+ * without a map they are black. */
 int arctic_create_hdri(ArcticRenderer *r, const float *rgba32f, uint32_t w, uint32_t h);
 
 /* ---- frames -------------------------------------------------------------- */
 
 /* replaces bool Renderer::render_frame(const Scene&, const Settings&, build_ui)
- * (renderer.hpp:106-107, renderer.cpp:274-415) minus skybox/ImGui/present:
- * shadow-map raster -> visibility/G-buffer prepass -> shading (+fused tonemap)
- * -> RGBA8.  out_rgba8 is a HOST buffer of (row_end-row_begin)*width*4 bytes,
+ * (renderer.hpp:106-107, renderer.cpp:274-415) minus ImGui/present:
+ * shadow-map raster -> visibility/G-buffer prepass -> shading + skybox fill
+ * (+fused tonemap) -> RGBA8.  out_rgba8 is a HOST buffer of (row_end-row_begin)*width*4 bytes,
  * row-major, top-left origin; NULL = leave the frame on the device. */
 int arctic_render_frame(ArcticRenderer *r, const ArcticScene *scene,
                         const ArcticSettings *settings, uint8_t *out_rgba8);

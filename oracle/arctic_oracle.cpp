@@ -359,6 +359,7 @@ struct Oracle {
     std::vector<uint8_t> rgba8;     // rows*width*4
     float srgb_lut[256];
     uint64_t stats[6] = {0, 0, 0, 0, 0, 0};
+    std::vector<float> env; uint32_t env_w = 0, env_h = 0;   // skybox environment map (RGBA32F); empty = black
     int hdr16 = 0;        // 1: ps_main's colour passes through binary16 (the reference's RGBA16F target) before post_process
     int precision = 64;   // arithmetic of the BRDF/tonemap: 64 = float64 (parity arbiter), 32 = literal fp32 (CPU baseline)
     std::string err;
@@ -720,10 +721,61 @@ inline uint8_t to_unorm8(float x) {
     return (uint8_t)(x * 255.0f + 0.5f);
 }
 
+// ---- skybox (skybox.hlsl:61-90, skybox_pass.cpp:104-138) ---------------------------------------------------------
+// The reference draws a unit cube with proj * mat3(lookAtRH) at depth 1 (clip z = w) after the forward pass; it survives the
+// depth test exactly where no geometry was drawn, and its interpolated object-space position is the world-space view ray of
+// the pixel.  Restated without the cube: the ray through ndc (x, y) is fwd + x*right + y*up with lookAtRH's basis scaled by
+// the frustum half-extents (same direction as the interpolated cube position, which ps_main normalises anyway).
+struct SkyBasis { V3 fwd, right, up; };
+SkyBasis sky_basis(const Camera &c) {
+    V3 f = normalize(dir_from_rot(c.rotation));
+    V3 s = normalize(cross(f, v3(0.0f, 1.0f, 0.0f)));
+    V3 u = cross(s, f);
+    float t = std::tan(radians(c.fov_y) / 2.0f), tx = c.aspect * t;
+    return SkyBasis{f, scale(s, tx), scale(u, t)};
+}
+inline V3 sky_ray(const SkyBasis &b, uint32_t x, uint32_t y, uint32_t W, uint32_t H) {
+    float sx = 2.0f / (float)W, sy = 2.0f / (float)H;
+    float nx = std::fmaf((float)x + 0.5f, sx, -1.0f), ny = std::fmaf(-((float)y + 0.5f), sy, 1.0f);
+    return v3(std::fmaf(b.up.x, ny, std::fmaf(b.right.x, nx, b.fwd.x)), std::fmaf(b.up.y, ny, std::fmaf(b.right.y, nx, b.fwd.y)),
+              std::fmaf(b.up.z, ny, std::fmaf(b.right.z, nx, b.fwd.z)));
+}
+inline void wrap_axis64(double u, uint32_t n, int &i0, int &i1, float &f) {
+    double uw = u - std::floor(u);
+    double x = uw * (double)n - 0.5, xf = std::floor(x);
+    f = (float)(x - xf);
+    i0 = (int)xf; i1 = i0 + 1;
+    if (i0 < 0) i0 += (int)n;
+    if (i1 >= (int)n) i1 -= (int)n;
+}
+// sample_environment(dir): equirect lookup, LINEAR + WRAP sampler (skybox_pass.cpp:34-47), lookup coordinates in float64
+template <class R>
+Vec3<R> sample_environment(const Oracle &o, V3 dir, double *uv_out = nullptr) {
+    double x = dir.x, y = dir.y, z = dir.z;
+    double inv = 1.0 / std::sqrt(x * x + y * y + z * z);
+    x *= inv; y *= inv; z *= inv;
+    double u = std::atan2(z, x) * (double)0.1591f + 0.5;
+    double v = -(std::asin(std::fmin(std::fmax(y, -1.0), 1.0)) * (double)0.3183f + 0.5);
+    if (uv_out) { uv_out[0] = u; uv_out[1] = v; }
+    if (!o.env_w) return vec3<R>(0, 0, 0);
+    int x0, x1, y0, y1; float fx, fy;
+    wrap_axis64(u, o.env_w, x0, x1, fx);
+    wrap_axis64(v, o.env_h, y0, y1, fy);
+    const float *a = &o.env[((size_t)y0 * o.env_w + x0) * 4];
+    const float *b = &o.env[((size_t)y0 * o.env_w + x1) * 4];
+    const float *c = &o.env[((size_t)y1 * o.env_w + x0) * 4];
+    const float *d = &o.env[((size_t)y1 * o.env_w + x1) * 4];
+    R gx = (R)1 - (R)fx, gy = (R)1 - (R)fy;
+    R w00 = gx * gy, w10 = (R)fx * gy, w01 = gx * (R)fy, w11 = (R)fx * (R)fy;
+    return vec3<R>(w00 * a[0] + w10 * b[0] + w01 * c[0] + w11 * d[0], w00 * a[1] + w10 * b[1] + w01 * c[1] + w11 * d[1],
+                   w00 * a[2] + w10 * b[2] + w01 * c[2] + w11 * d[2]);
+}
+
 template <class R>
 void shade_rows(Oracle &o, const Scene &sc, const Settings &st, const float *attrs, const uint32_t *matid,
-                uint32_t r0, uint32_t r1, float *hdr, float *ldr, uint8_t *rgba8, std::atomic<uint64_t> *shaded) {
+                uint32_t r0, uint32_t r1, uint32_t y_origin, float *hdr, float *ldr, uint8_t *rgba8, std::atomic<uint64_t> *shaded) {
     uint32_t W = o.width;
+    SkyBasis sky = sky_basis(sc.camera);
     V3 eye = v3(sc.camera.eye[0], sc.camera.eye[1], sc.camera.eye[2]);
     V3 sun_dir = dir_from_rot(sc.sun.rotation);
     V3 sun_color = v3(sc.sun.color[0], sc.sun.color[1], sc.sun.color[2]);
@@ -732,9 +784,11 @@ void shade_rows(Oracle &o, const Scene &sc, const Settings &st, const float *att
     for (uint32_t y = r0; y < r1; ++y)
         for (uint32_t x = 0; x < W; ++x) {
             size_t p = (size_t)y * W + x;
-            Vec3<R> c = vec3<R>(0, 0, 0);   // no geometry: the reference's skybox is out of scope, defined black
+            Vec3<R> c = vec3<R>(0, 0, 0);
             uint32_t m = matid[p];
-            if (m != 0xFFFFFFFFu && m < o.materials.size()) {
+            if (m == 0xFFFFFFFFu) {   // no geometry: the skybox (black without an environment map)
+                if (o.env_w) c = sample_environment<R>(o, sky_ray(sky, x, y + y_origin, W, o.height));
+            } else if (m < o.materials.size()) {
                 c = ps_main<R>(o, attrs + p * 18, m, eye, sun_dir, sun_color, sc.ambient, smap);
                 ++count;
             }
@@ -748,12 +802,12 @@ void shade_rows(Oracle &o, const Scene &sc, const Settings &st, const float *att
 }
 
 void shade_parallel(Oracle &o, const Scene &sc, const Settings &st, const float *attrs, const uint32_t *matid,
-                    uint32_t rows, float *hdr, float *ldr, uint8_t *rgba8, int threads) {
+                    uint32_t rows, uint32_t y_origin, float *hdr, float *ldr, uint8_t *rgba8, int threads) {
     if (threads < 1) threads = 1;
     std::atomic<uint64_t> shaded{0};
     auto run = [&](uint32_t a, uint32_t b) {
-        if (o.precision == 32) shade_rows<float>(o, sc, st, attrs, matid, a, b, hdr, ldr, rgba8, &shaded);
-        else shade_rows<double>(o, sc, st, attrs, matid, a, b, hdr, ldr, rgba8, &shaded);
+        if (o.precision == 32) shade_rows<float>(o, sc, st, attrs, matid, a, b, y_origin, hdr, ldr, rgba8, &shaded);
+        else shade_rows<double>(o, sc, st, attrs, matid, a, b, y_origin, hdr, ldr, rgba8, &shaded);
     };
     if (threads == 1) run(0, rows);
     else {
@@ -830,7 +884,7 @@ int oracle_pass_shade(void *h, const Scene *sc, const Settings *st, int threads)
     size_t npx = (size_t)o->width * o->rows();
     if (o->attrs.size() != npx * 18) return -4;
     o->hdr.resize(npx * 3); o->ldr.resize(npx * 3); o->rgba8.resize(npx * 4);
-    shade_parallel(*o, *sc, *st, o->attrs.data(), o->matid.data(), o->rows(), o->hdr.data(), o->ldr.data(), o->rgba8.data(), threads);
+    shade_parallel(*o, *sc, *st, o->attrs.data(), o->matid.data(), o->rows(), o->row_begin, o->hdr.data(), o->ldr.data(), o->rgba8.data(), threads);
     return 0;
 }
 
@@ -840,7 +894,7 @@ int oracle_shade_gbuffer(void *h, const Scene *sc, const Settings *st, const flo
                          uint32_t rows, float *hdr, float *ldr, uint8_t *rgba8, int threads) {
     Oracle *o = static_cast<Oracle *>(h);
     if (!o || !sc || !st || !attrs || !matid) return -1;
-    shade_parallel(*o, *sc, *st, attrs, matid, rows, hdr, ldr, rgba8, threads);
+    shade_parallel(*o, *sc, *st, attrs, matid, rows, 0, hdr, ldr, rgba8, threads);   // stripe starts at frame row 0
     return 0;
 }
 
@@ -942,6 +996,24 @@ int oracle_fetch_surface(void *h, uint32_t mat, float u, float v, const float tb
     return 0;
 }
 uint8_t oracle_to_unorm8(float x) { return to_unorm8(x); }
+// renderer.cpp:555-583 create_hdri: RGBA32F environment map
+int oracle_create_hdri(void *h, const float *rgba, uint32_t w, uint32_t hh) {
+    Oracle *o = static_cast<Oracle *>(h);
+    if (!o || !rgba || !w || !hh) return -1;
+    o->env.assign(rgba, rgba + (size_t)w * hh * 4); o->env_w = w; o->env_h = hh;
+    return 0;
+}
+// unit entry points: the view ray of pixel (x, y) and the environment lookup along a direction (uv_out: the float64 uv)
+void oracle_sky_ray(void *h, const Camera *c, uint32_t x, uint32_t y, float out[3]) {
+    Oracle *o = static_cast<Oracle *>(h);
+    V3 d = sky_ray(sky_basis(*c), x, y, o->width, o->height);
+    out[0] = d.x; out[1] = d.y; out[2] = d.z;
+}
+void oracle_sample_environment(void *h, const float dir[3], double out_rgb[3], double uv_out[2]) {
+    Oracle *o = static_cast<Oracle *>(h);
+    Vec3<double> c = sample_environment<double>(*o, v3(dir[0], dir[1], dir[2]), uv_out);
+    out_rgb[0] = c.x; out_rgb[1] = c.y; out_rgb[2] = c.z;
+}
 int oracle_set_hdr16(void *h, int on) {
     Oracle *o = static_cast<Oracle *>(h);
     if (!o) return -1;

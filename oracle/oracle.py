@@ -88,6 +88,11 @@ def lib():
         L.oracle_hardware_threads.restype = i32
         L.oracle_set_precision.argtypes = [vp, i32]
         L.oracle_set_hdr16.argtypes = [vp, i32]
+        L.oracle_create_hdri.argtypes = [vp, vp, u32, u32]
+        L.oracle_sky_ray.argtypes = [vp, C.POINTER(Camera), u32, u32, vp]
+        L.oracle_sky_ray.restype = None
+        L.oracle_sample_environment.argtypes = [vp, vp, vp, vp]
+        L.oracle_sample_environment.restype = None
         L.oracle_through_half.restype = f32
         L.oracle_through_half.argtypes = [f32]
         _lib = L
@@ -123,6 +128,26 @@ class Oracle:
         """route ps_main's colour through binary16 like the reference's RGBA16F target (forward_pass.cpp:149)."""
         assert self.L.oracle_set_hdr16(self.h, int(on)) == 0
         return self
+
+    def create_hdri(self, rgba32f):
+        a = _f32(rgba32f)
+        assert a.ndim == 3 and a.shape[2] == 4
+        assert self.L.oracle_create_hdri(self.h, _ptr(a), a.shape[1], a.shape[0]) == 0
+
+    def sky_ray(self, camera, x, y):
+        cam = Camera()
+        cam.eye[:] = [float(v) for v in camera["eye"]]
+        cam.rotation[:] = [float(v) for v in camera["rotation"]]
+        cam.aspect, cam.fov_y = float(camera["aspect"]), float(camera["fov_y"])
+        cam.z_near_far[:] = [float(v) for v in camera["z_near_far"]]
+        out = np.zeros(3, np.float32)
+        self.L.oracle_sky_ray(self.h, C.byref(cam), x, y, _ptr(out))
+        return out
+
+    def sample_environment(self, direction):
+        d, rgb, uv = _f32(direction), np.zeros(3), np.zeros(2)
+        self.L.oracle_sample_environment(self.h, _ptr(d), _ptr(rgb), _ptr(uv))
+        return rgb, uv
 
     def close(self):
         if self.h:
