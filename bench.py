@@ -37,6 +37,11 @@ import __graft_entry__ as entry  # noqa: E402
 
 BYTES_PER_PIXEL = 80          # 72 B attributes + 4 B material id + 4 B RGBA8
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
+VALU_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: FP32 vector peak = every issue slot a v_pk_fma_f32 (4 flop per lane per 4-cycle slot)
+# k_light's loop, from its ISA (make -C arctic-renderer_amd/csrc asm): per trip of 4 lights 98 v_pk_* + 9 plain VALU
+# (4-cycle issue slots) + 12 transcendentals (v_rsq/v_rcp, 8 cycles = 2 slots each) = 131 slots -> 32.75 slots per light
+# evaluation per lane, priced at the peak's 4 flop per slot: the fraction is "VALU issue slots used / available"
+VALU_FLOPS_PER_LIGHT_EVAL = 32.75 * 4
 FP32_PEAK_TFLOPS = 157.3      # vector FP32 (needs packed FMA)
 
 
@@ -220,6 +225,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "kernel": "k_material + k_light (the shading pass)", "kernel_ms": round(pass_ms, 4),
+                         "kernel_ms_p10_p50_p90": [round(float(np.percentile(ms, q)), 4) for q in (10, 50, 90)],
                          "bytes_per_pixel": BYTES_PER_PIXEL,
                          "k_material_ms": round(mat_ms, 4), "k_material_GBps": round(mat_bytes / (mat_ms * 1e-3) / 1e9, 1),
                          "k_light_ms": round(light_ms, 4), "k_light_GBps": round(light_bytes / (light_ms * 1e-3) / 1e9, 1),
@@ -227,6 +233,11 @@ def main():
                          "point_light_evals_per_lit_pixel": round(light_evals / max(lit_px, 1), 2),
                          "point_light_evals_per_pixel": round(light_evals / max(shaded_local, 1), 2),
                          "k_light_Gevals_per_s": round(light_evals / (light_ms * 1e-3) / 1e9, 1),
+                         # the other roof: the FP32 vector peak, which is what binds k_light
+                         "valu": {"achieved": round(light_evals * VALU_FLOPS_PER_LIGHT_EVAL / (light_ms * 1e-3) / 1e12, 1),
+                                  "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s (FMA = 2, issue-slot equivalents)",
+                                  "frac": round(light_evals * VALU_FLOPS_PER_LIGHT_EVAL / (light_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4),
+                                  "kernel": "k_light", "binds": True},
                          "kernel_ms_no_culling": round(ms_nocull, 4),
                          "achieved_no_culling": round(shaded_local * BYTES_PER_PIXEL / (ms_nocull * 1e-3) / 1e9, 1)},
         }
@@ -267,8 +278,22 @@ def cpu_baseline(pkg, sc, r, cpu_rows):
         reps += 1
         dt = time.perf_counter() - t
     px = int((mat[start:start + n] != 0xFFFFFFFF).sum())
+    # one thread, on a few rows (SURVEY 8d asks for both figures)
+    n1, reps1, dt1 = min(4, attrs.shape[0]), 0, 0.0
+    t = time.perf_counter()
+    while reps1 < 1 or (dt1 < 2.0 and reps1 < 100):
+        o.shade_gbuffer(sc.desc, sc.settings, attrs[mid:mid + n1], mat[mid:mid + n1], threads=1, want=("rgba8",))
+        reps1 += 1
+        dt1 = time.perf_counter() - t
+    one_thread = int((mat[mid:mid + n1] != 0xFFFFFFFF).sum()) * reps1 / dt1 / 1e6
     o.close()
+    model = ""
+    try:
+        model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except Exception:
+        pass
     return {"value": round(px * reps / dt / 1e6, 3), "unit": "Mpixels/s", "cores": threads, "kind": "port",
+            "one_thread_value": round(one_thread, 4), "cpu_model": model,
             "sample": f"rows {start}..{start + n} of the {sc.height}-row frame x {reps} ({px * reps} shaded pixels, {dt:.1f} s), same "
                       f"G-buffer, shadow map and {len(sc.lights)} lights; scalar fp32 C++ oracle, {threads} threads, no culling"}
 
