@@ -128,6 +128,7 @@ struct ShadeParams {
     float4 *lit_r0, *lit_r1, *lit_r2;   // (world.xyz, 1-shadow) (n.xyz, roughness) (base.xyz, metalness)
     uint32_t *lit_px;                   // pixel index y*width + x inside the shard
     uint32_t *lit_count;                // LIT_SHARDS counters per band, LIT_COUNTER_STRIDE apart: this pass's set ...
+    uint32_t *tickets;                  // fused kernel: 8 per-XCD tile tickets + 1 exit counter, 128 B apart, zero between passes
     uint32_t *lit_count_next;           // ... and the other set, which k_light clears for the next pass
     // skybox (skybox.hlsl:61-90): environment map for pixels without geometry; env == null -> black
     const float4 *env;                  // RGBA32F equirect, row-major
@@ -147,6 +148,7 @@ struct ShadeLaunch {
     uint32_t n_bands, light_blocks;
     uint32_t lights_per_trip;   // k_light variant: 4 (two packed pairs per loop trip, 121 VGPRs) or 2 (one pair, 96 VGPRs)
     hipEvent_t mid;   // optional: recorded between k_material and k_light (single band), for per-kernel timing
+    uint32_t fused, fused_blocks;   // 1: the whole pass as one persistent kernel (k_shade_fused) of fused_blocks workgroups
 };
 constexpr uint32_t LIT_SHARDS = 256, LIT_COUNTER_STRIDE = 32;
 constexpr uint32_t MAX_LDS_MATERIALS = 512;   // 24 KiB of descriptors
@@ -171,6 +173,8 @@ hipError_t launch_resolve(const unsigned long long *vis, const SetupRec *recs, c
 hipError_t launch_fill_u64(unsigned long long *p, unsigned long long v, size_t n, hipStream_t s);
 hipError_t launch_fill_u32(uint32_t *p, uint32_t v, size_t n, hipStream_t s);
 hipError_t launch_shade(const ShadeParams &sp, const ShadeLaunch &L);
+size_t fused_lds_bytes(uint32_t n_materials, uint32_t n_lights);
+int fused_blocks_per_cu(size_t lds_bytes, uint32_t lights_per_trip);
 hipError_t launch_post_process(const float4 *hdr, uint32_t w, uint32_t h, int32_t tm, float inv_gamma, float exposure,
                                uint8_t *rgba8, float *ldr, hipStream_t s);
 hipError_t launch_gbuffer_tile(GBuffer g, float *attrs, uint32_t *mat, uint32_t width, uint32_t rows,

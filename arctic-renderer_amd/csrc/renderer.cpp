@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -83,6 +84,8 @@ struct ArcticRenderer {
     int keep_float = 0, count_evals = 0, culling = 1, debug = 0, hdr16 = 0;
     ShadeLaunch launch{};           // streams, events, band count and k_light's persistent grid
     uint32_t raster_blocks = 2048;  // persistent grid of k_raster
+    DevBuf d_tickets;               // fused shading kernel: tile tickets (zeroed once; the kernel resets them itself)
+    size_t fused_lds = ~(size_t)0; int fused_per_cu = 0;   // cached occupancy query
     int lit_parity = 0;             // which of the two stream-counter sets the next pass uses
     uint32_t cu_count = 256;
     uint32_t *h_counts = nullptr;   // pinned: [0] records, [1] work items (forward), [2], [3] the same for the shadow pass
@@ -144,6 +147,10 @@ int alloc_targets(ArcticRenderer *r) {
     HIPCHECK(r, r->d_src.ensure(px * 4));
     HIPCHECK(r, r->d_rgba8.ensure(out_px * 4));
     HIPCHECK(r, r->d_counter.ensure(64));
+    if (!r->d_tickets.p) {
+        HIPCHECK(r, r->d_tickets.ensure(9 * 128));
+        HIPCHECK(r, hipMemsetAsync(r->d_tickets.p, 0, 9 * 128, r->stream));
+    }
     {
         size_t cap = (size_t)r->lit_shard_cap() * LIT_SHARDS * std::max(1u, r->launch.n_bands);   // re-checked per frame: the band count is an option
         HIPCHECK(r, r->d_lit0.ensure(cap * 16));
@@ -341,6 +348,7 @@ int fill_shade_params(ArcticRenderer *r, const ArcticScene *sc, const ArcticSett
     sp.lit_r0 = r->d_lit0.as<float4>(); sp.lit_r1 = r->d_lit1.as<float4>(); sp.lit_r2 = r->d_lit2.as<float4>();
     sp.lit_px = r->d_litpx.as<uint32_t>(); sp.lit_count = sp.lit_count_next = nullptr;   // set per pass by shade_once
     sp.lit_shard_cap = r->lit_shard_cap();
+    sp.tickets = r->d_tickets.as<uint32_t>();
     {
         size_t cap = (size_t)sp.lit_shard_cap * LIT_SHARDS * r->launch.n_bands;
         HIPCHECK(r, r->d_lit0.ensure(cap * 16)); HIPCHECK(r, r->d_lit1.ensure(cap * 16)); HIPCHECK(r, r->d_lit2.ensure(cap * 16)); HIPCHECK(r, r->d_litpx.ensure(cap * 4));
@@ -351,6 +359,14 @@ int fill_shade_params(ArcticRenderer *r, const ArcticScene *sc, const ArcticSett
 
 // one shading pass; alternates the two stream-counter sets (k_light clears the set the NEXT pass will fill)
 hipError_t shade_once(ArcticRenderer *r, ShadeParams &sp, const ShadeLaunch &L) {
+    if (L.fused) {   // one persistent kernel, no stream: the counter sets are left alone (the cleared one stays cleared)
+        const size_t lds = fused_lds_bytes(sp.n_materials, sp.n_lights);
+        if (lds != r->fused_lds) { r->fused_lds = lds; r->fused_per_cu = fused_blocks_per_cu(lds, L.lights_per_trip); }
+        if (r->fused_per_cu < 1) return hipErrorLaunchOutOfResources;
+        ShadeLaunch F = L;
+        F.fused_blocks = r->cu_count * (uint32_t)r->fused_per_cu;
+        return launch_shade(sp, F);
+    }
     const size_t set = (size_t)MAX_BANDS * LIT_SHARDS * LIT_COUNTER_STRIDE;
     sp.lit_count = r->d_litcount.as<uint32_t>() + (r->lit_parity ? set : 0);
     sp.lit_count_next = r->d_litcount.as<uint32_t>() + (r->lit_parity ? 0 : set);
@@ -362,17 +378,17 @@ int pass_shade(ArcticRenderer *r, const ArcticScene *sc, const ArcticSettings *s
     ShadeParams sp;
     int rc = fill_shade_params(r, sc, st, d_out, sp);
     if (rc != ARCTIC_OK) return rc;
-    if (sp.light_evals) HIPCHECK(r, hipMemsetAsync(r->d_counter.p, 0, 8, r->stream));
+    if (sp.light_evals) HIPCHECK(r, hipMemsetAsync(r->d_counter.p, 0, 16, r->stream));
     HIPCHECK(r, shade_once(r, sp, r->launch));
     if (sp.light_evals) {
-        unsigned long long n = 0;
+        unsigned long long n[2] = {0, 0};
         std::vector<uint32_t> counts((size_t)r->launch.n_bands * LIT_SHARDS * LIT_COUNTER_STRIDE);
-        HIPCHECK(r, hipMemcpyAsync(&n, r->d_counter.p, 8, hipMemcpyDeviceToHost, r->stream));
-        HIPCHECK(r, hipMemcpyAsync(counts.data(), sp.lit_count, counts.size() * 4, hipMemcpyDeviceToHost, r->stream));
+        HIPCHECK(r, hipMemcpyAsync(n, r->d_counter.p, 16, hipMemcpyDeviceToHost, r->stream));
+        if (!r->launch.fused) HIPCHECK(r, hipMemcpyAsync(counts.data(), sp.lit_count, counts.size() * 4, hipMemcpyDeviceToHost, r->stream));
         HIPCHECK(r, hipStreamSynchronize(r->stream));
-        r->stats[5] = n;
-        r->stats[6] = 0;
-        for (uint32_t k = 0; k < r->launch.n_bands * LIT_SHARDS; ++k) r->stats[6] += counts[(size_t)k * LIT_COUNTER_STRIDE];
+        r->stats[5] = n[0];
+        r->stats[6] = n[1];   // fused kernel counts the lit pixels itself; the two-kernel pass leaves them in the stream counters
+        if (!r->launch.fused) for (uint32_t k = 0; k < r->launch.n_bands * LIT_SHARDS; ++k) r->stats[6] += counts[(size_t)k * LIT_COUNTER_STRIDE];
     }
     r->have_output = (d_out == nullptr);
     return ARCTIC_OK;
@@ -427,6 +443,8 @@ ArcticRenderer *arctic_create(const ArcticCreateInfo *info, char *err, uint64_t 
         r->launch.light_blocks = (uint32_t)std::max(1, prop.multiProcessorCount) * 24;
         r->launch.n_bands = 1;
         r->launch.lights_per_trip = 4;
+        r->launch.fused = 0; r->launch.fused_blocks = 0;
+        if (const char *f = std::getenv("ARCTIC_SHADE_FUSED")) r->launch.fused = std::atoi(f) ? 1u : 0u;   // default of ARCTIC_OPT_FUSED
         r->cu_count = (uint32_t)std::max(1, prop.multiProcessorCount);
         r->raster_blocks = (uint32_t)std::max(1, prop.multiProcessorCount) * 8;
         if ((e = hipHostMalloc((void **)&r->h_counts, 64)) != hipSuccess) return bail("hipHostMalloc", e);
@@ -465,7 +483,7 @@ void arctic_destroy(ArcticRenderer *r) {
     for (Mesh &m : r->meshes) { if (m.d_vertices) (void)hipFree(m.d_vertices); if (m.d_indices) (void)hipFree(m.d_indices); }
     for (void *p : r->tex_allocs) (void)hipFree(p);
     DevBuf *bufs[] = {&r->d_tex, &r->d_lut, &r->d_lights, &r->d_shadow, &r->d_env, &r->d_vis, &r->d_p0, &r->d_p1, &r->d_p2, &r->d_p3, &r->d_p4,
-                      &r->d_depth, &r->d_src, &r->d_rgba8, &r->d_ldr, &r->d_hdr, &r->d_counter, &r->d_lit0, &r->d_lit1, &r->d_lit2, &r->d_litpx, &r->d_litcount, &r->d_xverts, &r->d_sub_count, &r->d_sub_offset,
+                      &r->d_depth, &r->d_src, &r->d_rgba8, &r->d_ldr, &r->d_hdr, &r->d_counter, &r->d_tickets, &r->d_lit0, &r->d_lit1, &r->d_lit2, &r->d_litpx, &r->d_litcount, &r->d_xverts, &r->d_sub_count, &r->d_sub_offset,
                       &r->d_recs, &r->d_tile_count, &r->d_tile_offset, &r->d_scan, &r->d_stage, &r->tables[0].d, &r->tables[1].d};
     for (PassTables &T : r->tables) { if (T.h) (void)hipHostFree(T.h); if (T.copied) (void)hipEventDestroy(T.copied); }
     for (DevBuf *b : bufs) b->release();
@@ -804,9 +822,11 @@ int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value) {
     case ARCTIC_OPT_COUNT_LIGHT_EVALS: r->count_evals = value != 0; break;
     case ARCTIC_OPT_CULLING: r->culling = value != 0; break;
     case ARCTIC_OPT_DEBUG: r->debug = (int)value; break;
+    case ARCTIC_OPT_FUSED: r->launch.fused = value ? 1u : 0u; r->fused_lds = ~(size_t)0; break;
     case ARCTIC_OPT_LIGHT_KERNEL:   // tuning: value = lights per loop trip (2 or 4) + 16 * workgroups per CU
         if ((value & 15) != 2 && (value & 15) != 4) return r->fail(ARCTIC_E_INVALID, "set_option: light kernel variant must be 2 or 4");
         r->launch.lights_per_trip = (uint32_t)(value & 15);
+        r->fused_lds = ~(size_t)0;
         if (value >> 4) r->launch.light_blocks = r->cu_count * (uint32_t)(value >> 4);
         break;
     case ARCTIC_OPT_HDR16: r->hdr16 = value != 0; break;

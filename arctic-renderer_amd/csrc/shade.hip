@@ -423,32 +423,15 @@ __device__ __noinline__ f3 sample_environment(const float4 *__restrict__ env, ui
               w00 * a.z + w10 * b.z + w01 * c.z + w11 * d.z);
 }
 
-// ---- kernel 1: material fetch + shadow + classification ---------------------------------------------------------
-// LDS (dynamic): [0,256) sRGB LUT | texture descriptors, 4 dwords each
-__global__ __launch_bounds__(256) void k_material(const ShadeParams sp) {
-    extern __shared__ __align__(16) float smem[];
-    float *lut = smem;
-    uint4 *ldesc = reinterpret_cast<uint4 *>(smem + 256);
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (each with its own 4 MiB L2), so physical block b
-    // runs on XCD b % 8.  A workgroup = 4 horizontally adjacent tiles; XCD x takes the tile rows y = x (mod 8), walking
-    // each row left to right, so horizontal neighbours -- which share texture and shadow-map cache lines -- meet in the
-    // same L2, while all eight XCDs stay within 8 tile rows of each other in the G-buffer stream.  (Placement is a speed
-    // matter only; the grid is padded to whole groups of 8 rows and surplus blocks exit.)
-    const uint32_t bpr = (sp.tiles_x + 3) >> 2;                       // workgroups per tile row
-    const uint32_t xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
-    const uint32_t ty = ((idx / bpr) * sp.n_bands + sp.band) * 8 + xcd, tx = (idx % bpr) * 4 + wave;   // band: see launch_shade
-    const bool tile_ok = ty < sp.tiles_y && tx < sp.tiles_x;
-    const uint32_t t = ty * sp.tiles_x + tx;
-    TileHead cur;
-    if (tile_ok) cur = load_head(sp.g, (size_t)t * 64 + lane);   // in flight while LDS is staged
-    lut[threadIdx.x] = sp.srgb_lut[threadIdx.x];
-    for (uint32_t i = threadIdx.x; i < sp.n_materials * 3; i += 256) ldesc[i] = reinterpret_cast<const uint4 *>(sp.tex)[i];
-    __syncthreads();
-    if (!tile_ok) return;
-
-    const size_t gi = (size_t)t * 64 + lane;
+// ---- the material half of ps_main for one 8x8 tile (one wave) ------------------------------------------------------
+// forward.hlsl:98-124 (material fetch) + :64-96 (shadow test) + classification.  Pixels that need no light loop are
+// finished here (no geometry: skybox or black; fully shadowed: ambient * base); for every other pixel (`live`) the lane
+// gets the record the light loop needs.  Returns the ballot of live lanes.  Shared by k_material (two-kernel pass) and
+// k_shade_fused.
+struct LitRec { float4 r0, r1, r2; uint32_t px; };   // world.xyz, 1 - shadow | n.xyz, roughness | base.rgb, metalness | output index
+__device__ __forceinline__ unsigned long long material_tile(const ShadeParams &sp, const float *lut, const uint4 *ldesc, uint32_t ty, uint32_t tx,
+                                                            uint32_t lane, const TileHead &cur, bool &live, LitRec &rec) {
+    const size_t gi = ((size_t)ty * sp.tiles_x + tx) * 64 + lane;
     const uint32_t x = tx * 8 + (lane & 7);
     const int32_t y = (int32_t)(ty * 8 + (lane >> 3)) - (int32_t)sp.row0_in_tile;
     const bool in_frame = x < sp.width && y >= 0 && y < (int32_t)sp.rows;
@@ -468,8 +451,8 @@ __global__ __launch_bounds__(256) void k_material(const ShadeParams sp) {
     }
     // exact culling 1: Lo of ps_main is a sum of terms each multiplied by (1 - shadow) (point lights too: forward.hlsl:222,
     // 230), so a fully shadowed pixel is ambient * base and needs neither the sun, nor any point light, nor its normal,
-    // tangent frame, position, metalness or roughness.  Everything else goes to the lit-pixel stream.
-    const bool live = covered && (sp.culling ? lit != 0.0f : true);
+    // tangent frame, position, metalness or roughness.  Everything else goes to the light loop.
+    live = covered && (sp.culling ? lit != 0.0f : true);
     const unsigned long long m = __ballot(live);
     float4 gc, gd, ge;
     if (m != 0ull) { gc = sp.g.c[gi]; gd = sp.g.d[gi]; ge = sp.g.e[gi]; }   // second wave of loads: lit tiles only (48 B / pixel)
@@ -487,6 +470,51 @@ __global__ __launch_bounds__(256) void k_material(const ShadeParams sp) {
         }
         store_pixel(sp, o, c);
     }
+    if (live) {
+        float r = filt_unorm(t1, 0), g = 1.0f - filt_unorm(t1, 1), b = filt_unorm(t1, 2);   // normal.g = 1 - normal.g
+        r = r * 2.0f - 1.0f; g = g * 2.0f - 1.0f; b = b * 2.0f - 1.0f;
+        // mul(tbn, v), tbn columns t, b, n
+        const f3 T = mk(gc.w, gd.x, gd.y), B = mk(gd.z, gd.w, ge.x), N = mk(ge.y, ge.z, ge.w);
+        const f3 n = normalize(T * r + B * g + N * b);
+        const float rough = filt_unorm(t2, 1), metal = filt_unorm(t2, 2);   // .g, .b (forward.hlsl:117,123)
+        rec.r0 = make_float4(gc.x, gc.y, gc.z, lit);
+        rec.r1 = make_float4(n.x, n.y, n.z, rough);
+        rec.r2 = make_float4(base.x, base.y, base.z, metal);
+        rec.px = (uint32_t)o;
+    }
+    return m;
+}
+
+__device__ __forceinline__ void stage_material_lds(const ShadeParams &sp, float *lut, uint4 *ldesc) {
+    lut[threadIdx.x] = sp.srgb_lut[threadIdx.x];
+    for (uint32_t i = threadIdx.x; i < sp.n_materials * 3; i += 256) ldesc[i] = reinterpret_cast<const uint4 *>(sp.tex)[i];
+}
+
+// ---- kernel 1 of the two-kernel pass: material_tile over every tile, live pixels appended to the lit-pixel stream -----
+// LDS (dynamic): [0,256) sRGB LUT | texture descriptors, 4 dwords each
+__global__ __launch_bounds__(256) void k_material(const ShadeParams sp) {
+    extern __shared__ __align__(16) float smem[];
+    float *lut = smem;
+    uint4 *ldesc = reinterpret_cast<uint4 *>(smem + 256);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (each with its own 4 MiB L2), so physical block b
+    // runs on XCD b % 8.  A workgroup = 4 horizontally adjacent tiles; XCD x takes the tile rows y = x (mod 8), walking
+    // each row left to right, so horizontal neighbours -- which share texture and shadow-map cache lines -- meet in the
+    // same L2, while all eight XCDs stay within 8 tile rows of each other in the G-buffer stream.  (Placement is a speed
+    // matter only; the grid is padded to whole groups of 8 rows and surplus blocks exit.)
+    const uint32_t bpr = (sp.tiles_x + 3) >> 2;                       // workgroups per tile row
+    const uint32_t xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
+    const uint32_t ty = ((idx / bpr) * sp.n_bands + sp.band) * 8 + xcd, tx = (idx % bpr) * 4 + wave;   // band: see launch_shade
+    const bool tile_ok = ty < sp.tiles_y && tx < sp.tiles_x;
+    TileHead cur;
+    if (tile_ok) cur = load_head(sp.g, ((size_t)ty * sp.tiles_x + tx) * 64 + lane);   // in flight while LDS is staged
+    stage_material_lds(sp, lut, ldesc);
+    __syncthreads();
+    if (!tile_ok) return;
+    bool live;
+    LitRec rec;
+    const unsigned long long m = material_tile(sp, lut, ldesc, ty, tx, lane, cur, live, rec);
     // wave-wide compaction of the live pixels into this workgroup's SHARD of the stream (one atomicAdd per wave, on one
     // of LIT_SHARDS counters each on its own 128-byte line: a single counter would serialise at ~88 atomics/us)
     if (m != 0ull) {
@@ -495,45 +523,95 @@ __global__ __launch_bounds__(256) void k_material(const ShadeParams sp) {
         if (lane == first) slot0 = atomicAdd(sp.lit_count + (sp.band * LIT_SHARDS + shard) * LIT_COUNTER_STRIDE, (uint32_t)__popcll(m));
         slot0 = __shfl(slot0, (int)first);
         if (live) {
-            float r = filt_unorm(t1, 0), g = 1.0f - filt_unorm(t1, 1), b = filt_unorm(t1, 2);   // normal.g = 1 - normal.g
-            r = r * 2.0f - 1.0f; g = g * 2.0f - 1.0f; b = b * 2.0f - 1.0f;
-            // mul(tbn, v), tbn columns t, b, n
-            const f3 T = mk(gc.w, gd.x, gd.y), B = mk(gd.z, gd.w, ge.x), N = mk(ge.y, ge.z, ge.w);
-            const f3 n = normalize(T * r + B * g + N * b);
-            const float rough = filt_unorm(t2, 1), metal = filt_unorm(t2, 2);   // .g, .b (forward.hlsl:117,123)
             const size_t slot = (size_t)(sp.band * LIT_SHARDS + shard) * sp.lit_shard_cap + slot0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            sp.lit_r0[slot] = make_float4(gc.x, gc.y, gc.z, lit);
-            sp.lit_r1[slot] = make_float4(n.x, n.y, n.z, rough);
-            sp.lit_r2[slot] = make_float4(base.x, base.y, base.z, metal);
-            sp.lit_px[slot] = (uint32_t)o;
+            sp.lit_r0[slot] = rec.r0;
+            sp.lit_r1[slot] = rec.r1;
+            sp.lit_r2[slot] = rec.r2;
+            sp.lit_px[slot] = rec.px;
         }
     }
 }
 
-// ---- kernel 2: the sun + point lights over the lit-pixel stream, tonemap, store ----------------------------------
-// LDS (dynamic): the point lights as PAIRS, 12 floats per pair {x0,x1, y0,y1, z0,z1, r0,r1, g0,g1, b0,b1}; every lane reads
+// ---- the light half of ps_main for one lit pixel per lane: the sun + every point light, tonemap, store --------------
+// LDS image of the point lights: PAIRS, 12 floats per pair {x0,x1, y0,y1, z0,z1, r0,r1, g0,g1, b0,b1}; every lane reads
 // the same address, so a pair costs three broadcast ds_read_b128.  The count is padded to a multiple of 4 with black lights.
-// Persistent: gridDim.x workgroups; wave w works on shard w % LIT_SHARDS of the stream and takes every
-// (n_waves / LIT_SHARDS)-th 64-pixel group of it.
-template <int LIGHTS_PER_TRIP>
-__global__ __launch_bounds__(256) void k_light(const ShadeParams sp) {
-    extern __shared__ __align__(16) float smem[];
-    float4 *llights = reinterpret_cast<float4 *>(smem);
-    const uint32_t n_quads = (sp.n_lights + 3) >> 2, n_pairs = 2 * n_quads;
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+__device__ __forceinline__ void stage_lights_lds(const ShadeParams &sp, float4 *llights) {
+    const uint32_t n_pairs = 2 * ((sp.n_lights + 3) >> 2);
     for (uint32_t i = threadIdx.x; i < 2 * n_pairs; i += 256) {
         float4 lp = make_float4(0.0f, 1.0e6f, 0.0f, 0.0f), lc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // pad: colour 0
         if (i < sp.n_lights) { lp = sp.lights[2 * i]; lc = sp.lights[2 * i + 1]; }
         float *dst = reinterpret_cast<float *>(llights) + (size_t)(i >> 1) * 12 + (i & 1);
         dst[0] = lp.x; dst[2] = lp.y; dst[4] = lp.z; dst[6] = lc.x; dst[8] = lc.y; dst[10] = lc.z;
     }
+}
+
+template <int LIGHTS_PER_TRIP>
+__device__ __forceinline__ void light_pixel(const ShadeParams &sp, const float4 *llights, uint32_t lane, float4 r0, float4 r1, float4 r2, uint32_t o) {
+    const uint32_t n_quads = (sp.n_lights + 3) >> 2, n_pairs = 2 * n_quads;
+    const f3 eye = mk(sp.eye[0], sp.eye[1], sp.eye[2]);
+    const f3 world = mk(r0.x, r0.y, r0.z), n = mk(r1.x, r1.y, r1.z), base = mk(r2.x, r2.y, r2.z);
+    const f3 wo = normalize(eye - world);
+    const Pix px = make_pix(n, wo, world, base, r2.w, r1.w);
+    f3 sun = mk(0.0f, 0.0f, 0.0f);
+    {   // the sun: wi = -sun_dir, radiance = sun_color (forward.hlsl:221-222)
+        const f3 d = mk(-sp.sun_dir[0], -sp.sun_dir[1], -sp.sun_dir[2]);
+        accumulate_light<false>(px, d, dot(n, d), mk(sp.sun_color[0], sp.sun_color[1], sp.sun_color[2]), sun);
+    }
+    LightSums S;
+    S.clear();
+    const v2 wx = splat(world.x), wy = splat(world.y), wz = splat(world.z);
+    // two pairs (four lights) per trip: the two evaluations are independent, which gives the scheduler instructions to
+    // put between dependent packed operations (n_quads = ceil(n_pairs / 2); the LDS image is padded with black lights)
+    if (LIGHTS_PER_TRIP == 4)
+    for (uint32_t q = 0; q < n_quads; ++q) {
+        const float4 A0 = llights[6 * q], B0 = llights[6 * q + 1], C0 = llights[6 * q + 2];
+        const float4 A1 = llights[6 * q + 3], B1 = llights[6 * q + 4], C1 = llights[6 * q + 5];
+        const v2 dx0 = (v2){A0.x, A0.y} - wx, dy0 = (v2){A0.z, A0.w} - wy, dz0 = (v2){B0.x, B0.y} - wz;
+        const v2 dx1 = (v2){A1.x, A1.y} - wx, dy1 = (v2){A1.z, A1.w} - wy, dz1 = (v2){B1.x, B1.y} - wz;
+        const v2 nd0 = fma2(splat(n.z), dz0, fma2(splat(n.y), dy0, splat(n.x) * dx0));
+        const v2 nd1 = fma2(splat(n.z), dz1, fma2(splat(n.y), dy1, splat(n.x) * dx1));
+        // exact culling 2: n.wi <= 0 zeroes a light (forward.hlsl:191-192); skip the trip when that holds for all four
+        // lights in every lane of the wave
+        if (sp.culling && __ballot(nd0.x > 0.0f || nd0.y > 0.0f || nd1.x > 0.0f || nd1.y > 0.0f) == 0ull) continue;
+        accumulate_pair(px, dx0, dy0, dz0, nd0, (v2){B0.z, B0.w}, (v2){C0.x, C0.y}, (v2){C0.z, C0.w}, S);
+        accumulate_pair(px, dx1, dy1, dz1, nd1, (v2){B1.z, B1.w}, (v2){C1.x, C1.y}, (v2){C1.z, C1.w}, S);
+        if (sp.light_evals) {
+            const unsigned long long active = __ballot(1);
+            const uint32_t k = min(4u, sp.n_lights - 4 * q);
+            if (lane == (uint32_t)__ffsll((long long)active) - 1) atomicAdd(sp.light_evals, (unsigned long long)__popcll(active) * k);
+        }
+    }
+    if (LIGHTS_PER_TRIP == 2)
+    for (uint32_t p = 0; p < n_pairs; ++p) {
+        const float4 A = llights[3 * p], Bq = llights[3 * p + 1], C = llights[3 * p + 2];
+        const v2 dx = (v2){A.x, A.y} - wx, dy = (v2){A.z, A.w} - wy, dz = (v2){Bq.x, Bq.y} - wz;
+        const v2 nd = fma2(splat(n.z), dz, fma2(splat(n.y), dy, splat(n.x) * dx));
+        if (sp.culling && __ballot(nd.x > 0.0f || nd.y > 0.0f) == 0ull) continue;
+        accumulate_pair(px, dx, dy, dz, nd, (v2){Bq.z, Bq.w}, (v2){C.x, C.y}, (v2){C.z, C.w}, S);
+        if (sp.light_evals) {
+            const unsigned long long active = __ballot(1);
+            const uint32_t k = min(2u, sp.n_lights > 2 * p ? sp.n_lights - 2 * p : 0u);
+            if (lane == (uint32_t)__ffsll((long long)active) - 1) atomicAdd(sp.light_evals, (unsigned long long)__popcll(active) * k);
+        }
+    }
+    store_pixel(sp, o, (sun + S.resolve(px)) * r0.w + base * sp.ambient);   // r0.w = 1 - shadow
+}
+
+// ---- kernel 2 of the two-kernel pass: light_pixel over the lit-pixel stream ------------------------------------------
+// LDS (dynamic): the light pairs.  Persistent: gridDim.x workgroups; wave w works on shard w % LIT_SHARDS of the stream
+// and takes every (n_waves / LIT_SHARDS)-th 64-pixel group of it.
+template <int LIGHTS_PER_TRIP>
+__global__ __launch_bounds__(256) void k_light(const ShadeParams sp) {
+    extern __shared__ __align__(16) float smem[];
+    float4 *llights = reinterpret_cast<float4 *>(smem);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    stage_lights_lds(sp, llights);
     __syncthreads();
     // the stream counters are double-buffered: this pass reads the set k_material has just filled and clears the other
     // one for the next pass's k_material -- no memset launch between passes
     if (blockIdx.x == 0)
         for (uint32_t i = threadIdx.x; i < sp.n_bands * LIT_SHARDS; i += 256) sp.lit_count_next[i * LIT_COUNTER_STRIDE] = 0;
-    const f3 eye = mk(sp.eye[0], sp.eye[1], sp.eye[2]);
     const uint32_t w = blockIdx.x * 4 + wave, n_waves = gridDim.x * 4;
     const bool wide = n_waves >= LIT_SHARDS;
     const uint32_t nsub = wide ? n_waves / LIT_SHARDS : 1u, sub = wide ? w / LIT_SHARDS : 0u;
@@ -542,54 +620,78 @@ __global__ __launch_bounds__(256) void k_light(const ShadeParams sp) {
     for (uint32_t count = sp.lit_count[(sp.band * LIT_SHARDS + shard) * LIT_COUNTER_STRIDE], grp = sub; grp * 64 < count; grp += nsub) {
         if (grp * 64 + lane >= count) continue;
         const size_t i = (size_t)(sp.band * LIT_SHARDS + shard) * sp.lit_shard_cap + grp * 64 + lane;
-        const float4 r0 = sp.lit_r0[i], r1 = sp.lit_r1[i], r2 = sp.lit_r2[i];
-        const uint32_t o = sp.lit_px[i];
-        const f3 world = mk(r0.x, r0.y, r0.z), n = mk(r1.x, r1.y, r1.z), base = mk(r2.x, r2.y, r2.z);
-        const f3 wo = normalize(eye - world);
-        const Pix px = make_pix(n, wo, world, base, r2.w, r1.w);
-        f3 sun = mk(0.0f, 0.0f, 0.0f);
-        {   // the sun: wi = -sun_dir, radiance = sun_color (forward.hlsl:221-222)
-            const f3 d = mk(-sp.sun_dir[0], -sp.sun_dir[1], -sp.sun_dir[2]);
-            accumulate_light<false>(px, d, dot(n, d), mk(sp.sun_color[0], sp.sun_color[1], sp.sun_color[2]), sun);
-        }
-        LightSums S;
-        S.clear();
-        const v2 wx = splat(world.x), wy = splat(world.y), wz = splat(world.z);
-        // two pairs (four lights) per trip: the two evaluations are independent, which gives the scheduler instructions to
-        // put between dependent packed operations (n_quads = ceil(n_pairs / 2); the LDS image is padded with black lights)
-        if (LIGHTS_PER_TRIP == 4)
-        for (uint32_t q = 0; q < n_quads; ++q) {
-            const float4 A0 = llights[6 * q], B0 = llights[6 * q + 1], C0 = llights[6 * q + 2];
-            const float4 A1 = llights[6 * q + 3], B1 = llights[6 * q + 4], C1 = llights[6 * q + 5];
-            const v2 dx0 = (v2){A0.x, A0.y} - wx, dy0 = (v2){A0.z, A0.w} - wy, dz0 = (v2){B0.x, B0.y} - wz;
-            const v2 dx1 = (v2){A1.x, A1.y} - wx, dy1 = (v2){A1.z, A1.w} - wy, dz1 = (v2){B1.x, B1.y} - wz;
-            const v2 nd0 = fma2(splat(n.z), dz0, fma2(splat(n.y), dy0, splat(n.x) * dx0));
-            const v2 nd1 = fma2(splat(n.z), dz1, fma2(splat(n.y), dy1, splat(n.x) * dx1));
-            // exact culling 2: n.wi <= 0 zeroes a light (forward.hlsl:191-192); skip the trip when that holds for all four
-            // lights in every lane of the wave
-            if (sp.culling && __ballot(nd0.x > 0.0f || nd0.y > 0.0f || nd1.x > 0.0f || nd1.y > 0.0f) == 0ull) continue;
-            accumulate_pair(px, dx0, dy0, dz0, nd0, (v2){B0.z, B0.w}, (v2){C0.x, C0.y}, (v2){C0.z, C0.w}, S);
-            accumulate_pair(px, dx1, dy1, dz1, nd1, (v2){B1.z, B1.w}, (v2){C1.x, C1.y}, (v2){C1.z, C1.w}, S);
-            if (sp.light_evals) {
-                const unsigned long long active = __ballot(1);
-                const uint32_t k = min(4u, sp.n_lights - 4 * q);
-                if (lane == (uint32_t)__ffsll((long long)active) - 1) atomicAdd(sp.light_evals, (unsigned long long)__popcll(active) * k);
+        light_pixel<LIGHTS_PER_TRIP>(sp, llights, lane, sp.lit_r0[i], sp.lit_r1[i], sp.lit_r2[i], sp.lit_px[i]);
+    }
+}
+
+// ---- the whole pass in ONE persistent kernel: material_tile and light_pixel decoupled through a per-wave LDS queue ----
+// k_material is bound by memory and k_light by the FP32 VALU; run back to back each leaves the other resource idle, and
+// the lit-pixel stream between them costs 52 B written + 52 B read per lit pixel.  Here every wave takes tiles from a
+// ticket counter, runs the material half, and appends the live pixels to ITS OWN queue in LDS (128 records); whenever
+// the queue holds 64 it pops them and runs the light half with all 64 lanes busy.  Waves of one SIMD are in different
+// phases at any moment, so memory waits of one overlap the arithmetic of another, and the stream never touches HBM.
+// No wave ever waits for another one (no barrier after the prologue, no inter-wave flag): nothing can deadlock.
+// Tickets: one counter per XCD (128 B apart); XCD x walks the tile rows y = x (mod 8) left to right like k_material,
+// then steals from the other XCDs' rows.  The last wave to leave resets the counters for the next pass.
+// LDS (dynamic): sRGB LUT | texture descriptors | light pairs | 4 queues x 128 x (3 float4 + 1 dword)
+constexpr uint32_t FQ_CAP = 128, TICKET_STRIDE = 32, FT_BATCH = 4;
+template <int LIGHTS_PER_TRIP>
+__global__ __launch_bounds__(256) void k_shade_fused(const ShadeParams sp) {
+    extern __shared__ __align__(16) float smem[];
+    float *lut = smem;
+    uint4 *ldesc = reinterpret_cast<uint4 *>(smem + 256);
+    float4 *llights = reinterpret_cast<float4 *>(smem + 256 + (size_t)sp.n_materials * 12);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float4 *q0 = llights + (size_t)((sp.n_lights + 3) >> 2) * 6 + (size_t)wave * (3 * FQ_CAP + FQ_CAP / 4);
+    float4 *q1 = q0 + FQ_CAP, *q2 = q1 + FQ_CAP;
+    uint32_t *qp = reinterpret_cast<uint32_t *>(q2 + FQ_CAP);
+    stage_material_lds(sp, lut, ldesc);
+    stage_lights_lds(sp, llights);
+    __syncthreads();
+    const uint32_t xcd = blockIdx.x & 7u;
+    uint32_t qn = 0, lit_px = 0;   // wave-uniform: records queued; lit pixels seen
+    const uint32_t bpr = (sp.tiles_x + FT_BATCH - 1) / FT_BATCH;   // tickets per tile row: one ticket = FT_BATCH adjacent tiles
+    for (uint32_t k = 0; k < 8; ++k) {
+        const uint32_t src = (xcd + k) & 7u;
+        if (src >= sp.tiles_y) continue;
+        const uint32_t total = ((sp.tiles_y - 1 - src) / 8 + 1) * bpr;   // tickets of the rows y = src (mod 8)
+        // a same-address atomic retires at ~88 per microsecond: FT_BATCH tiles per ticket keeps the eight counters far
+        // below that, and the NEXT ticket is requested before the current batch is processed, so its round trip is hidden
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(sp.tickets + src * TICKET_STRIDE, 1u);
+        t = __builtin_amdgcn_readfirstlane(t);
+        while (t < total) {
+            uint32_t t_next = 0;
+            if (lane == 0) t_next = atomicAdd(sp.tickets + src * TICKET_STRIDE, 1u);
+            const uint32_t ty = (t / bpr) * 8 + src, tx0 = (t % bpr) * FT_BATCH;
+            for (uint32_t tx = tx0; tx < min(tx0 + FT_BATCH, sp.tiles_x); ++tx) {
+                const TileHead cur = load_head(sp.g, ((size_t)ty * sp.tiles_x + tx) * 64 + lane);
+                bool live;
+                LitRec rec;
+                const unsigned long long m = material_tile(sp, lut, ldesc, ty, tx, lane, cur, live, rec);
+                if (m == 0ull) continue;
+                if (live) {
+                    const uint32_t slot = qn + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    q0[slot] = rec.r0; q1[slot] = rec.r1; q2[slot] = rec.r2; qp[slot] = rec.px;
+                }
+                const uint32_t add = (uint32_t)__popcll(m);
+                qn += add; lit_px += add;
+                if (qn >= 64) {   // pop the newest 64 (LDS operations of one wave execute in order: the records are there)
+                    qn -= 64;
+                    light_pixel<LIGHTS_PER_TRIP>(sp, llights, lane, q0[qn + lane], q1[qn + lane], q2[qn + lane], qp[qn + lane]);
+                }
             }
+            t = __builtin_amdgcn_readfirstlane(t_next);
         }
-        if (LIGHTS_PER_TRIP == 2)
-        for (uint32_t p = 0; p < n_pairs; ++p) {
-            const float4 A = llights[3 * p], Bq = llights[3 * p + 1], C = llights[3 * p + 2];
-            const v2 dx = (v2){A.x, A.y} - wx, dy = (v2){A.z, A.w} - wy, dz = (v2){Bq.x, Bq.y} - wz;
-            const v2 nd = fma2(splat(n.z), dz, fma2(splat(n.y), dy, splat(n.x) * dx));
-            if (sp.culling && __ballot(nd.x > 0.0f || nd.y > 0.0f) == 0ull) continue;
-            accumulate_pair(px, dx, dy, dz, nd, (v2){Bq.z, Bq.w}, (v2){C.x, C.y}, (v2){C.z, C.w}, S);
-            if (sp.light_evals) {
-                const unsigned long long active = __ballot(1);
-                const uint32_t k = min(2u, sp.n_lights > 2 * p ? sp.n_lights - 2 * p : 0u);
-                if (lane == (uint32_t)__ffsll((long long)active) - 1) atomicAdd(sp.light_evals, (unsigned long long)__popcll(active) * k);
-            }
+    }
+    if (lane < qn) light_pixel<LIGHTS_PER_TRIP>(sp, llights, lane, q0[lane], q1[lane], q2[lane], qp[lane]);
+    if (lane == 0) {
+        if (sp.light_evals && lit_px) atomicAdd(sp.light_evals + 1, (unsigned long long)lit_px);
+        const uint32_t done = atomicAdd(sp.tickets + 8 * TICKET_STRIDE, 1u);
+        if (done == gridDim.x * 4 - 1) {   // every other wave has taken its last ticket: reset for the next pass
+            for (uint32_t i = 0; i <= 8; ++i) sp.tickets[i * TICKET_STRIDE] = 0;
         }
-        store_pixel(sp, o, (sun + S.resolve(px)) * r0.w + base * sp.ambient);   // r0.w = 1 - shadow
     }
 }
 
@@ -621,6 +723,14 @@ hipError_t launch_shade(const ShadeParams &sp0, const ShadeLaunch &L) {
     hipError_t e = hipSuccess;
     const size_t lds_a = (256 + (size_t)sp.n_materials * 12) * sizeof(float);
     const size_t lds_b = std::max<size_t>(96, (size_t)((sp.n_lights + 3) / 4) * 96);
+    if (L.fused) {
+        sp.n_bands = 1; sp.band = 0;
+        const size_t lds = fused_lds_bytes(sp.n_materials, sp.n_lights);
+        if (L.mid && (e = hipEventRecord(L.mid, L.main)) != hipSuccess) return e;   // per-kernel timing: "k_material" part is empty
+        if (L.lights_per_trip == 2) k_shade_fused<2><<<std::max(1u, L.fused_blocks), 256, lds, L.main>>>(sp);
+        else k_shade_fused<4><<<std::max(1u, L.fused_blocks), 256, lds, L.main>>>(sp);
+        return hipGetLastError();
+    }
     for (uint32_t k = 0; k < n_bands; ++k) {
         sp.band = k;
         const uint32_t groups = (row_groups - k + n_bands - 1) / n_bands;
@@ -642,6 +752,18 @@ hipError_t launch_shade(const ShadeParams &sp0, const ShadeLaunch &L) {
         if ((e = hipStreamWaitEvent(L.main, L.aux_done, 0)) != hipSuccess) return e;
     }
     return hipSuccess;
+}
+
+size_t fused_lds_bytes(uint32_t n_materials, uint32_t n_lights) {
+    return (256 + (size_t)n_materials * 12) * sizeof(float) + (size_t)((n_lights + 3) / 4) * 96 + 4 * (size_t)(3 * FQ_CAP + FQ_CAP / 4) * 16;
+}
+
+// resident workgroups per CU of the fused kernel for this LDS size (the persistent grid is CUs x this)
+int fused_blocks_per_cu(size_t lds_bytes, uint32_t lights_per_trip) {
+    int n = 0;
+    hipError_t e = lights_per_trip == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_shade_fused<2>, 256, lds_bytes)
+                                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_shade_fused<4>, 256, lds_bytes);
+    return e == hipSuccess ? n : 0;
 }
 
 hipError_t launch_post_process(const float4 *hdr, uint32_t w, uint32_t h, int32_t tm, float inv_gamma, float exposure,

@@ -264,6 +264,7 @@ int arctic_stats(ArcticRenderer *r, uint64_t *out, uint32_t n);
 #define ARCTIC_OPT_HDR16             6 /* 1 = round ps_main's colour through binary16 before post_process, like the reference's
                                         R16G16B16A16_FLOAT colour target (forward_pass.cpp:149, renderer.cpp:128-144); default 0 = fp32 */
 #define ARCTIC_OPT_LIGHT_KERNEL      7 /* tuning: lights per loop trip of k_light (2 or 4) + 16 * persistent workgroups per CU */
+#define ARCTIC_OPT_FUSED             8 /* 1 = the shading pass as ONE persistent kernel (material and light halves decoupled through LDS queues); 0 = k_material + k_light */
 #define ARCTIC_OPT_BANDS             5 /* 1..16 interleaved screen bands the two shading kernels are pipelined over (default 1: no gain measured) */
 int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value);
 

@@ -101,6 +101,33 @@ def test_culling_is_exact(pair):
     assert np.abs(a - b).max() <= 2e-6
 
 
+def test_fused_kernel_equals_two_kernel_pass(pair):
+    """ARCTIC_OPT_FUSED: the single persistent kernel (LDS queues between the material and light halves) runs the same
+    per-pixel arithmetic as k_material + k_light; only the grouping of pixels into waves differs."""
+    sc, o, r = pair
+    r.pass_shade(sc.desc, sc.settings)
+    a_ldr, a_hdr, a_rgba = (x.copy() for x in r.read_output())
+    r.set_option("fused", 1)
+    try:
+        for _ in range(2):   # twice: the kernel resets its own ticket counters for the next pass
+            r.pass_shade(sc.desc, sc.settings)
+            b_ldr, b_hdr, b_rgba = r.read_output()
+            assert np.abs(a_ldr - b_ldr).max() <= 2e-6
+            np.testing.assert_array_equal(a_rgba[..., 3], b_rgba[..., 3])
+            assert np.abs(a_rgba.astype(np.int16) - b_rgba.astype(np.int16)).max() <= 1
+        r.set_option("count_light_evals", 1)
+        r.pass_shade(sc.desc, sc.settings)
+        fused_stats = r.stats()
+        r.set_option("fused", 0)
+        r.pass_shade(sc.desc, sc.settings)
+        split_stats = r.stats()
+        assert fused_stats[6] == split_stats[6]                           # same lit pixels
+        assert abs(int(fused_stats[5]) - int(split_stats[5])) <= 0.05 * max(int(split_stats[5]), 1)   # wave-level skips depend on the grouping
+    finally:
+        r.set_option("count_light_evals", 0)
+        r.set_option("fused", 0)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # beyond the per-scene fixtures: sharding, odd inputs, the stand-alone post-process kernel, full-size properties
 # ---------------------------------------------------------------------------------------------------------------
