@@ -336,7 +336,7 @@ int fill_shade_params(ArcticRenderer *r, const ArcticScene *sc, const ArcticSett
         HIPCHECK(r, r->d_hdr.ensure(out_px * 12));
         sp.out_ldr = r->d_ldr.as<float>(); sp.out_hdr = r->d_hdr.as<float>();
     }
-    sp.light_evals = r->count_evals ? r->d_counter.as<unsigned long long>() : nullptr;
+    sp.light_evals = r->count_evals == 1 ? r->d_counter.as<unsigned long long>() : nullptr;   // 2: lit pixels only, no atomics in the loop
     sp.culling = r->culling;
     sp.debug = r->debug;
     sp.hdr16 = r->hdr16;
@@ -378,15 +378,17 @@ int pass_shade(ArcticRenderer *r, const ArcticScene *sc, const ArcticSettings *s
     ShadeParams sp;
     int rc = fill_shade_params(r, sc, st, d_out, sp);
     if (rc != ARCTIC_OK) return rc;
+    const bool fused_count = r->launch.fused && r->count_evals;   // the fused kernel has no stream counters: it counts lit pixels itself
+    if (fused_count) sp.light_evals = r->d_counter.as<unsigned long long>();
     if (sp.light_evals) HIPCHECK(r, hipMemsetAsync(r->d_counter.p, 0, 16, r->stream));
     HIPCHECK(r, shade_once(r, sp, r->launch));
-    if (sp.light_evals) {
+    if (r->count_evals) {
         unsigned long long n[2] = {0, 0};
         std::vector<uint32_t> counts((size_t)r->launch.n_bands * LIT_SHARDS * LIT_COUNTER_STRIDE);
-        HIPCHECK(r, hipMemcpyAsync(n, r->d_counter.p, 16, hipMemcpyDeviceToHost, r->stream));
+        if (sp.light_evals) HIPCHECK(r, hipMemcpyAsync(n, r->d_counter.p, 16, hipMemcpyDeviceToHost, r->stream));
         if (!r->launch.fused) HIPCHECK(r, hipMemcpyAsync(counts.data(), sp.lit_count, counts.size() * 4, hipMemcpyDeviceToHost, r->stream));
         HIPCHECK(r, hipStreamSynchronize(r->stream));
-        r->stats[5] = n[0];
+        r->stats[5] = r->count_evals == 1 ? n[0] : 0;
         r->stats[6] = n[1];   // fused kernel counts the lit pixels itself; the two-kernel pass leaves them in the stream counters
         if (!r->launch.fused) for (uint32_t k = 0; k < r->launch.n_bands * LIT_SHARDS; ++k) r->stats[6] += counts[(size_t)k * LIT_COUNTER_STRIDE];
     }
@@ -819,7 +821,7 @@ int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value) {
     if (!r) return ARCTIC_E_INVALID;
     switch (option) {
     case ARCTIC_OPT_KEEP_FLOAT_OUTPUT: r->keep_float = value != 0; break;
-    case ARCTIC_OPT_COUNT_LIGHT_EVALS: r->count_evals = value != 0; break;
+    case ARCTIC_OPT_COUNT_LIGHT_EVALS: r->count_evals = value == 2 ? 2 : (value != 0); break;
     case ARCTIC_OPT_CULLING: r->culling = value != 0; break;
     case ARCTIC_OPT_DEBUG: r->debug = (int)value; break;
     case ARCTIC_OPT_FUSED: r->launch.fused = value ? 1u : 0u; r->fused_lds = ~(size_t)0; break;

@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="<1 shrinks the workload (debug only; makes the number invalid)")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline shades (0 = auto)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--extras", action="store_true", help="also time the pass with culling off and count the executed light evaluations "
+                    "(extra, slower launches of the same kernels: keep them out of a rocprofv3 --stats run of this command)")
     args = ap.parse_args()
 
     import torch
@@ -189,27 +191,38 @@ def main():
 
     pass_ms, mat_ms, light_ms = float(np.mean(ms)), float(np.mean(ms_mat)), float(np.mean(ms_light))
     achieved = shaded_local * BYTES_PER_PIXEL / (pass_ms * 1e-3) / 1e9
-    # the same pass with the exact culling disabled: every covered pixel evaluates the sun and all n_lights
-    r.set_option("culling", 0)
-    ms_nocull = float(np.mean(r.time_shade(sc.desc, sc.settings, warmup=2, iters=10)))
-    r.set_option("culling", 1)
-    r.set_option("count_light_evals", 1)
+    # lit pixels of this pass (read back from the stream counters; the kernels run exactly as in the timed loop)
+    r.set_option("count_light_evals", 2)
     r.pass_shade(sc.desc, sc.settings)
     r.flush()
-    st = r.stats()
-    light_evals, lit_px = int(st[5]), int(st[6])
+    lit_px = int(r.stats()[6])
     r.set_option("count_light_evals", 0)
-    # bytes each kernel really moves (its own figure, next to the 80 B/px algorithmic one)
-    mat_bytes = shaded_local * 76 + (shaded_local - lit_px) * 4 + lit_px * 52
-    light_bytes = lit_px * (52 + 4)
-
+    light_evals, ms_nocull = lit_px * len(sc.lights), None   # every lit pixel evaluates every point light (+ the sun)
+    if args.extras:
+        # not in the default run, so that a rocprofv3 --stats average over this command's launches is the timed kernel's:
+        # the same pass with the exact culling disabled (every covered pixel evaluates the sun and all n_lights) ...
+        r.set_option("culling", 0)
+        ms_nocull = float(np.mean(r.time_shade(sc.desc, sc.settings, warmup=2, iters=10)))
+        r.set_option("culling", 1)
+        # ... and the light evaluations actually executed, counted with atomics in the loop (wave-level skips included)
+        r.set_option("count_light_evals", 1)
+        r.pass_shade(sc.desc, sc.settings)
+        r.flush()
+        light_evals = int(r.stats()[5])
+        r.set_option("count_light_evals", 0)
+    # bytes each kernel really moves: from the committed counter passes (profiles/pmc_latest.json: 2 x FETCH_SIZE + WRITE_SIZE
+    # per launch of that kernel), divided by the time measured live here
+    mat_bytes = light_bytes = None
     result = None
     if rank == 0:
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc_path) and world == 1 and args.scale == 1.0 and args.config == 3:
             try:
-                traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+                pmc = json.load(open(pmc_path))
+                traffic = pmc.get("hbm_bytes_per_launch")
+                mat_bytes = (2 * pmc["FETCH_SIZE_KB"]["k_material"] + pmc["WRITE_SIZE_KB"]["k_material"]) * 1024
+                light_bytes = (2 * pmc["FETCH_SIZE_KB"]["k_light"] + pmc["WRITE_SIZE_KB"]["k_light"]) * 1024
             except Exception:
                 traffic = None
         value = args.steps * shaded / dt / 1e6
@@ -227,8 +240,8 @@ def main():
                          "kernel": "k_material + k_light (the shading pass)", "kernel_ms": round(pass_ms, 4),
                          "kernel_ms_p10_p50_p90": [round(float(np.percentile(ms, q)), 4) for q in (10, 50, 90)],
                          "bytes_per_pixel": BYTES_PER_PIXEL,
-                         "k_material_ms": round(mat_ms, 4), "k_material_GBps": round(mat_bytes / (mat_ms * 1e-3) / 1e9, 1),
-                         "k_light_ms": round(light_ms, 4), "k_light_GBps": round(light_bytes / (light_ms * 1e-3) / 1e9, 1),
+                         "k_material_ms": round(mat_ms, 4), "k_material_hbm_GBps": round(mat_bytes / (mat_ms * 1e-3) / 1e9, 1) if mat_bytes else None,
+                         "k_light_ms": round(light_ms, 4), "k_light_hbm_GBps": round(light_bytes / (light_ms * 1e-3) / 1e9, 1) if light_bytes else None,
                          "k_light_bound": "fp32 valu", "lit_pixel_fraction": round(lit_px / max(shaded_local, 1), 4),
                          "point_light_evals_per_lit_pixel": round(light_evals / max(lit_px, 1), 2),
                          "point_light_evals_per_pixel": round(light_evals / max(shaded_local, 1), 2),
@@ -238,8 +251,8 @@ def main():
                                   "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s (FMA = 2, issue-slot equivalents)",
                                   "frac": round(light_evals * VALU_FLOPS_PER_LIGHT_EVAL / (light_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4),
                                   "kernel": "k_light", "binds": True},
-                         "kernel_ms_no_culling": round(ms_nocull, 4),
-                         "achieved_no_culling": round(shaded_local * BYTES_PER_PIXEL / (ms_nocull * 1e-3) / 1e9, 1)},
+                         "kernel_ms_no_culling": round(ms_nocull, 4) if ms_nocull else None,
+                         "achieved_no_culling": round(shaded_local * BYTES_PER_PIXEL / (ms_nocull * 1e-3) / 1e9, 1) if ms_nocull else None},
         }
         if world == 1 and not args.no_cpu:
             result["cpu_baseline"] = cpu_baseline(pkg, sc, r, args.cpu_rows)

@@ -258,7 +258,8 @@ int arctic_stats(ArcticRenderer *r, uint64_t *out, uint32_t n);
 
 /* tuning / debug switches. */
 #define ARCTIC_OPT_KEEP_FLOAT_OUTPUT 1 /* 1 = shade also stores float LDR+HDR planes (tests); 0 = RGBA8 only (bench) */
-#define ARCTIC_OPT_COUNT_LIGHT_EVALS 2 /* 1 = shade counts evaluated lights per pixel (slower) */
+#define ARCTIC_OPT_COUNT_LIGHT_EVALS 2 /* 1 = shade counts evaluated lights (stats[5], atomics in the light loop: slower) and lit pixels (stats[6]);
+                                          2 = lit pixels only (read back from the stream counters, the kernels run at full speed) */
 #define ARCTIC_OPT_CULLING           3 /* 0 = evaluate every light for every pixel; 1 = exact wave-level culling (default) */
 #define ARCTIC_OPT_DEBUG             4 /* timing experiments only (wrong images): bit 0 skip material textures, bit 1 skip shadow test */
 #define ARCTIC_OPT_HDR16             6 /* 1 = round ps_main's colour through binary16 before post_process, like the reference's
