@@ -86,6 +86,9 @@ struct ArcticRenderer {
     uint32_t raster_blocks = 2048;  // persistent grid of k_raster
     DevBuf d_tickets;               // fused shading kernel: tile tickets (zeroed once; the kernel resets them itself)
     size_t fused_lds = ~(size_t)0; int fused_per_cu = 0;   // cached occupancy query
+    // render_frame re-renders the shadow map only when its inputs changed (sun, objects, meshes): the reference redraws it
+    // every frame (renderer.cpp:300-337), but a depth map of unchanged geometry from an unchanged light is the same map
+    std::vector<uint8_t> shadow_key; bool shadow_cache = true;
     int lit_parity = 0;             // which of the two stream-counter sets the next pass uses
     uint32_t cu_count = 256;
     uint32_t *h_counts = nullptr;   // pinned: [0] records, [1] work items (forward), [2], [3] the same for the shadow pass
@@ -125,6 +128,7 @@ int select_device(ArcticRenderer *r) {
 }
 
 int alloc_targets(ArcticRenderer *r) {
+    r->shadow_key.clear();   // buffers may move: render_frame redraws the shadow map
     r->tile_y0 = r->row_begin / TILE;
     r->row0_in_tile = r->row_begin - r->tile_y0 * TILE;
     r->tiles_x = (r->width + TILE - 1) / TILE;
@@ -396,6 +400,19 @@ int pass_shade(ArcticRenderer *r, const ArcticScene *sc, const ArcticSettings *s
     return ARCTIC_OK;
 }
 
+// everything the shadow map is a function of, as bytes (compared exactly, not hashed)
+std::vector<uint8_t> shadow_inputs(const ArcticRenderer *r, const ArcticScene *sc) {
+    std::vector<uint8_t> k;
+    if (!r->shadow_size) return k;
+    auto put = [&](const void *p, size_t n) { const uint8_t *b = static_cast<const uint8_t *>(p); k.insert(k.end(), b, b + n); };
+    const uint64_t head[3] = {r->shadow_size, (uint64_t)r->meshes.size(), sc->n_objects};
+    put(head, sizeof head);
+    put(sc->sun.position, sizeof sc->sun.position);
+    put(sc->sun.rotation, sizeof sc->sun.rotation);
+    for (uint64_t i = 0; i < sc->n_objects; ++i) { put(sc->objects[i].trs, sizeof sc->objects[i].trs); put(&sc->objects[i].mesh_idx, sizeof sc->objects[i].mesh_idx); }
+    return k;
+}
+
 bool valid_scene(const ArcticScene *sc) { return sc && (sc->n_objects == 0 || sc->objects); }
 
 }  // namespace
@@ -624,7 +641,9 @@ int arctic_pass_shadow_map(ArcticRenderer *r, const ArcticScene *scene) {
     if (!r) return ARCTIC_E_INVALID;
     if (!valid_scene(scene)) return r->fail(ARCTIC_E_INVALID, "pass_shadow_map: bad scene");
     int rc = select_device(r);
-    return rc ? rc : pass_shadow_map(r, scene);
+    if (rc) return rc;
+    r->shadow_key.clear();   // an explicit pass always renders; render_frame's cache starts over
+    return pass_shadow_map(r, scene);
 }
 
 int arctic_pass_gbuffer(ArcticRenderer *r, const ArcticScene *scene) {
@@ -646,7 +665,12 @@ int arctic_render_frame_device(ArcticRenderer *r, const ArcticScene *scene, cons
     if (!valid_scene(scene) || !settings) return r->fail(ARCTIC_E_INVALID, "render_frame: bad scene/settings");
     int rc = select_device(r);
     if (rc) return rc;
-    if ((rc = pass_shadow_map(r, scene)) != ARCTIC_OK) return rc;
+    std::vector<uint8_t> key = shadow_inputs(r, scene);
+    if (!r->shadow_cache || key != r->shadow_key) {
+        r->shadow_key.clear();
+        if ((rc = pass_shadow_map(r, scene)) != ARCTIC_OK) return rc;
+        r->shadow_key.swap(key);
+    }
     if ((rc = pass_gbuffer(r, scene)) != ARCTIC_OK) return rc;
     return pass_shade(r, scene, settings, d_out);
 }
@@ -783,6 +807,7 @@ int arctic_write_shadow_map(ArcticRenderer *r, const float *depth) {
     if (rc) return rc;
     HIPCHECK(r, hipStreamSynchronize(r->stream));
     HIPCHECK(r, hipMemcpy(r->d_shadow.p, depth, (size_t)r->shadow_size * r->shadow_size * 4, hipMemcpyHostToDevice));
+    r->shadow_key.clear();
     return ARCTIC_OK;
 }
 
@@ -832,6 +857,7 @@ int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value) {
         if (value >> 4) r->launch.light_blocks = r->cu_count * (uint32_t)(value >> 4);
         break;
     case ARCTIC_OPT_HDR16: r->hdr16 = value != 0; break;
+    case ARCTIC_OPT_SHADOW_CACHE: r->shadow_cache = value != 0; r->shadow_key.clear(); break;
     case ARCTIC_OPT_BANDS:
         if (value < 1 || value > (int64_t)MAX_BANDS) return r->fail(ARCTIC_E_INVALID, "set_option: bands must be 1..%u", MAX_BANDS);
         r->launch.n_bands = (uint32_t)value;

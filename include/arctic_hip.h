@@ -266,6 +266,8 @@ int arctic_stats(ArcticRenderer *r, uint64_t *out, uint32_t n);
                                         R16G16B16A16_FLOAT colour target (forward_pass.cpp:149, renderer.cpp:128-144); default 0 = fp32 */
 #define ARCTIC_OPT_LIGHT_KERNEL      7 /* tuning: lights per loop trip of k_light (2 or 4) + 16 * persistent workgroups per CU */
 #define ARCTIC_OPT_FUSED             8 /* 1 = the shading pass as ONE persistent kernel (material and light halves decoupled through LDS queues); 0 = k_material + k_light */
+#define ARCTIC_OPT_SHADOW_CACHE      9 /* 1 (default) = arctic_render_frame redraws the shadow map only when the sun, the objects or the mesh list changed
+                                          (byte-compared); 0 = every frame like the reference (renderer.cpp:300-337).  Same image either way. */
 #define ARCTIC_OPT_BANDS             5 /* 1..16 interleaved screen bands the two shading kernels are pipelined over (default 1: no gain measured) */
 int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value);
 

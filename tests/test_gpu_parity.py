@@ -217,6 +217,34 @@ def test_skybox_parity(pkg, oracle, hip, cfg, scale):
     rb.close(); r.close(); o.close()
 
 
+def test_render_frame_redraws_the_shadow_map_only_when_its_inputs_change(pkg, oracle, hip):
+    """ARCTIC_OPT_SHADOW_CACHE (default on): same frames as with the cache off, through sun and object changes."""
+    import copy
+    sc = pkg.scenes.config2(scale=0.25)
+    cached = sc.upload(hip.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights))
+    plain = sc.upload(hip.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights))
+    plain.set_option("shadow_cache", 0)
+    desc = copy.deepcopy(sc.desc)
+    frames = []
+    for step in range(6):
+        if step == 2:
+            desc.sun["rotation"] = (-55.0, 30.0)                      # the light moves
+        if step == 4:
+            desc.objects["trs"][0][12] += 0.75                        # an object moves (glm column 3 = translation)
+        if step == 5:
+            desc.camera["eye"] = tuple(np.add(desc.camera["eye"], (0.2, 0.1, 0.0)))   # only the camera moves: map is reused
+        a, b = cached.render_frame(desc, sc.settings), plain.render_frame(desc, sc.settings)
+        np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(cached.read_shadow_map().view(np.uint32), plain.read_shadow_map().view(np.uint32))
+        frames.append(a)
+    assert (frames[0] == frames[1]).all() and (frames[1] != frames[2]).any() and (frames[3] != frames[4]).any()
+    o = sc.upload(oracle.Oracle(sc.width, sc.height, sc.shadow_size, sc.max_lights))
+    ref = o.render_frame(desc, sc.settings)
+    d = np.abs(frames[-1].astype(np.int16) - ref.astype(np.int16))
+    assert d.max() <= 1 and (d != 0).mean() < 2e-3
+    cached.close(); plain.close(); o.close()
+
+
 def test_materials_with_unequal_texture_sizes(pkg, oracle, hip):
     """equal-size triples are stored interleaved; this exercises the other layout (and the fallback 16x16 textures)."""
     rng = np.random.default_rng(21)
