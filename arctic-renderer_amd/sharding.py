@@ -33,6 +33,23 @@ def owned_rows(height, rank, world, band_rows=16):
     return y[(y // band_rows) % world == rank]
 
 
+def padded_gather_plan(height, world, band_rows=16):
+    """equal-size exchange for interleaved shards: every rank sends `pad` rows (its own rows first, the rest unused), so
+    the gather is ONE collective (ncclGather) whatever the band count.  Returns (pad, dest) where dest[k * pad + j] is the
+    frame row of rank k's j-th sent row; the unused tail rows of the shards go to distinct dummy rows height .. world*pad - 1
+    of an extended frame (world * pad rows), so the root de-interleaves with one indexed copy of the whole staging buffer."""
+    import numpy as np
+    rows = [owned_rows(height, k, world, band_rows) for k in range(world)]
+    pad = max(len(x) for x in rows)
+    dest = np.empty(world * pad, np.int64)
+    dummy = height
+    for k, x in enumerate(rows):
+        dest[k * pad:k * pad + len(x)] = x
+        dest[k * pad + len(x):(k + 1) * pad] = dummy + np.arange(pad - len(x))
+        dummy += pad - len(x)
+    return pad, dest
+
+
 def assemble_banded(gathered, height, band_rows=16):
     """root only: the full frame from interleaved shards (one indexed copy per rank)."""
     world = len(gathered)

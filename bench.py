@@ -104,16 +104,17 @@ def main():
     # host synchronisation; two output buffers let the gather of frame k overlap the shading of frame k + 1
     # (each buffer is reused only after its own gather has completed).
     n_buf = 2 if world > 1 else 1
-    outs = [torch.empty((rows, sc.width, 4), dtype=torch.uint8, device="cuda") for _ in range(n_buf)]
-    shard_rows = [len(sharding.owned_rows(sc.height, k, world, BAND)) for k in range(world)] if world > 1 else [rows]
-    # root: the shards land back to back in one staging buffer per in-flight frame (rank k's rows at [off_k, off_k + n_k)),
-    # and ONE indexed copy de-interleaves them into the final frame
-    offs = np.concatenate([[0], np.cumsum(shard_rows)]).astype(int)
-    staging = [torch.empty((sc.height, sc.width, 4), dtype=torch.uint8, device="cuda") for _ in range(n_buf)] if (world > 1 and rank == 0) else None
-    gathered = [[staging[b][offs[k]:offs[k + 1]] for k in range(world)] for b in range(n_buf)] if staging is not None else [None] * n_buf
+    # N > 1: every rank sends the same number of rows (its own, padded to the largest shard), so the exchange is ONE
+    # ncclGather per frame; on the root the shards land back to back in a staging buffer and ONE indexed copy
+    # de-interleaves them into the frame (the padding rows go to dummy rows past the frame's end: world * pad rows in all)
+    pad, dest = sharding.padded_gather_plan(sc.height, world, BAND) if world > 1 else (rows, None)
+    outs = [torch.empty((pad, sc.width, 4), dtype=torch.uint8, device="cuda") for _ in range(n_buf)]
+    staging = [torch.empty((world * pad, sc.width, 4), dtype=torch.uint8, device="cuda") for _ in range(n_buf)] if (world > 1 and rank == 0) else None
+    gathered = [[staging[b][k * pad:(k + 1) * pad] for k in range(world)] for b in range(n_buf)] if staging is not None else [None] * n_buf
     pending = [None] * n_buf
-    frame = torch.empty((sc.height, sc.width, 4), dtype=torch.uint8, device="cuda") if staging is not None else None
-    perm = torch.as_tensor(np.concatenate([sharding.owned_rows(sc.height, k, world, BAND) for k in range(world)]), device="cuda") if staging is not None else None
+    frame_ext = torch.empty((world * pad, sc.width, 4), dtype=torch.uint8, device="cuda") if staging is not None else None
+    frame = frame_ext[:sc.height] if frame_ext is not None else None
+    perm = torch.as_tensor(dest, device="cuda") if staging is not None else None
     out_ptrs = [o.data_ptr() for o in outs]
     if world > 1:
         r.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -133,7 +134,7 @@ def main():
         pending[b].wait()
         pending[b] = None
         if frame is not None:
-            frame.index_copy_(0, perm, staging[b])
+            frame_ext.index_copy_(0, perm, staging[b])
 
     def drain():
         for b in range(n_buf):

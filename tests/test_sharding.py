@@ -47,6 +47,26 @@ def test_owned_rows_partition_and_assemble(pkg):
         sh.owned_rows(100, 0, 2, 12)
 
 
+def test_padded_gather_plan_is_one_indexed_copy(pkg):
+    """equal-size exchange (what bench.py uses for N > 1): staging row k*pad+j -> frame row dest[k*pad+j]."""
+    from importlib import import_module
+    sh = import_module("arctic_renderer_amd.sharding")
+    for h, world, band in ((2160, 8, 16), (2160, 2, 16), (2160, 4, 16), (216, 3, 16), (100, 4, 8), (4320, 8, 16)):
+        pad, dest = sh.padded_gather_plan(h, world, band)
+        rows = [sh.owned_rows(h, r, world, band) for r in range(world)]
+        assert pad == max(map(len, rows)) and len(dest) == world * pad
+        real = dest[dest < h]
+        np.testing.assert_array_equal(np.sort(real), np.arange(h))          # every frame row exactly once
+        np.testing.assert_array_equal(np.sort(dest), np.arange(world * pad))  # a permutation: padding rows land on distinct dummy rows
+        frame = torch.arange(h * 3 * 4, dtype=torch.int64).reshape(h, 3, 4).to(torch.uint8)
+        staging = torch.full((world * pad, 3, 4), 77, dtype=torch.uint8)
+        for k, x in enumerate(rows):
+            staging[k * pad:k * pad + len(x)] = frame[torch.as_tensor(x)]
+        ext = torch.zeros((world * pad, 3, 4), dtype=torch.uint8)
+        ext.index_copy_(0, torch.as_tensor(dest), staging)
+        assert torch.equal(ext[:h], frame)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
