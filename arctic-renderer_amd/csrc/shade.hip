@@ -455,7 +455,7 @@ __device__ __forceinline__ unsigned long long material_tile(const ShadeParams &s
     live = covered && (sp.culling ? lit != 0.0f : true);
     const unsigned long long m = __ballot(live);
     float4 gc, gd, ge;
-    if (m != 0ull) { gc = sp.g.c[gi]; gd = sp.g.d[gi]; ge = sp.g.e[gi]; }   // second wave of loads: lit tiles only (48 B / pixel)
+    if (live) { gc = sp.g.c[gi]; gd = sp.g.d[gi]; ge = sp.g.e[gi]; }   // second wave of loads: lit pixels only (48 B / pixel, whole 128-byte tile rows)
     f3 base = mk(0.0f, 0.0f, 0.0f);
     if (covered) base = mk(filt_srgb(t0, 0, lut), filt_srgb(t0, 1, lut), filt_srgb(t0, 2, lut));
     if (in_frame && !live) {

@@ -12,7 +12,7 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "liboracle.so")
+LIB_PATH = os.environ.get("ARCTIC_ORACLE_LIB") or os.path.join(HERE, "liboracle.so")   # override: the sanitizer build (Makefile: liboracle_asan.so)
 
 
 class Camera(C.Structure):
