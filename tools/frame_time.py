@@ -12,12 +12,16 @@ for cfg in [int(a) for a in sys.argv[1:]] or (3, 2, 1):
         sc.environment = env
         r = sc.upload(pkg.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights))
         out = torch.empty((sc.height, sc.width, 4), dtype=torch.uint8, device="cuda")
-        for i in range(3): r.render_frame_device(sc.desc, sc.settings, out.data_ptr())
-        r.flush(); t = time.perf_counter(); N = 20 if cfg < 5 else 5
-        for i in range(N): r.render_frame_device(sc.desc, sc.settings, out.data_ptr())
-        r.flush(); dt = (time.perf_counter() - t) / N
-        print(f"config {cfg}{' + environment map' if env is not None else ''}: {sc.width}x{sc.height} {sc.n_triangles} tris, {len(sc.lights)} lights, "
-              f"whole frame (shadow raster + prepass + shading) {dt*1e3:.3f} ms = {1/dt:.0f} fps, {sc.width*sc.height/dt/1e6:.0f} Mpx/s", flush=True)
+        N = 20 if cfg < 5 else 5
+        for cache in (1, 0):   # 1: the shadow map is redrawn only when the sun / objects change (default); 0: every frame, like the reference
+            r.set_option("shadow_cache", cache)
+            for i in range(3): r.render_frame_device(sc.desc, sc.settings, out.data_ptr())
+            r.flush(); t = time.perf_counter()
+            for i in range(N): r.render_frame_device(sc.desc, sc.settings, out.data_ptr())
+            r.flush(); dt = (time.perf_counter() - t) / N
+            print(f"config {cfg}{' + environment map' if env is not None else ''}: {sc.width}x{sc.height} {sc.n_triangles} tris, {len(sc.lights)} lights, "
+                  f"whole frame ({'static sun: G-buffer prepass + shading' if cache else 'shadow raster + G-buffer prepass + shading'}) "
+                  f"{dt*1e3:.3f} ms = {1/dt:.0f} fps, {sc.width*sc.height/dt/1e6:.0f} Mpx/s", flush=True)
         ms, ms_mat, ms_light = r.time_shade_split(sc.desc, sc.settings, warmup=3, iters=N)
         r.set_option("count_light_evals", 1); r.pass_shade(sc.desc, sc.settings); r.flush(); st = r.stats(); r.set_option("count_light_evals", 0)
         _, mat, _, _ = r.read_gbuffer(want=("material",)); cov = int((mat != 0xFFFFFFFF).sum())
