@@ -65,7 +65,8 @@ struct SetupRec {
     int64_t area2;
     int32_t px0, py0, px1, py1;  // inclusive pixel bounds (scissored)
     uint32_t src_tri, object;
-    uint32_t pad[2];
+    uint32_t order_id;    // 8 * src_tri + index of this sub-triangle: the tie-break of equal depths (first drawn wins)
+    uint32_t pad;
 };
 static_assert(sizeof(SetupRec) == 128, "SetupRec layout");
 
@@ -158,17 +159,14 @@ constexpr uint32_t MAX_SHADE_LIGHTS = 2048;    // 48 KiB of light pairs in LDS
 // every launcher enqueues on `s` and returns the launch error, never synchronises.
 hipError_t launch_vertex(const ObjectRec *objs, const uint32_t *block_obj, const uint32_t *block_first,
                          uint32_t n_blocks, const GeomParams *gp, XVert *xv, int clip_only, hipStream_t s);
-hipError_t launch_setup(const ObjectRec *objs, const uint32_t *block_obj, const uint32_t *block_first,
-                        uint32_t n_blocks, const GeomParams *gp, const XVert *xv,
-                        const uint32_t *sub_offset /*null: count pass*/, uint32_t *sub_count,
-                        SetupRec *recs, uint32_t *tile_count, hipStream_t s);
-hipError_t launch_scan(const uint32_t *in, uint32_t *out /*n+1, exclusive*/, uint32_t n, uint32_t *scratch, hipStream_t s);
-uint32_t scan_scratch_elems(uint32_t n);
-hipError_t launch_raster_vis(const SetupRec *recs, const uint32_t *tile_offset, uint32_t n_slots, uint32_t grid_blocks,
+hipError_t launch_setup(const ObjectRec *objs, const uint32_t *block_obj, const uint32_t *block_first, uint32_t n_blocks,
+                        const GeomParams *gp, const XVert *xv, SetupRec *recs, uint32_t *rec_of /*8 per source triangle*/,
+                        uint2 *items, uint32_t item_cap, uint32_t *counters /*records, items, overflow: zeroed before*/, hipStream_t s);
+hipError_t launch_raster_vis(const SetupRec *recs, const uint2 *items, uint32_t item_cap, const uint32_t *counters, uint32_t grid_blocks,
                              const GeomParams *gp, unsigned long long *vis, hipStream_t s);
-hipError_t launch_raster_depth(const SetupRec *recs, const uint32_t *tile_offset, uint32_t n_slots, uint32_t grid_blocks,
+hipError_t launch_raster_depth(const SetupRec *recs, const uint2 *items, uint32_t item_cap, const uint32_t *counters, uint32_t grid_blocks,
                                const GeomParams *gp, uint32_t *depth_bits, hipStream_t s);
-hipError_t launch_resolve(const unsigned long long *vis, const SetupRec *recs, const ObjectRec *objs, const XVert *xv,
+hipError_t launch_resolve(const unsigned long long *vis, const SetupRec *recs, const uint32_t *rec_of, const ObjectRec *objs, const XVert *xv,
                           const GeomParams *gp, uint32_t n_tiles, GBuffer g, float *depth_out, uint32_t *src_out, hipStream_t s);
 hipError_t launch_fill_u64(unsigned long long *p, unsigned long long v, size_t n, hipStream_t s);
 hipError_t launch_fill_u32(uint32_t *p, uint32_t v, size_t n, hipStream_t s);

@@ -207,121 +207,120 @@ __global__ __launch_bounds__(256) void k_vertex(const ObjectRec *__restrict__ ob
 }
 
 // ---------------------------------------------------------------------------------------------
-// clip + setup, one thread per source triangle.  Pass 1 (sub_offset == null) counts the triangles
-// each source triangle produces; after an exclusive scan pass 2 writes them compacted, in draw
-// order, together with the number of 8x8 tiles each one touches.
+// clip + setup + work-item expansion in ONE launch, one thread per source triangle.
+// Record slots and work-item slots are taken from two device counters with one wave-aggregated atomicAdd each, so
+// there is no count pass, no prefix scan and nothing for the host to wait for.  Records therefore land in arbitrary
+// order; what must stay deterministic -- "first drawn wins" on equal depth -- travels in the record instead:
+// order_id = 8 * (draw-order index of the source triangle) + (index of the sub-triangle the clipper produced), which is
+// the low word of the visibility key.  rec_of[order_id] finds the record again in k_resolve.
+// A work item is one (record, 16x16-pixel block) pair, stored explicitly: items[i] = {record, block index in the
+// record's bounding box}.
+// counters: [0] records, [1] work items, [2] set when the item table overflowed (the frame is then incomplete).
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v, uint32_t lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(v, d); if (lane >= (uint32_t)d) v += y; }
+    return v;
+}
+
+// the k-th triangle of the fan over the clipped polygon that survives setup (culling, zero area, empty bounds)
+__device__ __forceinline__ bool nth_record(const CV *poly, int n, const GeomParams &gp, uint32_t k, SetupRec &t) {
+    uint32_t seen = 0;
+    for (int f = 1; f + 1 < n; ++f) {
+        if (!setup_triangle(poly[0], poly[f], poly[f + 1], gp, t)) continue;
+        if (seen == k) return true;
+        ++seen;
+    }
+    return false;
+}
+
 __global__ __launch_bounds__(256) void k_setup(const ObjectRec *__restrict__ objs, const uint32_t *__restrict__ block_obj,
                                                const uint32_t *__restrict__ block_first, const GeomParams *__restrict__ gpp,
-                                               const XVert *__restrict__ xv, const uint32_t *__restrict__ sub_offset,
-                                               uint32_t *__restrict__ sub_count, SetupRec *__restrict__ recs,
-                                               uint32_t *__restrict__ tile_count) {
-    uint32_t oi = block_obj[blockIdx.x];
+                                               const XVert *__restrict__ xv, SetupRec *__restrict__ recs,
+                                               uint32_t *__restrict__ rec_of, uint2 *__restrict__ items, uint32_t item_cap,
+                                               uint32_t *__restrict__ counters) {
+    const uint32_t oi = block_obj[blockIdx.x];
     const ObjectRec &ob = objs[oi];
-    uint32_t ti = block_first[blockIdx.x] + threadIdx.x;
-    if (ti >= ob.n_triangles) return;
+    const uint32_t ti = block_first[blockIdx.x] + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63;
     const GeomParams gp = *gpp;
-    uint32_t src = ob.first_triangle + ti;
-    uint32_t idx[3] = {ob.indices[3 * ti], ob.indices[3 * ti + 1], ob.indices[3 * ti + 2]};
+    const uint32_t src = ob.first_triangle + ti;
     uint32_t produced = 0;
-    uint32_t out = sub_offset ? sub_offset[src] : 0;
-    if (idx[0] < ob.n_vertices && idx[1] < ob.n_vertices && idx[2] < ob.n_vertices) {
-        CV poly[MAX_POLY];
+    int n = 0;
+    CV poly[MAX_POLY];
+    SetupRec t0;   // the first record stays in registers: unclipped triangles (nearly all) are set up exactly once
+    if (ti < ob.n_triangles) {
+        const uint32_t idx[3] = {ob.indices[3 * ti], ob.indices[3 * ti + 1], ob.indices[3 * ti + 2]};
+        if (idx[0] < ob.n_vertices && idx[1] < ob.n_vertices && idx[2] < ob.n_vertices) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const float *c = xv[ob.first_xvert + idx[k]].clip;
-            poly[k].x = c[0]; poly[k].y = c[1]; poly[k].z = c[2]; poly[k].w = c[3];
-            poly[k].b0 = k == 0 ? 1.0f : 0.0f; poly[k].b1 = k == 1 ? 1.0f : 0.0f; poly[k].b2 = k == 2 ? 1.0f : 0.0f;
-        }
-        bool inside = true;
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-#pragma unroll
-            for (int p = 0; p < 6; ++p) inside = inside && (plane_dist(poly[k], p) >= 0.0f);
-        int n = inside ? 3 : clip_polygon(poly, 3);
-        for (int f = 1; f + 1 < n; ++f) {
-            SetupRec t;
-            if (!setup_triangle(poly[0], poly[f], poly[f + 1], gp, t)) continue;
-            if (sub_offset) {
-                t.src_tri = src; t.object = oi; t.pad[0] = 0; t.pad[1] = 0;
-                recs[out + produced] = t;
-                tile_count[out + produced] = tiles_of(t);
+            for (int k = 0; k < 3; ++k) {
+                const float *c = xv[ob.first_xvert + idx[k]].clip;
+                poly[k].x = c[0]; poly[k].y = c[1]; poly[k].z = c[2]; poly[k].w = c[3];
+                poly[k].b0 = k == 0 ? 1.0f : 0.0f; poly[k].b1 = k == 1 ? 1.0f : 0.0f; poly[k].b2 = k == 2 ? 1.0f : 0.0f;
             }
-            ++produced;
+            bool inside = true;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int p = 0; p < 6; ++p) inside = inside && (plane_dist(poly[k], p) >= 0.0f);
+            n = inside ? 3 : clip_polygon(poly, 3);
+            for (int f = 1; f + 1 < n; ++f) {
+                SetupRec t;
+                if (!setup_triangle(poly[0], poly[f], poly[f + 1], gp, t)) continue;
+                if (produced == 0) t0 = t;
+                ++produced;
+            }
         }
     }
-    if (!sub_offset) sub_count[src] = produced;
-}
-
-// ---------------------------------------------------------------------------------------------
-// exclusive prefix sum (out has n+1 entries; out[n] = total): 1024 elements per block
-// ---------------------------------------------------------------------------------------------
-constexpr int SCAN_BLOCK = 256, SCAN_PER_THREAD = 4, SCAN_ELEMS = SCAN_BLOCK * SCAN_PER_THREAD;
-
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_block(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
-                                                           uint32_t n, uint32_t *__restrict__ block_sums) {
-    __shared__ uint32_t wave_sums[SCAN_BLOCK / 64];
-    uint32_t base = blockIdx.x * SCAN_ELEMS + threadIdx.x * SCAN_PER_THREAD;
-    uint32_t v[SCAN_PER_THREAD], sum = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_PER_THREAD; ++k) { v[k] = (base + k < n) ? in[base + k] : 0; sum += v[k]; }
-    uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t incl = sum;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(incl, d); if (lane >= (uint32_t)d) incl += y; }
-    if (lane == 63) wave_sums[wave] = incl;
-    __syncthreads();
-    uint32_t wave_base = 0;
-    for (uint32_t w = 0; w < wave; ++w) wave_base += wave_sums[w];
-    uint32_t run = wave_base + incl - sum;
-#pragma unroll
-    for (int k = 0; k < SCAN_PER_THREAD; ++k) { if (base + k < n) out[base + k] = run; run += v[k]; }
-    if (threadIdx.x == SCAN_BLOCK - 1) block_sums[blockIdx.x] = wave_base + incl;
-}
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_add(uint32_t *__restrict__ out, uint32_t n, const uint32_t *__restrict__ block_offsets,
-                                                         uint32_t n_blocks) {
-    uint32_t add = block_offsets[blockIdx.x];
-    uint32_t base = blockIdx.x * SCAN_ELEMS + threadIdx.x * SCAN_PER_THREAD;
-#pragma unroll
-    for (int k = 0; k < SCAN_PER_THREAD; ++k) if (base + k < n) out[base + k] += add;
-    if (blockIdx.x == n_blocks - 1 && threadIdx.x == 0) out[n] = block_offsets[n_blocks];   // grand total
-}
-__global__ void k_scan_total1(uint32_t *out, uint32_t n, const uint32_t *block_sums) { out[n] = block_sums[0]; }
-
-// ---------------------------------------------------------------------------------------------
-// raster: one wavefront per (triangle, 8x8 tile) work item, one lane per pixel
-// ---------------------------------------------------------------------------------------------
-// item -> record: the largest r with tile_offset[r] <= item.  A scalar binary search would be ~21 DEPENDENT loads per
-// work item (latency bound); the wave searches 65-ary instead -- each lane probes one split point, a ballot picks the
-// segment -- which is 4 rounds for 1.6 M slots.  All 64 lanes must be active.
-__device__ __forceinline__ uint32_t find_record(const uint32_t *__restrict__ tile_offset, uint32_t n_slots, uint32_t item, uint32_t lane) {
-    uint32_t lo = 0, hi = n_slots;   // invariant: tile_offset[lo] <= item < tile_offset[hi]
-    while (hi - lo > 1) {
-        const uint32_t span = hi - lo;
-        const uint32_t p = lo + (uint32_t)(((unsigned long long)(lane + 1) * span) / 65u);   // lo <= p < hi, non-decreasing in lane
-        const unsigned long long le = __ballot(tile_offset[p] <= item);                       // ones then zeros
-        const uint32_t c = (uint32_t)__popcll(le);
-        const uint32_t nlo = c > 0 ? lo + (uint32_t)(((unsigned long long)c * span) / 65u) : lo;
-        const uint32_t nhi = c < 64 ? lo + (uint32_t)(((unsigned long long)(c + 1) * span) / 65u) : hi;
-        lo = nlo; hi = nhi;
+    // record slots: one atomicAdd per wave
+    const uint32_t incl = wave_inclusive_sum(produced, lane);
+    uint32_t rbase = 0;
+    if (lane == 63 && incl) rbase = atomicAdd(&counters[0], incl);
+    const uint32_t out = __shfl(rbase, 63) + incl - produced;
+    // records and their work items, sub-triangle by sub-triangle (the loop runs once unless a triangle of the wave was clipped)
+    for (uint32_t k = 0; __ballot(k < produced) != 0ull; ++k) {
+        uint32_t nb = 0;
+        const uint32_t r = out + k;
+        if (k < produced) {
+            SetupRec t;
+            if (k == 0) t = t0; else nth_record(poly, n, gp, k, t);
+            t.src_tri = src; t.object = oi; t.order_id = src * 8u + k; t.pad = 0;
+            recs[r] = t;
+            rec_of[src * 8u + k] = r;
+            nb = tiles_of(t);
+        }
+        const uint32_t iincl = wave_inclusive_sum(nb, lane);
+        uint32_t ibase = 0;
+        if (lane == 63 && iincl) ibase = atomicAdd(&counters[1], iincl);
+        ibase = __shfl(ibase, 63) + iincl - nb;
+        if (__shfl(ibase, 63) + __shfl(nb, 63) > item_cap && lane == 0) counters[2] = 1;   // table full: reported by the host
+        // small records: the lane writes its own items; large ones (a wall across the screen is thousands of blocks): the
+        // whole wave writes them, 64 per step
+        if (nb <= 16)
+            for (uint32_t j = 0; j < nb; ++j) if (ibase + j < item_cap) items[ibase + j] = make_uint2(r, j);
+        for (unsigned long long big = __ballot(nb > 16); big != 0ull; big &= big - 1ull) {
+            const int L = __ffsll((long long)big) - 1;
+            const uint32_t R = __shfl(r, L), NB = __shfl(nb, L), IB = __shfl(ibase, L);
+            for (uint32_t j = lane; j < NB; j += 64) if (IB + j < item_cap) items[IB + j] = make_uint2(R, j);
+        }
     }
-    return lo;
 }
 
-// Persistent: the number of work items is only known on the device (tile_offset[n_slots], the total of the scan), so a
-// fixed grid strides over them and the host never waits for a count.  n_slots = capacity of the record array; slots past
-// the last record have zero tiles and offset == total, which the search skips by construction.
+// ---------------------------------------------------------------------------------------------
+// raster: one wavefront per (triangle, 16x16 block) work item, a 2x2 pixel quad per lane
+// ---------------------------------------------------------------------------------------------
+// Persistent: the number of work items is only known on the device (counters[1]), so a fixed grid strides over the item
+// table and the host never waits for a count.
 template <bool DEPTH_ONLY>
-__global__ __launch_bounds__(256) void k_raster(const SetupRec *__restrict__ recs, const uint32_t *__restrict__ tile_offset,
-                                                uint32_t n_slots, const GeomParams *__restrict__ gpp,
+__global__ __launch_bounds__(256) void k_raster(const SetupRec *__restrict__ recs, const uint2 *__restrict__ items, uint32_t item_cap,
+                                                const uint32_t *__restrict__ counters, const GeomParams *__restrict__ gpp,
                                                 unsigned long long *__restrict__ vis, uint32_t *__restrict__ depth_bits) {
-    const uint32_t n_items = tile_offset[n_slots];
+    const uint32_t n_items = min(counters[1], item_cap);
     const uint32_t lane = threadIdx.x & 63;
     for (uint32_t item = blockIdx.x * 4 + (threadIdx.x >> 6); item < n_items; item += gridDim.x * 4) {
-        uint32_t r = find_record(tile_offset, n_slots, item, lane);
-        r = __builtin_amdgcn_readfirstlane(r);
+        const uint2 it = items[item];
+        const uint32_t r = __builtin_amdgcn_readfirstlane(it.x), local = __builtin_amdgcn_readfirstlane(it.y);
         const SetupRec &t = recs[r];
-        uint32_t local = item - tile_offset[r];
         int32_t bx0 = t.px0 >> 4, by0 = t.py0 >> 4;
         uint32_t nbx = (uint32_t)((t.px1 >> 4) - bx0 + 1);
         const int32_t qx = (bx0 + (int32_t)(local % nbx)) * 16 + (int32_t)(lane & 7) * 2;   // this lane's 2x2 quad
@@ -353,7 +352,7 @@ __global__ __launch_bounds__(256) void k_raster(const SetupRec *__restrict__ rec
                 const int ty_rel = (py >> 3) - gpp->tile_y0;
                 if (!row_owned(ty_rel, gpp->band_tiles, gpp->shard_count, gpp->shard_index)) continue;   // another shard's band
                 size_t idx = ((size_t)row_local(ty_rel, gpp->band_tiles, gpp->shard_count) * gpp->tiles_x + (px >> 3)) * 64 + (py & 7) * 8 + (px & 7);
-                unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | r;   // ties: first drawn (smallest id) wins
+                unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | t.order_id;   // ties: first drawn (smallest order id) wins
                 if (key < vis[idx]) atomicMin(&vis[idx], key);
             }
         }
@@ -364,7 +363,7 @@ __global__ __launch_bounds__(256) void k_raster(const SetupRec *__restrict__ rec
 // resolve: visibility -> interpolated attributes, tile-major G-buffer
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_resolve(const unsigned long long *__restrict__ vis, const SetupRec *__restrict__ recs,
-                                                 const ObjectRec *__restrict__ objs, const XVert *__restrict__ xv,
+                                                 const uint32_t *__restrict__ rec_of, const ObjectRec *__restrict__ objs, const XVert *__restrict__ xv,
                                                  const GeomParams *__restrict__ gpp, uint32_t n_tiles, GBuffer g,
                                                  float *__restrict__ depth_out, uint32_t *__restrict__ src_out) {
     uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -378,7 +377,7 @@ __global__ __launch_bounds__(256) void k_resolve(const unsigned long long *__res
     uint32_t mat = NO_MATERIAL, src = 0xFFFFFFFFu;
     float depth = 1.0f;
     if (key != ~0ull) {
-        const SetupRec &t = recs[(uint32_t)key];
+        const SetupRec &t = recs[rec_of[(uint32_t)key]];   // low word = order id (k_setup)
         depth = __uint_as_float((uint32_t)(key >> 32));
         int32_t tx = (int32_t)(tile % (uint32_t)gpp->tiles_x);
         int32_t ty = row_global((int)(tile / (uint32_t)gpp->tiles_x), gpp->band_tiles, gpp->shard_count, gpp->shard_index) + gpp->tile_y0;
@@ -475,53 +474,29 @@ hipError_t launch_vertex(const ObjectRec *objs, const uint32_t *block_obj, const
 }
 
 hipError_t launch_setup(const ObjectRec *objs, const uint32_t *block_obj, const uint32_t *block_first, uint32_t n_blocks,
-                        const GeomParams *gp, const XVert *xv, const uint32_t *sub_offset, uint32_t *sub_count,
-                        SetupRec *recs, uint32_t *tile_count, hipStream_t s) {
+                        const GeomParams *gp, const XVert *xv, SetupRec *recs, uint32_t *rec_of, uint2 *items, uint32_t item_cap,
+                        uint32_t *counters, hipStream_t s) {
     if (n_blocks == 0) return hipSuccess;
-    k_setup<<<n_blocks, 256, 0, s>>>(objs, block_obj, block_first, gp, xv, sub_offset, sub_count, recs, tile_count);
+    k_setup<<<n_blocks, 256, 0, s>>>(objs, block_obj, block_first, gp, xv, recs, rec_of, items, item_cap, counters);
     return hipGetLastError();
 }
 
-uint32_t scan_scratch_elems(uint32_t n) {
-    // block sums of every level, each level followed by its own scanned copy (+1 for the total)
-    uint32_t total = 0;
-    while (n > 1) { n = div_up(n, SCAN_ELEMS); total += 2 * n + 2; if (n == 1) break; }
-    return total + 4;
-}
-
-hipError_t launch_scan(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *scratch, hipStream_t s) {
-    if (n == 0) return hipMemsetAsync(out, 0, sizeof(uint32_t), s);
-    uint32_t nb = div_up(n, SCAN_ELEMS);
-    uint32_t *sums = scratch, *sums_scanned = scratch + nb;   // sums_scanned has nb+1 entries
-    k_scan_block<<<nb, SCAN_BLOCK, 0, s>>>(in, out, n, sums);
-    if (nb == 1) {
-        k_scan_total1<<<1, 1, 0, s>>>(out, n, sums);
-        return hipGetLastError();
-    }
-    hipError_t e = launch_scan(sums, sums_scanned, nb, scratch + 2 * nb + 1, s);
-    if (e != hipSuccess) return e;
-    k_scan_add<<<nb, SCAN_BLOCK, 0, s>>>(out, n, sums_scanned, nb);
-    return hipGetLastError();
-}
-
-hipError_t launch_raster_vis(const SetupRec *recs, const uint32_t *tile_offset, uint32_t n_slots, uint32_t grid_blocks,
+hipError_t launch_raster_vis(const SetupRec *recs, const uint2 *items, uint32_t item_cap, const uint32_t *counters, uint32_t grid_blocks,
                              const GeomParams *gp, unsigned long long *vis, hipStream_t s) {
-    if (n_slots == 0) return hipSuccess;
-    k_raster<false><<<grid_blocks, 256, 0, s>>>(recs, tile_offset, n_slots, gp, vis, nullptr);
+    k_raster<false><<<grid_blocks, 256, 0, s>>>(recs, items, item_cap, counters, gp, vis, nullptr);
     return hipGetLastError();
 }
 
-hipError_t launch_raster_depth(const SetupRec *recs, const uint32_t *tile_offset, uint32_t n_slots, uint32_t grid_blocks,
+hipError_t launch_raster_depth(const SetupRec *recs, const uint2 *items, uint32_t item_cap, const uint32_t *counters, uint32_t grid_blocks,
                                const GeomParams *gp, uint32_t *depth_bits, hipStream_t s) {
-    if (n_slots == 0) return hipSuccess;
-    k_raster<true><<<grid_blocks, 256, 0, s>>>(recs, tile_offset, n_slots, gp, nullptr, depth_bits);
+    k_raster<true><<<grid_blocks, 256, 0, s>>>(recs, items, item_cap, counters, gp, nullptr, depth_bits);
     return hipGetLastError();
 }
 
-hipError_t launch_resolve(const unsigned long long *vis, const SetupRec *recs, const ObjectRec *objs, const XVert *xv,
+hipError_t launch_resolve(const unsigned long long *vis, const SetupRec *recs, const uint32_t *rec_of, const ObjectRec *objs, const XVert *xv,
                           const GeomParams *gp, uint32_t n_tiles, GBuffer g, float *depth_out, uint32_t *src_out, hipStream_t s) {
     if (n_tiles == 0) return hipSuccess;
-    k_resolve<<<div_up(n_tiles, 4), 256, 0, s>>>(vis, recs, objs, xv, gp, n_tiles, g, depth_out, src_out);
+    k_resolve<<<div_up(n_tiles, 4), 256, 0, s>>>(vis, recs, rec_of, objs, xv, gp, n_tiles, g, depth_out, src_out);
     return hipGetLastError();
 }
 

@@ -79,7 +79,8 @@ struct ArcticRenderer {
     bool have_gbuffer = false, have_output = false;
     // per-frame geometry scratch
     PassTables tables[2];   // [0] forward pass, [1] shadow pass
-    DevBuf d_xverts, d_sub_count, d_sub_offset, d_recs, d_tile_count, d_tile_offset, d_scan, d_stage;
+    DevBuf d_xverts, d_recs, d_rec_of, d_items, d_geo_counters, d_stage;
+    uint32_t item_cap = 0;          // entries of d_items (work-item table of the rasteriser)
     uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int keep_float = 0, count_evals = 0, culling = 1, debug = 0, hdr16 = 0;
     ShadeLaunch launch{};           // streams, events, band count and k_light's persistent grid
@@ -91,7 +92,7 @@ struct ArcticRenderer {
     std::vector<uint8_t> shadow_key; bool shadow_cache = true;
     int lit_parity = 0;             // which of the two stream-counter sets the next pass uses
     uint32_t cu_count = 256;
-    uint32_t *h_counts = nullptr;   // pinned: [0] records, [1] work items (forward), [2], [3] the same for the shadow pass
+    uint32_t *h_counts = nullptr;   // pinned: [0] records, [1] work items (forward), [2], [3] the same for the shadow pass, [4], [5] item-table overflow flags
     std::string err;
 
     int fail(int code, const char *fmt, ...) {
@@ -151,6 +152,7 @@ int alloc_targets(ArcticRenderer *r) {
     HIPCHECK(r, r->d_src.ensure(px * 4));
     HIPCHECK(r, r->d_rgba8.ensure(out_px * 4));
     HIPCHECK(r, r->d_counter.ensure(64));
+    HIPCHECK(r, r->d_geo_counters.ensure(32));
     if (!r->d_tickets.p) {
         HIPCHECK(r, r->d_tickets.ensure(9 * 128));
         HIPCHECK(r, hipMemsetAsync(r->d_tickets.p, 0, 9 * 128, r->stream));
@@ -228,8 +230,6 @@ int upload_pass_tables(ArcticRenderer *r, PassTables &T, const GeomParams &gp, c
     T.tblock_obj = reinterpret_cast<const uint32_t *>(d + o_to); T.tblock_first = reinterpret_cast<const uint32_t *>(d + o_tf);
     if (n_objs) {
         HIPCHECK(r, r->d_xverts.ensure((size_t)n_xverts * sizeof(XVert)));
-        HIPCHECK(r, r->d_sub_count.ensure((size_t)n_src_tris * 4 + 4));
-        HIPCHECK(r, r->d_sub_offset.ensure((size_t)n_src_tris * 4 + 8));
     }
     return ARCTIC_OK;
 }
@@ -259,38 +259,38 @@ int run_geometry(ArcticRenderer *r, const ArcticScene *sc, bool shadow_pass) {
     int rc = upload_pass_tables(r, T, gp, sc, n_objs, n_xverts, n_src, n_vblocks, n_tblocks);
     if (rc != ARCTIC_OK) return rc;
     const GeomParams *d_gp = T.gp;
-    r->h_counts[shadow_pass ? 2 : 0] = r->h_counts[shadow_pass ? 3 : 1] = 0;
-    if (n_objs == 0 || n_src == 0) return ARCTIC_OK;
+    if (n_objs == 0 || n_src == 0) { r->h_counts[shadow_pass ? 2 : 0] = r->h_counts[shadow_pass ? 3 : 1] = 0; return ARCTIC_OK; }
     const ObjectRec *objs = T.objs;
     HIPCHECK(r, launch_vertex(objs, T.vblock_obj, T.vblock_first, n_vblocks, d_gp, r->d_xverts.as<XVert>(), shadow_pass ? 1 : 0, r->stream));
-    // Record slots: a triangle clipped against 6 planes yields at most 7 triangles, so 7 * n_src slots can never overflow and
-    // neither the record count nor the work-item count has to come back to the host: the frame stays asynchronous.
+    // Record slots: a triangle clipped against 6 planes yields at most 7 triangles, so 7 * n_src slots can never overflow.
+    // Records and work items are allocated on the device from two counters (k_setup): no count pass, no scan, and neither
+    // count has to come back to the host -- the frame stays asynchronous.
     const uint64_t slots64 = 7ull * n_src;
-    if (slots64 > 0x7FFFFFF0ull) return r->fail(ARCTIC_E_CAPACITY, "scene too large: %u triangles", n_src);
+    if (slots64 > 0x0FFFFFF0ull) return r->fail(ARCTIC_E_CAPACITY, "scene too large: %u triangles", n_src);
     const uint32_t n_slots = (uint32_t)slots64;
-    HIPCHECK(r, r->d_scan.ensure(((size_t)scan_scratch_elems(n_src) + scan_scratch_elems(n_slots)) * 4 + 4096));
-    HIPCHECK(r, r->d_recs.ensure((size_t)n_slots * sizeof(SetupRec)));
-    HIPCHECK(r, r->d_tile_count.ensure((size_t)n_slots * 4 + 4));
-    HIPCHECK(r, r->d_tile_offset.ensure((size_t)n_slots * 4 + 8));
-    // pass 1: count the triangles each source triangle yields, scan
-    HIPCHECK(r, launch_setup(objs, T.tblock_obj, T.tblock_first, n_tblocks, d_gp,
-                             r->d_xverts.as<XVert>(), nullptr, r->d_sub_count.as<uint32_t>(), nullptr, nullptr, r->stream));
-    HIPCHECK(r, launch_scan(r->d_sub_count.as<uint32_t>(), r->d_sub_offset.as<uint32_t>(), n_src, r->d_scan.as<uint32_t>(), r->stream));
-    // pass 2: emit the compacted records + tiles per record (unused slots stay 0), scan
-    HIPCHECK(r, hipMemsetAsync(r->d_tile_count.p, 0, (size_t)n_slots * 4, r->stream));
-    HIPCHECK(r, launch_setup(objs, T.tblock_obj, T.tblock_first, n_tblocks, d_gp,
-                             r->d_xverts.as<XVert>(), r->d_sub_offset.as<uint32_t>(), nullptr, r->d_recs.as<SetupRec>(),
-                             r->d_tile_count.as<uint32_t>(), r->stream));
-    HIPCHECK(r, launch_scan(r->d_tile_count.as<uint32_t>(), r->d_tile_offset.as<uint32_t>(), n_slots, r->d_scan.as<uint32_t>(), r->stream));
-    // counts for arctic_stats(): copied to pinned memory, looked at only when asked for
+    // work-item table: explicit (record, 16x16 block) pairs.  Its size follows the largest count seen so far (pinned
+    // h_counts, refreshed asynchronously each pass) with 4x headroom; an overflow drops work, is flagged by the kernel and
+    // reported by the next call that synchronises (arctic_flush / read-backs) -- and the table has grown by then.
     uint32_t *h = r->h_counts + (shadow_pass ? 2 : 0);
-    HIPCHECK(r, hipMemcpyAsync(h, r->d_sub_offset.as<uint32_t>() + n_src, 4, hipMemcpyDeviceToHost, r->stream));
-    HIPCHECK(r, hipMemcpyAsync(h + 1, r->d_tile_offset.as<uint32_t>() + n_slots, 4, hipMemcpyDeviceToHost, r->stream));
+    const uint64_t want = std::max<uint64_t>(1u << 22, 4ull * std::max(r->h_counts[1], r->h_counts[3]));
+    if (want > r->item_cap) {
+        HIPCHECK(r, r->d_items.ensure((size_t)want * 8));
+        r->item_cap = (uint32_t)std::min<uint64_t>(want, 0x7FFFFFF0ull);
+    }
+    HIPCHECK(r, r->d_recs.ensure((size_t)n_slots * sizeof(SetupRec)));
+    HIPCHECK(r, r->d_rec_of.ensure((size_t)n_src * 8 * 4));
+    uint32_t *counters = r->d_geo_counters.as<uint32_t>() + (shadow_pass ? 4 : 0);
+    HIPCHECK(r, hipMemsetAsync(counters, 0, 16, r->stream));
+    HIPCHECK(r, launch_setup(objs, T.tblock_obj, T.tblock_first, n_tblocks, d_gp, r->d_xverts.as<XVert>(), r->d_recs.as<SetupRec>(),
+                             r->d_rec_of.as<uint32_t>(), r->d_items.as<uint2>(), r->item_cap, counters, r->stream));
+    // counts for arctic_stats() and the overflow flag: copied to pinned memory, looked at only when the stream has been synchronised
+    HIPCHECK(r, hipMemcpyAsync(h, counters, 8, hipMemcpyDeviceToHost, r->stream));
+    HIPCHECK(r, hipMemcpyAsync(r->h_counts + 4 + (shadow_pass ? 1 : 0), counters + 2, 4, hipMemcpyDeviceToHost, r->stream));
     if (shadow_pass)
-        HIPCHECK(r, launch_raster_depth(r->d_recs.as<SetupRec>(), r->d_tile_offset.as<uint32_t>(), n_slots, r->raster_blocks, d_gp,
+        HIPCHECK(r, launch_raster_depth(r->d_recs.as<SetupRec>(), r->d_items.as<uint2>(), r->item_cap, counters, r->raster_blocks, d_gp,
                                         r->d_shadow.as<uint32_t>(), r->stream));
     else
-        HIPCHECK(r, launch_raster_vis(r->d_recs.as<SetupRec>(), r->d_tile_offset.as<uint32_t>(), n_slots, r->raster_blocks, d_gp,
+        HIPCHECK(r, launch_raster_vis(r->d_recs.as<SetupRec>(), r->d_items.as<uint2>(), r->item_cap, counters, r->raster_blocks, d_gp,
                                       r->d_vis.as<unsigned long long>(), r->stream));
     return ARCTIC_OK;
 }
@@ -306,7 +306,7 @@ int pass_gbuffer(ArcticRenderer *r, const ArcticScene *sc) {
     HIPCHECK(r, launch_fill_u64(r->d_vis.as<unsigned long long>(), ~0ull, r->n_tiles() * TILE_PIXELS, r->stream));
     int rc = run_geometry(r, sc, false);
     if (rc != ARCTIC_OK) return rc;
-    HIPCHECK(r, launch_resolve(r->d_vis.as<unsigned long long>(), r->d_recs.as<SetupRec>(), r->tables[0].objs,
+    HIPCHECK(r, launch_resolve(r->d_vis.as<unsigned long long>(), r->d_recs.as<SetupRec>(), r->d_rec_of.as<uint32_t>(), r->tables[0].objs,
                                r->d_xverts.as<XVert>(), r->tables[0].gp, (uint32_t)r->n_tiles(), r->gbuffer(),
                                r->d_depth.as<float>(), r->d_src.as<uint32_t>(), r->stream));
     r->have_gbuffer = true;
@@ -413,6 +413,17 @@ std::vector<uint8_t> shadow_inputs(const ArcticRenderer *r, const ArcticScene *s
     return k;
 }
 
+// after a stream synchronisation: did a rasteriser pass run out of work-item slots?  (k_setup flags it; the table is re-sized
+// from the counts of that very pass, so rendering the frame again succeeds)
+int check_item_overflow(ArcticRenderer *r) {
+    if (!r->h_counts || !(r->h_counts[4] | r->h_counts[5])) return ARCTIC_OK;
+    const uint32_t need = std::max(r->h_counts[1], r->h_counts[3]);
+    r->h_counts[4] = r->h_counts[5] = 0;
+    r->have_gbuffer = false; r->have_output = false; r->shadow_key.clear();
+    return r->fail(ARCTIC_E_CAPACITY, "rasteriser work-item table overflowed (%u items needed, %u slots): the last frame is incomplete; "
+                   "the table grows on the next pass -- render the frame again", need, r->item_cap);
+}
+
 bool valid_scene(const ArcticScene *sc) { return sc && (sc->n_objects == 0 || sc->objects); }
 
 }  // namespace
@@ -502,8 +513,8 @@ void arctic_destroy(ArcticRenderer *r) {
     for (Mesh &m : r->meshes) { if (m.d_vertices) (void)hipFree(m.d_vertices); if (m.d_indices) (void)hipFree(m.d_indices); }
     for (void *p : r->tex_allocs) (void)hipFree(p);
     DevBuf *bufs[] = {&r->d_tex, &r->d_lut, &r->d_lights, &r->d_shadow, &r->d_env, &r->d_vis, &r->d_p0, &r->d_p1, &r->d_p2, &r->d_p3, &r->d_p4,
-                      &r->d_depth, &r->d_src, &r->d_rgba8, &r->d_ldr, &r->d_hdr, &r->d_counter, &r->d_tickets, &r->d_lit0, &r->d_lit1, &r->d_lit2, &r->d_litpx, &r->d_litcount, &r->d_xverts, &r->d_sub_count, &r->d_sub_offset,
-                      &r->d_recs, &r->d_tile_count, &r->d_tile_offset, &r->d_scan, &r->d_stage, &r->tables[0].d, &r->tables[1].d};
+                      &r->d_depth, &r->d_src, &r->d_rgba8, &r->d_ldr, &r->d_hdr, &r->d_counter, &r->d_tickets, &r->d_lit0, &r->d_lit1, &r->d_lit2, &r->d_litpx, &r->d_litcount, &r->d_xverts,
+                      &r->d_recs, &r->d_rec_of, &r->d_items, &r->d_geo_counters, &r->d_stage, &r->tables[0].d, &r->tables[1].d};
     for (PassTables &T : r->tables) { if (T.h) (void)hipHostFree(T.h); if (T.copied) (void)hipEventDestroy(T.copied); }
     for (DevBuf *b : bufs) b->release();
     delete r;
@@ -527,6 +538,7 @@ int arctic_flush(ArcticRenderer *r) {
     int rc = select_device(r);
     if (rc) return rc;
     HIPCHECK(r, hipStreamSynchronize(r->stream));
+    if (int ov = check_item_overflow(r)) return ov;
     return ARCTIC_OK;
 }
 
@@ -680,6 +692,7 @@ int arctic_render_frame(ArcticRenderer *r, const ArcticScene *scene, const Arcti
     if (rc != ARCTIC_OK) return rc;
     if (out_rgba8) HIPCHECK(r, hipMemcpyAsync(out_rgba8, r->d_rgba8.p, (size_t)r->rows() * r->width * 4, hipMemcpyDeviceToHost, r->stream));
     HIPCHECK(r, hipStreamSynchronize(r->stream));
+    if (int ov = check_item_overflow(r)) return ov;
     return ARCTIC_OK;
 }
 
@@ -745,6 +758,8 @@ int arctic_read_gbuffer(ArcticRenderer *r, float *attrs, uint32_t *material, flo
     if (!r->have_gbuffer) return r->fail(ARCTIC_E_STATE, "read_gbuffer: no G-buffer");
     int rc = select_device(r);
     if (rc) return rc;
+    HIPCHECK(r, hipStreamSynchronize(r->stream));
+    if (int ov = check_item_overflow(r)) return ov;
     size_t px = (size_t)r->rows() * r->width;
     if (attrs || material) {
         HIPCHECK(r, r->d_stage.ensure(px * 76));
@@ -796,6 +811,7 @@ int arctic_read_shadow_map(ArcticRenderer *r, float *depth) {
     int rc = select_device(r);
     if (rc) return rc;
     HIPCHECK(r, hipStreamSynchronize(r->stream));
+    if (int ov = check_item_overflow(r)) return ov;
     HIPCHECK(r, hipMemcpy(depth, r->d_shadow.p, (size_t)r->shadow_size * r->shadow_size * 4, hipMemcpyDeviceToHost));
     return ARCTIC_OK;
 }
@@ -819,6 +835,7 @@ int arctic_read_output(ArcticRenderer *r, float *ldr, float *hdr, uint8_t *rgba8
     if (rc) return rc;
     size_t px = (size_t)r->rows() * r->width;
     HIPCHECK(r, hipStreamSynchronize(r->stream));
+    if (int ov = check_item_overflow(r)) return ov;
     if (ldr) HIPCHECK(r, hipMemcpy(ldr, r->d_ldr.p, px * 12, hipMemcpyDeviceToHost));
     if (hdr) HIPCHECK(r, hipMemcpy(hdr, r->d_hdr.p, px * 12, hipMemcpyDeviceToHost));
     if (rgba8) HIPCHECK(r, hipMemcpy(rgba8, r->d_rgba8.p, px * 4, hipMemcpyDeviceToHost));
