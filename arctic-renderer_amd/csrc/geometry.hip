@@ -223,17 +223,6 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v, uint32_t lane
     return v;
 }
 
-// the k-th triangle of the fan over the clipped polygon that survives setup (culling, zero area, empty bounds)
-__device__ __forceinline__ bool nth_record(const CV *poly, int n, const GeomParams &gp, uint32_t k, SetupRec &t) {
-    uint32_t seen = 0;
-    for (int f = 1; f + 1 < n; ++f) {
-        if (!setup_triangle(poly[0], poly[f], poly[f + 1], gp, t)) continue;
-        if (seen == k) return true;
-        ++seen;
-    }
-    return false;
-}
-
 __global__ __launch_bounds__(256) void k_setup(const ObjectRec *__restrict__ objs, const uint32_t *__restrict__ block_obj,
                                                const uint32_t *__restrict__ block_first, const GeomParams *__restrict__ gpp,
                                                const XVert *__restrict__ xv, SetupRec *__restrict__ recs,
@@ -245,10 +234,8 @@ __global__ __launch_bounds__(256) void k_setup(const ObjectRec *__restrict__ obj
     const uint32_t lane = threadIdx.x & 63;
     const GeomParams gp = *gpp;
     const uint32_t src = ob.first_triangle + ti;
-    uint32_t produced = 0;
-    int n = 0;
+    int n = 0;   // vertices of the clipped polygon; 0: no triangle in this lane
     CV poly[MAX_POLY];
-    SetupRec t0;   // the first record stays in registers: unclipped triangles (nearly all) are set up exactly once
     if (ti < ob.n_triangles) {
         const uint32_t idx[3] = {ob.indices[3 * ti], ob.indices[3 * ti + 1], ob.indices[3 * ti + 2]};
         if (idx[0] < ob.n_vertices && idx[1] < ob.n_vertices && idx[2] < ob.n_vertices) {
@@ -264,36 +251,41 @@ __global__ __launch_bounds__(256) void k_setup(const ObjectRec *__restrict__ obj
 #pragma unroll
                 for (int p = 0; p < 6; ++p) inside = inside && (plane_dist(poly[k], p) >= 0.0f);
             n = inside ? 3 : clip_polygon(poly, 3);
-            for (int f = 1; f + 1 < n; ++f) {
-                SetupRec t;
-                if (!setup_triangle(poly[0], poly[f], poly[f + 1], gp, t)) continue;
-                if (produced == 0) t0 = t;
-                ++produced;
-            }
         }
     }
-    // record slots: one atomicAdd per wave
-    const uint32_t incl = wave_inclusive_sum(produced, lane);
-    uint32_t rbase = 0;
-    if (lane == 63 && incl) rbase = atomicAdd(&counters[0], incl);
-    const uint32_t out = __shfl(rbase, 63) + incl - produced;
-    // records and their work items, sub-triangle by sub-triangle (the loop runs once unless a triangle of the wave was clipped)
-    for (uint32_t k = 0; __ballot(k < produced) != 0ull; ++k) {
-        uint32_t nb = 0;
-        const uint32_t r = out + k;
-        if (k < produced) {
-            SetupRec t;
-            if (k == 0) t = t0; else nth_record(poly, n, gp, k, t);
-            t.src_tri = src; t.object = oi; t.order_id = src * 8u + k; t.pad = 0;
-            recs[r] = t;
-            rec_of[src * 8u + k] = r;
-            nb = tiles_of(t);
-        }
+    // the fan over the polygon, one triangle per trip (one trip unless a triangle of this workgroup was clipped); every trip
+    // takes the workgroup's record slots and work-item slots with ONE atomicAdd each (a same-address atomic retires at
+    // ~88 per microsecond: one per wave was 40 us of this kernel), split among the four waves through LDS
+    __shared__ uint32_t s_count[4][2], s_base[2];
+    const uint32_t wave = threadIdx.x >> 6;
+    uint32_t produced = 0;   // sub-triangles this lane has emitted so far = index of the next one in draw order
+    for (int f = 1; __syncthreads_or(f + 1 < n); ++f) {
+        SetupRec t;
+        const bool has = (f + 1 < n) && setup_triangle(poly[0], poly[f], poly[f + 1], gp, t);
+        const uint32_t nb = has ? tiles_of(t) : 0u;
+        const unsigned long long m = __ballot(has);
         const uint32_t iincl = wave_inclusive_sum(nb, lane);
-        uint32_t ibase = 0;
-        if (lane == 63 && iincl) ibase = atomicAdd(&counters[1], iincl);
-        ibase = __shfl(ibase, 63) + iincl - nb;
-        if (__shfl(ibase, 63) + __shfl(nb, 63) > item_cap && lane == 0) counters[2] = 1;   // table full: reported by the host
+        const uint32_t itotal = __shfl(iincl, 63);
+        if (lane == 0) { s_count[wave][0] = (uint32_t)__popcll(m); s_count[wave][1] = itotal; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t nr = s_count[0][0] + s_count[1][0] + s_count[2][0] + s_count[3][0];
+            const uint32_t ni = s_count[0][1] + s_count[1][1] + s_count[2][1] + s_count[3][1];
+            s_base[0] = nr ? atomicAdd(&counters[0], nr) : 0u;
+            s_base[1] = ni ? atomicAdd(&counters[1], ni) : 0u;
+            if (s_base[1] + ni > item_cap) counters[2] = 1;   // table full: reported by the host
+        }
+        __syncthreads();
+        uint32_t rbase = s_base[0], ibase = s_base[1];
+        for (uint32_t w = 0; w < wave; ++w) { rbase += s_count[w][0]; ibase += s_count[w][1]; }
+        ibase += iincl - nb;
+        const uint32_t r = rbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (has) {
+            t.src_tri = src; t.object = oi; t.order_id = src * 8u + produced; t.pad = 0;
+            recs[r] = t;
+            rec_of[src * 8u + produced] = r;
+            ++produced;
+        }
         // small records: the lane writes its own items; large ones (a wall across the screen is thousands of blocks): the
         // whole wave writes them, 64 per step
         if (nb <= 16)
