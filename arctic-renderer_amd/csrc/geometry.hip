@@ -303,51 +303,85 @@ __global__ __launch_bounds__(256) void k_setup(const ObjectRec *__restrict__ obj
 // ---------------------------------------------------------------------------------------------
 // Persistent: the number of work items is only known on the device (counters[1]), so a fixed grid strides over the item
 // table and the host never waits for a count.
+// one work item: the lane's 2x2 quad of the 16x16 block `local` of record t.  The four early depth reads are issued
+// together (one memory round trip per item, not four), then the atomics of the pixels that still win.
+template <bool DEPTH_ONLY>
+__device__ __forceinline__ void raster_item(const SetupRec &t, uint32_t local, uint32_t lane, const GeomParams *__restrict__ gpp,
+                                            unsigned long long *__restrict__ vis, uint32_t *__restrict__ depth_bits) {
+    const int32_t bx0 = t.px0 >> 4, by0 = t.py0 >> 4;
+    const uint32_t nbx = (uint32_t)((t.px1 >> 4) - bx0 + 1);
+    const int32_t qx = (bx0 + (int32_t)(local % nbx)) * 16 + (int32_t)(lane & 7) * 2;   // this lane's 2x2 quad
+    const int32_t qy = (by0 + (int32_t)(local / nbx)) * 16 + (int32_t)(lane >> 3) * 2;
+    if (qx > t.px1 || qx + 1 < t.px0 || qy > t.py1 || qy + 1 < t.py0) return;
+    Edges e;
+    make_edges(t, e);
+    const float inv_area = 1.0f / (float)t.area2;
+    // edge functions at the quad's first pixel; one pixel right adds -dy*256, one pixel down adds dx*256 (exact integers)
+    const int64_t e0 = edge_eval(e, 0, qx, qy), e1 = edge_eval(e, 1, qx, qy), e2 = edge_eval(e, 2, qx, qy);
+    bool ok[4];
+    size_t at[4];
+    unsigned long long key[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int dx = k & 1, dy = k >> 1;
+        const int32_t px = qx + dx, py = qy + dy;
+        ok[k] = !(px < t.px0 || px > t.px1 || py < t.py0 || py > t.py1);
+        const int64_t f0 = e0 + (dy ? e.dx[0] * 256 : 0) - (dx ? e.dy[0] * 256 : 0);
+        const int64_t f1 = e1 + (dy ? e.dx[1] * 256 : 0) - (dx ? e.dy[1] * 256 : 0);
+        const int64_t f2 = e2 + (dy ? e.dx[2] * 256 : 0) - (dx ? e.dy[2] * 256 : 0);
+        ok[k] = ok[k] && !((f0 + e.bias[0]) < 0 || (f1 + e.bias[1]) < 0 || (f2 + e.bias[2]) < 0);
+        const float l1 = (float)f2 * inv_area, l2 = (float)f0 * inv_area;
+        float z = fmaf(l2, t.z[2] - t.z[0], fmaf(l1, t.z[1] - t.z[0], t.z[0]));
+        z = fminf(fmaxf(z, 0.0f), 1.0f);
+        ok[k] = ok[k] && (z < 1.0f);   // depth LESS against the 1.0 clear
+        at[k] = 0;
+        if (DEPTH_ONLY) {
+            at[k] = (size_t)py * gpp->pitch + px;
+            key[k] = __float_as_uint(z);
+        } else {
+            const int ty_rel = (py >> 3) - gpp->tile_y0;
+            ok[k] = ok[k] && row_owned(ty_rel, gpp->band_tiles, gpp->shard_count, gpp->shard_index);   // else another shard's band
+            at[k] = ((size_t)row_local(ty_rel, gpp->band_tiles, gpp->shard_count) * gpp->tiles_x + (px >> 3)) * 64 + (py & 7) * 8 + (px & 7);
+            key[k] = ((unsigned long long)__float_as_uint(z) << 32) | t.order_id;   // ties: first drawn (smallest order id) wins
+        }
+    }
+    unsigned long long cur[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        cur[k] = 0ull;
+        if (ok[k]) cur[k] = DEPTH_ONLY ? (unsigned long long)depth_bits[at[k]] : vis[at[k]];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (ok[k] && key[k] < cur[k]) {
+            if (DEPTH_ONLY) atomicMin(depth_bits + at[k], (uint32_t)key[k]);
+            else atomicMin(vis + at[k], key[k]);
+        }
+}
+
+// Persistent: the number of work items is only known on the device (counters[1]), so a fixed grid strides over the item
+// table and the host never waits for a count.  Software pipeline, two items deep: while item i is rasterised the record
+// of item i+1 (scalar loads, its index arrived a trip ago) and the table entry of item i+2 are in flight, so a wave pays
+// the entry -> record -> pixels chain of dependent round trips once, not per item.
 template <bool DEPTH_ONLY>
 __global__ __launch_bounds__(256) void k_raster(const SetupRec *__restrict__ recs, const uint2 *__restrict__ items, uint32_t item_cap,
                                                 const uint32_t *__restrict__ counters, const GeomParams *__restrict__ gpp,
                                                 unsigned long long *__restrict__ vis, uint32_t *__restrict__ depth_bits) {
     const uint32_t n_items = min(counters[1], item_cap);
     const uint32_t lane = threadIdx.x & 63;
-    for (uint32_t item = blockIdx.x * 4 + (threadIdx.x >> 6); item < n_items; item += gridDim.x * 4) {
-        const uint2 it = items[item];
-        const uint32_t r = __builtin_amdgcn_readfirstlane(it.x), local = __builtin_amdgcn_readfirstlane(it.y);
-        const SetupRec &t = recs[r];
-        int32_t bx0 = t.px0 >> 4, by0 = t.py0 >> 4;
-        uint32_t nbx = (uint32_t)((t.px1 >> 4) - bx0 + 1);
-        const int32_t qx = (bx0 + (int32_t)(local % nbx)) * 16 + (int32_t)(lane & 7) * 2;   // this lane's 2x2 quad
-        const int32_t qy = (by0 + (int32_t)(local / nbx)) * 16 + (int32_t)(lane >> 3) * 2;
-        if (qx > t.px1 || qx + 1 < t.px0 || qy > t.py1 || qy + 1 < t.py0) continue;
-        Edges e;
-        make_edges(t, e);
-        const float inv_area = 1.0f / (float)t.area2;
-        // edge functions at the quad's first pixel; one pixel right adds -dy*256, one pixel down adds dx*256 (exact integers)
-        const int64_t e0 = edge_eval(e, 0, qx, qy), e1 = edge_eval(e, 1, qx, qy), e2 = edge_eval(e, 2, qx, qy);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int dx = k & 1, dy = k >> 1;
-            const int32_t px = qx + dx, py = qy + dy;
-            if (px < t.px0 || px > t.px1 || py < t.py0 || py > t.py1) continue;
-            const int64_t f0 = e0 + (dy ? e.dx[0] * 256 : 0) - (dx ? e.dy[0] * 256 : 0);
-            const int64_t f1 = e1 + (dy ? e.dx[1] * 256 : 0) - (dx ? e.dy[1] * 256 : 0);
-            const int64_t f2 = e2 + (dy ? e.dx[2] * 256 : 0) - (dx ? e.dy[2] * 256 : 0);
-            if ((f0 + e.bias[0]) < 0 || (f1 + e.bias[1]) < 0 || (f2 + e.bias[2]) < 0) continue;
-            const float l1 = (float)f2 * inv_area, l2 = (float)f0 * inv_area;
-            float z = fmaf(l2, t.z[2] - t.z[0], fmaf(l1, t.z[1] - t.z[0], t.z[0]));
-            z = fminf(fmaxf(z, 0.0f), 1.0f);
-            if (!(z < 1.0f)) continue;   // depth LESS against the 1.0 clear
-            if (DEPTH_ONLY) {
-                uint32_t *p = depth_bits + (size_t)py * gpp->pitch + px;
-                uint32_t zb = __float_as_uint(z);
-                if (zb < *p) atomicMin(p, zb);
-            } else {
-                const int ty_rel = (py >> 3) - gpp->tile_y0;
-                if (!row_owned(ty_rel, gpp->band_tiles, gpp->shard_count, gpp->shard_index)) continue;   // another shard's band
-                size_t idx = ((size_t)row_local(ty_rel, gpp->band_tiles, gpp->shard_count) * gpp->tiles_x + (px >> 3)) * 64 + (py & 7) * 8 + (px & 7);
-                unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | t.order_id;   // ties: first drawn (smallest order id) wins
-                if (key < vis[idx]) atomicMin(&vis[idx], key);
-            }
-        }
+    const uint32_t stride = gridDim.x * 4;
+    uint32_t item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= n_items) return;
+    uint2 e1 = items[item];
+    SetupRec cur = recs[__builtin_amdgcn_readfirstlane(e1.x)];
+    uint32_t local = __builtin_amdgcn_readfirstlane(e1.y);
+    e1 = items[min(item + stride, n_items - 1)];
+    for (; item < n_items; item += stride) {
+        const uint32_t r1 = __builtin_amdgcn_readfirstlane(e1.x), local1 = __builtin_amdgcn_readfirstlane(e1.y);
+        const SetupRec nxt = recs[r1];                                   // used next trip
+        e1 = items[min(item + 2 * stride, n_items - 1)];                 // used the trip after
+        raster_item<DEPTH_ONLY>(cur, local, lane, gpp, vis, depth_bits);
+        cur = nxt; local = local1;
     }
 }
 
