@@ -301,47 +301,61 @@ __global__ __launch_bounds__(256) void k_setup(const ObjectRec *__restrict__ obj
 // ---------------------------------------------------------------------------------------------
 // raster: one wavefront per (triangle, 16x16 block) work item, a 2x2 pixel quad per lane
 // ---------------------------------------------------------------------------------------------
-// Persistent: the number of work items is only known on the device (counters[1]), so a fixed grid strides over the item
-// table and the host never waits for a count.
-// one work item: the lane's 2x2 quad of the 16x16 block `local` of record t.  The four early depth reads are issued
-// together (one memory round trip per item, not four), then the atomics of the pixels that still win.
+// one work item: the lane's 2x2 quad of the 16x16 block `local` of record t.  Everything that depends only on the
+// record and the block (edge setup, the edge functions at the block's first pixel, 64-bit) is wave-uniform and runs on the
+// scalar unit; a lane adds its own offset with two 32x32+64 multiply-adds per edge (the 24.8 coordinates, their
+// differences and the offsets inside a block all fit 32 bits), then +-dx*256 / dy*256 per pixel of the quad: the same exact
+// integers as edge_eval at every pixel.  The four early depth reads are issued together (one memory round trip per item,
+// not four), then the atomics of the pixels that still win.
 template <bool DEPTH_ONLY>
 __device__ __forceinline__ void raster_item(const SetupRec &t, uint32_t local, uint32_t lane, const GeomParams *__restrict__ gpp,
                                             unsigned long long *__restrict__ vis, uint32_t *__restrict__ depth_bits) {
     const int32_t bx0 = t.px0 >> 4, by0 = t.py0 >> 4;
     const uint32_t nbx = (uint32_t)((t.px1 >> 4) - bx0 + 1);
-    const int32_t qx = (bx0 + (int32_t)(local % nbx)) * 16 + (int32_t)(lane & 7) * 2;   // this lane's 2x2 quad
-    const int32_t qy = (by0 + (int32_t)(local / nbx)) * 16 + (int32_t)(lane >> 3) * 2;
+    const int32_t ox = (bx0 + (int32_t)(local % nbx)) * 16, oy = (by0 + (int32_t)(local / nbx)) * 16;   // the block's first pixel
+    const int32_t lx = (int32_t)(lane & 7) * 2, ly = (int32_t)(lane >> 3) * 2;                          // this lane's 2x2 quad in it
+    const int32_t qx = ox + lx, qy = oy + ly;
     if (qx > t.px1 || qx + 1 < t.px0 || qy > t.py1 || qy + 1 < t.py0) return;
     Edges e;
     make_edges(t, e);
     const float inv_area = 1.0f / (float)t.area2;
-    // edge functions at the quad's first pixel; one pixel right adds -dy*256, one pixel down adds dx*256 (exact integers)
-    const int64_t e0 = edge_eval(e, 0, qx, qy), e1 = edge_eval(e, 1, qx, qy), e2 = edge_eval(e, 2, qx, qy);
+    int64_t eq[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        eq[i] = edge_eval(e, i, ox, oy) + (int64_t)(int32_t)e.dx[i] * (int64_t)(ly * 256) - (int64_t)(int32_t)e.dy[i] * (int64_t)(lx * 256);
+    // target row: both rows of the quad lie in the same 8-pixel tile row (qy is even)
+    uint32_t row_base = 0;
+    bool owned = true;
+    if (!DEPTH_ONLY) {
+        const int ty_rel = (qy >> 3) - gpp->tile_y0;
+        int lrow = ty_rel;
+        if (gpp->band_tiles != 0) {   // interleaved shard: rows of other shards are skipped, the own ones are packed
+            owned = row_owned(ty_rel, gpp->band_tiles, gpp->shard_count, gpp->shard_index);
+            lrow = row_local(ty_rel, gpp->band_tiles, gpp->shard_count);
+        }
+        row_base = (uint32_t)lrow * (uint32_t)gpp->tiles_x;
+    }
     bool ok[4];
-    size_t at[4];
+    uint32_t at[4];
     unsigned long long key[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int dx = k & 1, dy = k >> 1;
         const int32_t px = qx + dx, py = qy + dy;
-        ok[k] = !(px < t.px0 || px > t.px1 || py < t.py0 || py > t.py1);
-        const int64_t f0 = e0 + (dy ? e.dx[0] * 256 : 0) - (dx ? e.dy[0] * 256 : 0);
-        const int64_t f1 = e1 + (dy ? e.dx[1] * 256 : 0) - (dx ? e.dy[1] * 256 : 0);
-        const int64_t f2 = e2 + (dy ? e.dx[2] * 256 : 0) - (dx ? e.dy[2] * 256 : 0);
+        ok[k] = owned && !(px < t.px0 || px > t.px1 || py < t.py0 || py > t.py1);
+        const int64_t f0 = eq[0] + (dy ? e.dx[0] * 256 : 0) - (dx ? e.dy[0] * 256 : 0);
+        const int64_t f1 = eq[1] + (dy ? e.dx[1] * 256 : 0) - (dx ? e.dy[1] * 256 : 0);
+        const int64_t f2 = eq[2] + (dy ? e.dx[2] * 256 : 0) - (dx ? e.dy[2] * 256 : 0);
         ok[k] = ok[k] && !((f0 + e.bias[0]) < 0 || (f1 + e.bias[1]) < 0 || (f2 + e.bias[2]) < 0);
         const float l1 = (float)f2 * inv_area, l2 = (float)f0 * inv_area;
         float z = fmaf(l2, t.z[2] - t.z[0], fmaf(l1, t.z[1] - t.z[0], t.z[0]));
         z = fminf(fmaxf(z, 0.0f), 1.0f);
         ok[k] = ok[k] && (z < 1.0f);   // depth LESS against the 1.0 clear
-        at[k] = 0;
         if (DEPTH_ONLY) {
-            at[k] = (size_t)py * gpp->pitch + px;
+            at[k] = (uint32_t)py * (uint32_t)gpp->pitch + (uint32_t)px;
             key[k] = __float_as_uint(z);
         } else {
-            const int ty_rel = (py >> 3) - gpp->tile_y0;
-            ok[k] = ok[k] && row_owned(ty_rel, gpp->band_tiles, gpp->shard_count, gpp->shard_index);   // else another shard's band
-            at[k] = ((size_t)row_local(ty_rel, gpp->band_tiles, gpp->shard_count) * gpp->tiles_x + (px >> 3)) * 64 + (py & 7) * 8 + (px & 7);
+            at[k] = (row_base + ((uint32_t)px >> 3)) * 64u + ((uint32_t)py & 7u) * 8u + ((uint32_t)px & 7u);
             key[k] = ((unsigned long long)__float_as_uint(z) << 32) | t.order_id;   // ties: first drawn (smallest order id) wins
         }
     }
