@@ -167,7 +167,7 @@ hipError_t launch_raster_vis(const SetupRec *recs, const uint2 *items, uint32_t 
 hipError_t launch_raster_depth(const SetupRec *recs, const uint2 *items, uint32_t item_cap, const uint32_t *counters, uint32_t grid_blocks,
                                const GeomParams *gp, uint32_t *depth_bits, hipStream_t s);
 hipError_t launch_resolve(const unsigned long long *vis, const SetupRec *recs, const uint32_t *rec_of, const ObjectRec *objs, const XVert *xv,
-                          const GeomParams *gp, uint32_t n_tiles, GBuffer g, float *depth_out, uint32_t *src_out, hipStream_t s);
+                          const GeomParams *gp, uint32_t n_tiles, GBuffer g, hipStream_t s);
 hipError_t launch_fill_u64(unsigned long long *p, unsigned long long v, size_t n, hipStream_t s);
 hipError_t launch_fill_u32(uint32_t *p, uint32_t v, size_t n, hipStream_t s);
 hipError_t launch_shade(const ShadeParams &sp, const ShadeLaunch &L);

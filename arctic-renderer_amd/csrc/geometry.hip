@@ -404,8 +404,7 @@ __global__ __launch_bounds__(256) void k_raster(const SetupRec *__restrict__ rec
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_resolve(const unsigned long long *__restrict__ vis, const SetupRec *__restrict__ recs,
                                                  const uint32_t *__restrict__ rec_of, const ObjectRec *__restrict__ objs, const XVert *__restrict__ xv,
-                                                 const GeomParams *__restrict__ gpp, uint32_t n_tiles, GBuffer g,
-                                                 float *__restrict__ depth_out, uint32_t *__restrict__ src_out) {
+                                                 const GeomParams *__restrict__ gpp, uint32_t n_tiles, GBuffer g) {
     uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tile >= n_tiles) return;
     uint32_t lane = threadIdx.x & 63;
@@ -414,11 +413,9 @@ __global__ __launch_bounds__(256) void k_resolve(const unsigned long long *__res
     float a[18];
 #pragma unroll
     for (int k = 0; k < 18; ++k) a[k] = 0.0f;
-    uint32_t mat = NO_MATERIAL, src = 0xFFFFFFFFu;
-    float depth = 1.0f;
+    uint32_t mat = NO_MATERIAL;
     if (key != ~0ull) {
         const SetupRec &t = recs[rec_of[(uint32_t)key]];   // low word = order id (k_setup)
-        depth = __uint_as_float((uint32_t)(key >> 32));
         int32_t tx = (int32_t)(tile % (uint32_t)gpp->tiles_x);
         int32_t ty = row_global((int)(tile / (uint32_t)gpp->tiles_x), gpp->band_tiles, gpp->shard_count, gpp->shard_index) + gpp->tile_y0;
         int32_t px = tx * 8 + (int32_t)(lane & 7), py = ty * 8 + (int32_t)(lane >> 3);
@@ -442,7 +439,6 @@ __global__ __launch_bounds__(256) void k_resolve(const unsigned long long *__res
 #pragma unroll
         for (int k = 0; k < 18; ++k) a[k] = (B[0] * A0[k] + B[1] * A1[k]) + B[2] * A2[k];
         mat = ob.material;
-        src = t.src_tri;
     }
     {
         float4 A, C, D, E; float B3[3];
@@ -450,8 +446,6 @@ __global__ __launch_bounds__(256) void k_resolve(const unsigned long long *__res
         g.a[idx] = A; g.c[idx] = C; g.d[idx] = D; g.e[idx] = E;
         g.b[idx * 3] = B3[0]; g.b[idx * 3 + 1] = B3[1]; g.b[idx * 3 + 2] = B3[2];
     }
-    if (depth_out) depth_out[idx] = depth;
-    if (src_out) src_out[idx] = src;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -534,9 +528,9 @@ hipError_t launch_raster_depth(const SetupRec *recs, const uint2 *items, uint32_
 }
 
 hipError_t launch_resolve(const unsigned long long *vis, const SetupRec *recs, const uint32_t *rec_of, const ObjectRec *objs, const XVert *xv,
-                          const GeomParams *gp, uint32_t n_tiles, GBuffer g, float *depth_out, uint32_t *src_out, hipStream_t s) {
+                          const GeomParams *gp, uint32_t n_tiles, GBuffer g, hipStream_t s) {
     if (n_tiles == 0) return hipSuccess;
-    k_resolve<<<div_up(n_tiles, 4), 256, 0, s>>>(vis, recs, rec_of, objs, xv, gp, n_tiles, g, depth_out, src_out);
+    k_resolve<<<div_up(n_tiles, 4), 256, 0, s>>>(vis, recs, rec_of, objs, xv, gp, n_tiles, g);
     return hipGetLastError();
 }
 

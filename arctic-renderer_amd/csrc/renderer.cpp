@@ -74,9 +74,9 @@ struct ArcticRenderer {
     uint32_t env_w = 0, env_h = 0;
     uint32_t n_lights = 0;
     // frame targets
-    DevBuf d_vis, d_p0, d_p1, d_p2, d_p3, d_p4, d_depth, d_src, d_rgba8, d_ldr, d_hdr, d_counter;
+    DevBuf d_vis, d_p0, d_p1, d_p2, d_p3, d_p4, d_rgba8, d_ldr, d_hdr, d_counter;
     DevBuf d_lit0, d_lit1, d_lit2, d_litpx, d_litcount;   // lit-pixel stream between k_material and k_light
-    bool have_gbuffer = false, have_output = false;
+    bool have_gbuffer = false, have_output = false, have_vis = false;   // have_vis: d_vis holds the visibility of the current G-buffer
     // per-frame geometry scratch
     PassTables tables[2];   // [0] forward pass, [1] shadow pass
     DevBuf d_xverts, d_recs, d_rec_of, d_items, d_geo_counters, d_stage;
@@ -148,8 +148,6 @@ int alloc_targets(ArcticRenderer *r) {
     HIPCHECK(r, r->d_p2.ensure(px * 16));
     HIPCHECK(r, r->d_p3.ensure(px * 16));
     HIPCHECK(r, r->d_p4.ensure(px * 12));
-    HIPCHECK(r, r->d_depth.ensure(px * 4));
-    HIPCHECK(r, r->d_src.ensure(px * 4));
     HIPCHECK(r, r->d_rgba8.ensure(out_px * 4));
     HIPCHECK(r, r->d_counter.ensure(64));
     HIPCHECK(r, r->d_geo_counters.ensure(32));
@@ -167,7 +165,7 @@ int alloc_targets(ArcticRenderer *r) {
         HIPCHECK(r, hipMemsetAsync(r->d_litcount.p, 0, (size_t)2 * MAX_BANDS * LIT_SHARDS * LIT_COUNTER_STRIDE * 4, r->stream));
         r->lit_parity = 0;
     }
-    r->have_gbuffer = r->have_output = false;
+    r->have_gbuffer = r->have_output = r->have_vis = false;
     return ARCTIC_OK;
 }
 
@@ -308,8 +306,8 @@ int pass_gbuffer(ArcticRenderer *r, const ArcticScene *sc) {
     if (rc != ARCTIC_OK) return rc;
     HIPCHECK(r, launch_resolve(r->d_vis.as<unsigned long long>(), r->d_recs.as<SetupRec>(), r->d_rec_of.as<uint32_t>(), r->tables[0].objs,
                                r->d_xverts.as<XVert>(), r->tables[0].gp, (uint32_t)r->n_tiles(), r->gbuffer(),
-                               r->d_depth.as<float>(), r->d_src.as<uint32_t>(), r->stream));
-    r->have_gbuffer = true;
+                               r->stream));
+    r->have_gbuffer = r->have_vis = true;
     return ARCTIC_OK;
 }
 
@@ -419,7 +417,7 @@ int check_item_overflow(ArcticRenderer *r) {
     if (!r->h_counts || !(r->h_counts[4] | r->h_counts[5])) return ARCTIC_OK;
     const uint32_t need = std::max(r->h_counts[1], r->h_counts[3]);
     r->h_counts[4] = r->h_counts[5] = 0;
-    r->have_gbuffer = false; r->have_output = false; r->shadow_key.clear();
+    r->have_gbuffer = false; r->have_output = false; r->have_vis = false; r->shadow_key.clear();
     return r->fail(ARCTIC_E_CAPACITY, "rasteriser work-item table overflowed (%u items needed, %u slots): the last frame is incomplete; "
                    "the table grows on the next pass -- render the frame again", need, r->item_cap);
 }
@@ -513,7 +511,7 @@ void arctic_destroy(ArcticRenderer *r) {
     for (Mesh &m : r->meshes) { if (m.d_vertices) (void)hipFree(m.d_vertices); if (m.d_indices) (void)hipFree(m.d_indices); }
     for (void *p : r->tex_allocs) (void)hipFree(p);
     DevBuf *bufs[] = {&r->d_tex, &r->d_lut, &r->d_lights, &r->d_shadow, &r->d_env, &r->d_vis, &r->d_p0, &r->d_p1, &r->d_p2, &r->d_p3, &r->d_p4,
-                      &r->d_depth, &r->d_src, &r->d_rgba8, &r->d_ldr, &r->d_hdr, &r->d_counter, &r->d_tickets, &r->d_lit0, &r->d_lit1, &r->d_lit2, &r->d_litpx, &r->d_litcount, &r->d_xverts,
+                      &r->d_rgba8, &r->d_ldr, &r->d_hdr, &r->d_counter, &r->d_tickets, &r->d_lit0, &r->d_lit1, &r->d_lit2, &r->d_litpx, &r->d_litcount, &r->d_xverts,
                       &r->d_recs, &r->d_rec_of, &r->d_items, &r->d_geo_counters, &r->d_stage, &r->tables[0].d, &r->tables[1].d};
     for (PassTables &T : r->tables) { if (T.h) (void)hipHostFree(T.h); if (T.copied) (void)hipEventDestroy(T.copied); }
     for (DevBuf *b : bufs) b->release();
@@ -771,18 +769,21 @@ int arctic_read_gbuffer(ArcticRenderer *r, float *attrs, uint32_t *material, flo
         HIPCHECK(r, hipStreamSynchronize(r->stream));
     }
     if (depth || tri) {
+        // both come straight from the visibility plane the prepass resolved: key = depth bits << 32 | order id, and
+        // order id = 8 * (draw-order index of the source triangle) + sub-triangle (k_setup); ~0 = nothing drawn
+        if (!r->have_vis) return r->fail(ARCTIC_E_STATE, "read_gbuffer: depth / triangle ids exist only after arctic_pass_gbuffer (not after arctic_write_gbuffer)");
         size_t tp = r->n_tiles() * TILE_PIXELS;
-        std::vector<float> hd(depth ? tp : 0);
-        std::vector<uint32_t> ht(tri ? tp : 0);
+        std::vector<unsigned long long> hv(tp);
         HIPCHECK(r, hipStreamSynchronize(r->stream));
-        if (depth) HIPCHECK(r, hipMemcpy(hd.data(), r->d_depth.p, tp * 4, hipMemcpyDeviceToHost));
-        if (tri) HIPCHECK(r, hipMemcpy(ht.data(), r->d_src.p, tp * 4, hipMemcpyDeviceToHost));
+        HIPCHECK(r, hipMemcpy(hv.data(), r->d_vis.p, tp * 8, hipMemcpyDeviceToHost));
         for (uint32_t y = 0; y < r->rows(); ++y)
             for (uint32_t x = 0; x < r->width; ++x) {
                 uint32_t yy = y + r->row0_in_tile;
                 size_t idx = ((size_t)(yy / 8) * r->tiles_x + x / 8) * 64 + (yy % 8) * 8 + (x % 8);
-                if (depth) depth[(size_t)y * r->width + x] = hd[idx];
-                if (tri) tri[(size_t)y * r->width + x] = ht[idx];
+                const unsigned long long key = hv[idx];
+                const uint32_t zb = key == ~0ull ? 0x3F800000u : (uint32_t)(key >> 32);
+                if (depth) std::memcpy(&depth[(size_t)y * r->width + x], &zb, 4);
+                if (tri) tri[(size_t)y * r->width + x] = key == ~0ull ? 0xFFFFFFFFu : (uint32_t)key >> 3;
             }
     }
     return ARCTIC_OK;
@@ -801,6 +802,7 @@ int arctic_write_gbuffer(ArcticRenderer *r, const float *attrs, const uint32_t *
     HIPCHECK(r, hipMemcpyAsync(d_mat, material, px * 4, hipMemcpyHostToDevice, r->stream));
     HIPCHECK(r, launch_gbuffer_tile(r->gbuffer(), d_attrs, d_mat, r->width, r->rows(), r->row0_in_tile, r->tiles_x, r->tiles_y, 1, r->stream));
     HIPCHECK(r, hipStreamSynchronize(r->stream));
+    r->have_vis = false;
     r->have_gbuffer = true;
     return ARCTIC_OK;
 }
