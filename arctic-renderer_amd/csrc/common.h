@@ -129,6 +129,8 @@ struct ShadeParams {
     float4 *lit_r0, *lit_r1, *lit_r2;   // (world.xyz, 1-shadow) (n.xyz, roughness) (base.xyz, metalness)
     uint32_t *lit_px;                   // pixel index y*width + x inside the shard
     uint32_t *lit_count;                // LIT_SHARDS counters per band, LIT_COUNTER_STRIDE apart: this pass's set ...
+    // whole frames without a G-buffer (k_material_vis): the visibility plane and what the prepass left behind
+    const unsigned long long *vis; const SetupRec *recs; const uint32_t *rec_of; const ObjectRec *objs; const XVert *xv;
     uint32_t *tickets;                  // fused kernel: 8 per-XCD tile tickets + 1 exit counter, 128 B apart, zero between passes
     uint32_t *lit_count_next;           // ... and the other set, which k_light clears for the next pass
     // skybox (skybox.hlsl:61-90): environment map for pixels without geometry; env == null -> black
@@ -149,6 +151,7 @@ struct ShadeLaunch {
     uint32_t n_bands, light_blocks;
     uint32_t lights_per_trip;   // k_light variant: 4 (two packed pairs per loop trip, 121 VGPRs) or 2 (one pair, 96 VGPRs)
     hipEvent_t mid;   // optional: recorded between k_material and k_light (single band), for per-kernel timing
+    uint32_t from_vis;              // 1: k_material_vis (attributes interpolated from the visibility plane) instead of k_material
     uint32_t fused, fused_blocks;   // 1: the whole pass as one persistent kernel (k_shade_fused) of fused_blocks workgroups
 };
 constexpr uint32_t LIT_SHARDS = 256, LIT_COUNTER_STRIDE = 32;

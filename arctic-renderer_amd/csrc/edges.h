@@ -1,0 +1,53 @@
+// edges.h -- the integer edge functions shared by the rasteriser (geometry.hip) and the visibility-buffer shading kernel
+// (shade.hip): device code only.
+#pragma once
+#include "common.h"
+
+namespace arctic {
+
+// edge i: vertex i -> vertex (i+1)%3, inside-positive; bias implements the top-left rule
+struct Edges {
+    int64_t dx[3], dy[3];
+    int32_t x0[3], y0[3];
+    int64_t bias[3];
+};
+__device__ __forceinline__ void make_edges(const SetupRec &t, Edges &e) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        int j = (i + 1) % 3;
+        e.dx[i] = (int64_t)t.X[j] - t.X[i];
+        e.dy[i] = (int64_t)t.Y[j] - t.Y[i];
+        e.x0[i] = t.X[i]; e.y0[i] = t.Y[i];
+        bool top_left = (e.dy[i] == 0 && e.dx[i] > 0) || (e.dy[i] < 0);
+        e.bias[i] = top_left ? 0 : -1;
+    }
+}
+__device__ __forceinline__ int64_t edge_eval(const Edges &e, int i, int32_t px, int32_t py) {
+    int64_t Px = (int64_t)px * 256 + 128, Py = (int64_t)py * 256 + 128;
+    return e.dx[i] * (Py - e.y0[i]) - e.dy[i] * (Px - e.x0[i]);
+}
+
+// perspective-correct barycentrics of pixel (px, py) with respect to the SOURCE triangle of record t (the weights the 18
+// VSOut attributes are interpolated with): screen-space barycentrics from the edge functions, 1/w correction, then through
+// the record's own barycentric coordinates in its source triangle, so clipped triangles need no vertices of their own.
+// Every operation rounds once, in this order, wherever it is compiled (the callers disable fp contraction).
+__device__ __forceinline__ void source_barycentrics(const SetupRec &t, int32_t px, int32_t py, float B[3]) {
+#pragma clang fp contract(off)
+    Edges e;
+    make_edges(t, e);
+    const float inv_area = 1.0f / (float)t.area2;
+    const float l1 = (float)edge_eval(e, 2, px, py) * inv_area;
+    const float l2 = (float)edge_eval(e, 0, px, py) * inv_area;
+    const float l0 = (1.0f - l1) - l2;
+    const float pw0 = l0 * t.iw[0], pw1 = l1 * t.iw[1], pw2 = l2 * t.iw[2];
+    const float rr = 1.0f / ((pw0 + pw1) + pw2);
+    const float b0 = pw0 * rr, b1 = pw1 * rr, b2 = pw2 * rr;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) B[k] = (b0 * t.bary[0][k] + b1 * t.bary[1][k]) + b2 * t.bary[2][k];
+}
+__device__ __forceinline__ float interpolate_attr(const float B[3], const float *A0, const float *A1, const float *A2, int k) {
+#pragma clang fp contract(off)
+    return (B[0] * A0[k] + B[1] * A1[k]) + B[2] * A2[k];
+}
+
+}  // namespace arctic

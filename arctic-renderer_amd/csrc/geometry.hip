@@ -22,6 +22,7 @@
 // operation rounds once, in a fixed order, so visibility and G-buffer are bit-reproducible
 // (the parity tests require bit equality with the CPU oracle).  fmaf() only where written.
 #include "common.h"
+#include "edges.h"
 
 namespace arctic {
 
@@ -133,27 +134,6 @@ __device__ __forceinline__ uint32_t tiles_of(const SetupRec &t) {
     return (uint32_t)((t.px1 >> 4) - (t.px0 >> 4) + 1) * (uint32_t)((t.py1 >> 4) - (t.py0 >> 4) + 1);
 }
 
-// edge i: vertex i -> vertex (i+1)%3, inside-positive; bias implements the top-left rule
-struct Edges {
-    int64_t dx[3], dy[3];
-    int32_t x0[3], y0[3];
-    int64_t bias[3];
-};
-__device__ __forceinline__ void make_edges(const SetupRec &t, Edges &e) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        int j = (i + 1) % 3;
-        e.dx[i] = (int64_t)t.X[j] - t.X[i];
-        e.dy[i] = (int64_t)t.Y[j] - t.Y[i];
-        e.x0[i] = t.X[i]; e.y0[i] = t.Y[i];
-        bool top_left = (e.dy[i] == 0 && e.dx[i] > 0) || (e.dy[i] < 0);
-        e.bias[i] = top_left ? 0 : -1;
-    }
-}
-__device__ __forceinline__ int64_t edge_eval(const Edges &e, int i, int32_t px, int32_t py) {
-    int64_t Px = (int64_t)px * 256 + 128, Py = (int64_t)py * 256 + 128;
-    return e.dx[i] * (Py - e.y0[i]) - e.dy[i] * (Px - e.x0[i]);
-}
 // coverage + barycentrics (l1, l2) + clamped depth
 __device__ __forceinline__ bool fragment(const SetupRec &t, const Edges &e, float inv_area, int32_t px, int32_t py,
                                          float &l1, float &l2, float &z) {
@@ -419,25 +399,15 @@ __global__ __launch_bounds__(256) void k_resolve(const unsigned long long *__res
         int32_t tx = (int32_t)(tile % (uint32_t)gpp->tiles_x);
         int32_t ty = row_global((int)(tile / (uint32_t)gpp->tiles_x), gpp->band_tiles, gpp->shard_count, gpp->shard_index) + gpp->tile_y0;
         int32_t px = tx * 8 + (int32_t)(lane & 7), py = ty * 8 + (int32_t)(lane >> 3);
-        Edges e;
-        make_edges(t, e);
-        float inv_area = 1.0f / (float)t.area2;
-        float l1 = (float)edge_eval(e, 2, px, py) * inv_area;
-        float l2 = (float)edge_eval(e, 0, px, py) * inv_area;
-        float l0 = (1.0f - l1) - l2;
-        float pw0 = l0 * t.iw[0], pw1 = l1 * t.iw[1], pw2 = l2 * t.iw[2];
-        float rr = 1.0f / ((pw0 + pw1) + pw2);
-        float b0 = pw0 * rr, b1 = pw1 * rr, b2 = pw2 * rr;
         float B[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) B[k] = (b0 * t.bary[0][k] + b1 * t.bary[1][k]) + b2 * t.bary[2][k];
+        source_barycentrics(t, px, py, B);
         const ObjectRec &ob = objs[t.object];
         uint32_t lt = t.src_tri - ob.first_triangle;
         const float *A0 = xv[ob.first_xvert + ob.indices[3 * lt]].attr;
         const float *A1 = xv[ob.first_xvert + ob.indices[3 * lt + 1]].attr;
         const float *A2 = xv[ob.first_xvert + ob.indices[3 * lt + 2]].attr;
 #pragma unroll
-        for (int k = 0; k < 18; ++k) a[k] = (B[0] * A0[k] + B[1] * A1[k]) + B[2] * A2[k];
+        for (int k = 0; k < 18; ++k) a[k] = interpolate_attr(B, A0, A1, A2, k);
         mat = ob.material;
     }
     {

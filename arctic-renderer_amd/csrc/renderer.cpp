@@ -77,6 +77,8 @@ struct ArcticRenderer {
     DevBuf d_vis, d_p0, d_p1, d_p2, d_p3, d_p4, d_rgba8, d_ldr, d_hdr, d_counter;
     DevBuf d_lit0, d_lit1, d_lit2, d_litpx, d_litcount;   // lit-pixel stream between k_material and k_light
     bool have_gbuffer = false, have_output = false, have_vis = false;   // have_vis: d_vis holds the visibility of the current G-buffer
+    int geo_owner = 0;              // whose records d_recs / d_rec_of / d_xverts hold: 1 forward pass, 2 shadow pass
+    bool visbuffer = true;          // arctic_render_frame shades straight from the visibility plane (no G-buffer)
     // per-frame geometry scratch
     PassTables tables[2];   // [0] forward pass, [1] shadow pass
     DevBuf d_xverts, d_recs, d_rec_of, d_items, d_geo_counters, d_stage;
@@ -253,6 +255,7 @@ int run_geometry(ArcticRenderer *r, const ArcticScene *sc, bool shadow_pass) {
         gp.band_tiles = (int32_t)(r->band_rows / TILE); gp.shard_index = (int32_t)r->shard_index; gp.shard_count = (int32_t)r->shard_count;
     }
     PassTables &T = r->tables[shadow_pass ? 1 : 0];
+    r->geo_owner = shadow_pass ? 2 : 1;
     uint32_t n_objs, n_xverts, n_src, n_vblocks, n_tblocks;
     int rc = upload_pass_tables(r, T, gp, sc, n_objs, n_xverts, n_src, n_vblocks, n_tblocks);
     if (rc != ARCTIC_OK) return rc;
@@ -300,21 +303,41 @@ int pass_shadow_map(ArcticRenderer *r, const ArcticScene *sc) {
     return run_geometry(r, sc, true);
 }
 
-int pass_gbuffer(ArcticRenderer *r, const ArcticScene *sc) {
+// visibility only: vertex -> setup -> raster of the camera view
+int pass_visibility(ArcticRenderer *r, const ArcticScene *sc) {
     HIPCHECK(r, launch_fill_u64(r->d_vis.as<unsigned long long>(), ~0ull, r->n_tiles() * TILE_PIXELS, r->stream));
+    r->have_gbuffer = false;
     int rc = run_geometry(r, sc, false);
     if (rc != ARCTIC_OK) return rc;
-    HIPCHECK(r, launch_resolve(r->d_vis.as<unsigned long long>(), r->d_recs.as<SetupRec>(), r->d_rec_of.as<uint32_t>(), r->tables[0].objs,
-                               r->d_xverts.as<XVert>(), r->tables[0].gp, (uint32_t)r->n_tiles(), r->gbuffer(),
-                               r->stream));
-    r->have_gbuffer = r->have_vis = true;
+    r->have_vis = true;
     return ARCTIC_OK;
 }
 
-int fill_shade_params(ArcticRenderer *r, const ArcticScene *sc, const ArcticSettings *st, void *d_out, ShadeParams &sp) {
-    if (!r->have_gbuffer) return r->fail(ARCTIC_E_STATE, "shade: no G-buffer (run arctic_pass_gbuffer or arctic_write_gbuffer first)");
+// visibility -> the 76 B/pixel G-buffer.  Valid while the records of the forward pass are still in place.
+int resolve_gbuffer(ArcticRenderer *r) {
+    if (!r->have_vis || r->geo_owner != 1)
+        return r->fail(ARCTIC_E_STATE, "no G-buffer: the frame was shaded from the visibility plane and a later pass has replaced its records (run arctic_pass_gbuffer)");
+    HIPCHECK(r, launch_resolve(r->d_vis.as<unsigned long long>(), r->d_recs.as<SetupRec>(), r->d_rec_of.as<uint32_t>(), r->tables[0].objs,
+                               r->d_xverts.as<XVert>(), r->tables[0].gp, (uint32_t)r->n_tiles(), r->gbuffer(),
+                               r->stream));
+    r->have_gbuffer = true;
+    return ARCTIC_OK;
+}
+
+int pass_gbuffer(ArcticRenderer *r, const ArcticScene *sc) {
+    int rc = pass_visibility(r, sc);
+    return rc != ARCTIC_OK ? rc : resolve_gbuffer(r);
+}
+
+int fill_shade_params(ArcticRenderer *r, const ArcticScene *sc, const ArcticSettings *st, void *d_out, ShadeParams &sp, bool from_vis = false) {
+    if (!from_vis && !r->have_gbuffer) {
+        if (r->have_vis && r->geo_owner == 1) { int rc = resolve_gbuffer(r); if (rc != ARCTIC_OK) return rc; }   // frame came from arctic_render_frame
+        else return r->fail(ARCTIC_E_STATE, "shade: no G-buffer (run arctic_pass_gbuffer or arctic_write_gbuffer first)");
+    }
     std::memset(&sp, 0, sizeof sp);
     sp.g = r->gbuffer();
+    sp.vis = r->d_vis.as<unsigned long long>(); sp.recs = r->d_recs.as<SetupRec>(); sp.rec_of = r->d_rec_of.as<uint32_t>();
+    sp.objs = r->tables[0].objs; sp.xv = r->d_xverts.as<XVert>();
     sp.tex = r->d_tex.as<TexDesc>();
     sp.n_materials = (uint32_t)(r->tex.size() / 3);
     sp.srgb_lut = r->d_lut.as<float>();
@@ -376,14 +399,16 @@ hipError_t shade_once(ArcticRenderer *r, ShadeParams &sp, const ShadeLaunch &L) 
     return launch_shade(sp, L);
 }
 
-int pass_shade(ArcticRenderer *r, const ArcticScene *sc, const ArcticSettings *st, void *d_out) {
+int pass_shade(ArcticRenderer *r, const ArcticScene *sc, const ArcticSettings *st, void *d_out, bool from_vis = false) {
     ShadeParams sp;
-    int rc = fill_shade_params(r, sc, st, d_out, sp);
+    int rc = fill_shade_params(r, sc, st, d_out, sp, from_vis);
     if (rc != ARCTIC_OK) return rc;
     const bool fused_count = r->launch.fused && r->count_evals;   // the fused kernel has no stream counters: it counts lit pixels itself
     if (fused_count) sp.light_evals = r->d_counter.as<unsigned long long>();
     if (sp.light_evals) HIPCHECK(r, hipMemsetAsync(r->d_counter.p, 0, 16, r->stream));
-    HIPCHECK(r, shade_once(r, sp, r->launch));
+    ShadeLaunch L = r->launch;
+    L.from_vis = from_vis ? 1u : 0u;
+    HIPCHECK(r, shade_once(r, sp, L));
     if (r->count_evals) {
         unsigned long long n[2] = {0, 0};
         std::vector<uint32_t> counts((size_t)r->launch.n_bands * LIT_SHARDS * LIT_COUNTER_STRIDE);
@@ -681,8 +706,11 @@ int arctic_render_frame_device(ArcticRenderer *r, const ArcticScene *scene, cons
         if ((rc = pass_shadow_map(r, scene)) != ARCTIC_OK) return rc;
         r->shadow_key.swap(key);
     }
-    if ((rc = pass_gbuffer(r, scene)) != ARCTIC_OK) return rc;
-    return pass_shade(r, scene, settings, d_out);
+    // whole frames skip the G-buffer: the shading pass interpolates from the visibility plane (k_material_vis), bit-identical
+    // to visibility -> G-buffer -> shading; arctic_read_gbuffer / arctic_pass_shade materialise the G-buffer afterwards if asked
+    const bool vis_path = r->visbuffer && r->launch.n_bands == 1;
+    if ((rc = vis_path ? pass_visibility(r, scene) : pass_gbuffer(r, scene)) != ARCTIC_OK) return rc;
+    return pass_shade(r, scene, settings, d_out, vis_path);
 }
 
 int arctic_render_frame(ArcticRenderer *r, const ArcticScene *scene, const ArcticSettings *settings, uint8_t *out_rgba8) {
@@ -753,7 +781,12 @@ int arctic_time_shade_split(ArcticRenderer *r, const ArcticScene *scene, const A
 
 int arctic_read_gbuffer(ArcticRenderer *r, float *attrs, uint32_t *material, float *depth, uint32_t *tri) {
     if (!r) return ARCTIC_E_INVALID;
-    if (!r->have_gbuffer) return r->fail(ARCTIC_E_STATE, "read_gbuffer: no G-buffer");
+    if (!r->have_gbuffer) {
+        if (!r->have_vis) return r->fail(ARCTIC_E_STATE, "read_gbuffer: no G-buffer");
+        int rs = select_device(r);
+        if (rs) return rs;
+        if ((rs = resolve_gbuffer(r)) != ARCTIC_OK) return rs;   // the frame was shaded from the visibility plane
+    }
     int rc = select_device(r);
     if (rc) return rc;
     HIPCHECK(r, hipStreamSynchronize(r->stream));
@@ -876,6 +909,7 @@ int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value) {
         if (value >> 4) r->launch.light_blocks = r->cu_count * (uint32_t)(value >> 4);
         break;
     case ARCTIC_OPT_HDR16: r->hdr16 = value != 0; break;
+    case ARCTIC_OPT_VISBUFFER: r->visbuffer = value != 0; break;
     case ARCTIC_OPT_SHADOW_CACHE: r->shadow_cache = value != 0; r->shadow_key.clear(); break;
     case ARCTIC_OPT_BANDS:
         if (value < 1 || value > (int64_t)MAX_BANDS) return r->fail(ARCTIC_E_INVALID, "set_option: bands must be 1..%u", MAX_BANDS);

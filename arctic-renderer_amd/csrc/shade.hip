@@ -24,6 +24,7 @@
 // BRDF and tonemap use v_rcp/v_rsq/v_exp/v_log (~1 ulp) and free contraction, inside the 1e-4
 // per-channel budget of the output.
 #include "common.h"
+#include "edges.h"
 
 namespace arctic {
 
@@ -429,9 +430,11 @@ __device__ __noinline__ f3 sample_environment(const float4 *__restrict__ env, ui
 // gets the record the light loop needs.  Returns the ballot of live lanes.  Shared by k_material (two-kernel pass) and
 // k_shade_fused.
 struct LitRec { float4 r0, r1, r2; uint32_t px; };   // world.xyz, 1 - shadow | n.xyz, roughness | base.rgb, metalness | output index
+// `second(gc, gd, ge)` delivers the lit pixels' remaining attributes (world position + tangent frame, packed like the
+// G-buffer planes c, d, e): loaded from the G-buffer, or interpolated on the spot by the visibility-buffer kernel.
+template <class Second>
 __device__ __forceinline__ unsigned long long material_tile(const ShadeParams &sp, const float *lut, const uint4 *ldesc, uint32_t ty, uint32_t tx,
-                                                            uint32_t lane, const TileHead &cur, bool &live, LitRec &rec) {
-    const size_t gi = ((size_t)ty * sp.tiles_x + tx) * 64 + lane;
+                                                            uint32_t lane, const TileHead &cur, bool &live, LitRec &rec, Second second) {
     const uint32_t x = tx * 8 + (lane & 7);
     const int32_t y = (int32_t)(ty * 8 + (lane >> 3)) - (int32_t)sp.row0_in_tile;
     const bool in_frame = x < sp.width && y >= 0 && y < (int32_t)sp.rows;
@@ -455,7 +458,7 @@ __device__ __forceinline__ unsigned long long material_tile(const ShadeParams &s
     live = covered && (sp.culling ? lit != 0.0f : true);
     const unsigned long long m = __ballot(live);
     float4 gc, gd, ge;
-    if (live) { gc = sp.g.c[gi]; gd = sp.g.d[gi]; ge = sp.g.e[gi]; }   // second wave of loads: lit pixels only (48 B / pixel, whole 128-byte tile rows)
+    if (live) second(gc, gd, ge);   // second wave: lit pixels only (48 B / pixel from the G-buffer, whole 128-byte tile rows)
     f3 base = mk(0.0f, 0.0f, 0.0f);
     if (covered) base = mk(filt_srgb(t0, 0, lut), filt_srgb(t0, 1, lut), filt_srgb(t0, 2, lut));
     if (in_frame && !live) {
@@ -514,11 +517,77 @@ __global__ __launch_bounds__(256) void k_material(const ShadeParams sp) {
     if (!tile_ok) return;
     bool live;
     LitRec rec;
-    const unsigned long long m = material_tile(sp, lut, ldesc, ty, tx, lane, cur, live, rec);
+    const size_t gi = ((size_t)ty * sp.tiles_x + tx) * 64 + lane;
+    const unsigned long long m = material_tile(sp, lut, ldesc, ty, tx, lane, cur, live, rec,
+                                               [&](float4 &gc, float4 &gd, float4 &ge) { gc = sp.g.c[gi]; gd = sp.g.d[gi]; ge = sp.g.e[gi]; });
     // wave-wide compaction of the live pixels into this workgroup's SHARD of the stream (one atomicAdd per wave, on one
     // of LIT_SHARDS counters each on its own 128-byte line: a single counter would serialise at ~88 atomics/us)
     if (m != 0ull) {
         const uint32_t shard = (ty * bpr + (tx >> 2)) % LIT_SHARDS;   // by screen position: lit regions spread over all shards
+        uint32_t first = (uint32_t)__ffsll((long long)m) - 1, slot0 = 0;
+        if (lane == first) slot0 = atomicAdd(sp.lit_count + (sp.band * LIT_SHARDS + shard) * LIT_COUNTER_STRIDE, (uint32_t)__popcll(m));
+        slot0 = __shfl(slot0, (int)first);
+        if (live) {
+            const size_t slot = (size_t)(sp.band * LIT_SHARDS + shard) * sp.lit_shard_cap + slot0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            sp.lit_r0[slot] = rec.r0;
+            sp.lit_r1[slot] = rec.r1;
+            sp.lit_r2[slot] = rec.r2;
+            sp.lit_px[slot] = rec.px;
+        }
+    }
+}
+
+// ---- kernel 1 without a G-buffer (whole frames): the same tile walk straight from the visibility plane ----------------
+// arctic_render_frame has no use for the 76 B/pixel G-buffer between its own two kernels: writing it (k_resolve, 630 MB at
+// 4K) and reading it back costs more than interpolating again.  This variant reads the 8-byte visibility key, finds the
+// triangle, and interpolates uv + light-space position for every covered pixel and world position + tangent frame only
+// for the lit ones -- with the very operations of k_resolve (edges.h, fp contraction off), so the pixels are bit-identical
+// to the G-buffer path.  Everything after the attributes is material_tile, shared.
+__global__ __launch_bounds__(256) void k_material_vis(const ShadeParams sp) {
+    extern __shared__ __align__(16) float smem[];
+    float *lut = smem;
+    uint4 *ldesc = reinterpret_cast<uint4 *>(smem + 256);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t bpr = (sp.tiles_x + 3) >> 2;
+    const uint32_t xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;   // XCD-aware order: see k_material
+    const uint32_t ty = ((idx / bpr) * sp.n_bands + sp.band) * 8 + xcd, tx = (idx % bpr) * 4 + wave;
+    const bool tile_ok = ty < sp.tiles_y && tx < sp.tiles_x;
+    const size_t gi = ((size_t)ty * sp.tiles_x + tx) * 64 + lane;
+    unsigned long long key = ~0ull;
+    if (tile_ok) key = sp.vis[gi];
+    stage_material_lds(sp, lut, ldesc);
+    __syncthreads();
+    if (!tile_ok) return;
+    const int32_t px = (int32_t)(tx * 8 + (lane & 7));
+    const int32_t py = (row_global((int)ty, sp.band_tiles, sp.shard_count, sp.shard_index) + sp.tile_y0) * 8 + (int32_t)(lane >> 3);
+    TileHead cur;
+    cur.a = make_float4(0.0f, 0.0f, 0.0f, 0.0f); cur.b0 = 0.0f; cur.b1 = 0.0f; cur.b2 = __uint_as_float(NO_MATERIAL);
+    float B[3] = {0.0f, 0.0f, 0.0f};
+    const float *A0 = nullptr, *A1 = nullptr, *A2 = nullptr;
+    if (key != ~0ull) {
+        const SetupRec &t = sp.recs[sp.rec_of[(uint32_t)key]];   // low word of the key = order id (k_setup)
+        source_barycentrics(t, px, py, B);
+        const ObjectRec &ob = sp.objs[t.object];
+        const uint32_t lt = t.src_tri - ob.first_triangle;
+        A0 = sp.xv[ob.first_xvert + ob.indices[3 * lt]].attr;
+        A1 = sp.xv[ob.first_xvert + ob.indices[3 * lt + 1]].attr;
+        A2 = sp.xv[ob.first_xvert + ob.indices[3 * lt + 2]].attr;
+        cur.a = make_float4(interpolate_attr(B, A0, A1, A2, 0), interpolate_attr(B, A0, A1, A2, 1),
+                            interpolate_attr(B, A0, A1, A2, 14), interpolate_attr(B, A0, A1, A2, 15));
+        cur.b0 = interpolate_attr(B, A0, A1, A2, 16); cur.b1 = interpolate_attr(B, A0, A1, A2, 17);
+        cur.b2 = __uint_as_float(ob.material);
+    }
+    bool live;
+    LitRec rec;
+    const unsigned long long m = material_tile(sp, lut, ldesc, ty, tx, lane, cur, live, rec, [&](float4 &gc, float4 &gd, float4 &ge) {
+        // attribute order (XVert::attr): uv 0-1, t 2-4, b 5-7, n 8-10, world 11-13, light space 14-17; planes as gbuffer_pack
+        gc = make_float4(interpolate_attr(B, A0, A1, A2, 11), interpolate_attr(B, A0, A1, A2, 12), interpolate_attr(B, A0, A1, A2, 13), interpolate_attr(B, A0, A1, A2, 2));
+        gd = make_float4(interpolate_attr(B, A0, A1, A2, 3), interpolate_attr(B, A0, A1, A2, 4), interpolate_attr(B, A0, A1, A2, 5), interpolate_attr(B, A0, A1, A2, 6));
+        ge = make_float4(interpolate_attr(B, A0, A1, A2, 7), interpolate_attr(B, A0, A1, A2, 8), interpolate_attr(B, A0, A1, A2, 9), interpolate_attr(B, A0, A1, A2, 10));
+    });
+    if (m != 0ull) {   // lit-pixel stream, as k_material
+        const uint32_t shard = (ty * bpr + (tx >> 2)) % LIT_SHARDS;
         uint32_t first = (uint32_t)__ffsll((long long)m) - 1, slot0 = 0;
         if (lane == first) slot0 = atomicAdd(sp.lit_count + (sp.band * LIT_SHARDS + shard) * LIT_COUNTER_STRIDE, (uint32_t)__popcll(m));
         slot0 = __shfl(slot0, (int)first);
@@ -669,7 +738,9 @@ __global__ __launch_bounds__(256) void k_shade_fused(const ShadeParams sp) {
                 const TileHead cur = load_head(sp.g, ((size_t)ty * sp.tiles_x + tx) * 64 + lane);
                 bool live;
                 LitRec rec;
-                const unsigned long long m = material_tile(sp, lut, ldesc, ty, tx, lane, cur, live, rec);
+                const size_t gi = ((size_t)ty * sp.tiles_x + tx) * 64 + lane;
+                const unsigned long long m = material_tile(sp, lut, ldesc, ty, tx, lane, cur, live, rec,
+                                                           [&](float4 &gc, float4 &gd, float4 &ge) { gc = sp.g.c[gi]; gd = sp.g.d[gi]; ge = sp.g.e[gi]; });
                 if (m == 0ull) continue;
                 if (live) {
                     const uint32_t slot = qn + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
@@ -723,7 +794,7 @@ hipError_t launch_shade(const ShadeParams &sp0, const ShadeLaunch &L) {
     hipError_t e = hipSuccess;
     const size_t lds_a = (256 + (size_t)sp.n_materials * 12) * sizeof(float);
     const size_t lds_b = std::max<size_t>(96, (size_t)((sp.n_lights + 3) / 4) * 96);
-    if (L.fused) {
+    if (L.fused && !L.from_vis) {
         sp.n_bands = 1; sp.band = 0;
         const size_t lds = fused_lds_bytes(sp.n_materials, sp.n_lights);
         if (L.mid && (e = hipEventRecord(L.mid, L.main)) != hipSuccess) return e;   // per-kernel timing: "k_material" part is empty
@@ -734,7 +805,8 @@ hipError_t launch_shade(const ShadeParams &sp0, const ShadeLaunch &L) {
     for (uint32_t k = 0; k < n_bands; ++k) {
         sp.band = k;
         const uint32_t groups = (row_groups - k + n_bands - 1) / n_bands;
-        k_material<<<groups * 8 * bpr, 256, lds_a, L.main>>>(sp);
+        if (L.from_vis) k_material_vis<<<groups * 8 * bpr, 256, lds_a, L.main>>>(sp);
+        else k_material<<<groups * 8 * bpr, 256, lds_a, L.main>>>(sp);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         hipStream_t ls = L.main;
         if (L.mid && n_bands == 1 && (e = hipEventRecord(L.mid, L.main)) != hipSuccess) return e;

@@ -268,6 +268,8 @@ int arctic_stats(ArcticRenderer *r, uint64_t *out, uint32_t n);
 #define ARCTIC_OPT_FUSED             8 /* 1 = the shading pass as ONE persistent kernel (material and light halves decoupled through LDS queues); 0 = k_material + k_light */
 #define ARCTIC_OPT_SHADOW_CACHE      9 /* 1 (default) = arctic_render_frame redraws the shadow map only when the sun, the objects or the mesh list changed
                                           (byte-compared); 0 = every frame like the reference (renderer.cpp:300-337).  Same image either way. */
+#define ARCTIC_OPT_VISBUFFER        10 /* 1 (default) = arctic_render_frame shades straight from the visibility plane, no 76 B/px G-buffer round trip
+                                          (bit-identical image; the G-buffer is materialised later if arctic_read_gbuffer / arctic_pass_shade ask); 0 = via the G-buffer */
 #define ARCTIC_OPT_BANDS             5 /* 1..16 interleaved screen bands the two shading kernels are pipelined over (default 1: no gain measured) */
 int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value);
 

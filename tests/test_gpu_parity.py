@@ -101,6 +101,28 @@ def test_culling_is_exact(pair):
     assert np.abs(a - b).max() <= 2e-6
 
 
+def test_frame_from_visibility_plane_equals_frame_through_gbuffer(pair):
+    """ARCTIC_OPT_VISBUFFER (default): arctic_render_frame interpolates the attributes inside the shading kernel instead of
+    writing and re-reading the G-buffer.  Same operations in the same order: the float image is bit-identical, and the
+    G-buffer materialised afterwards on request is the prepass's G-buffer."""
+    sc, o, r = pair
+    r.set_option("visbuffer", 0)
+    a = r.render_frame(sc.desc, sc.settings)
+    a_ldr, a_hdr, _ = (x.copy() for x in r.read_output())
+    ga = r.read_gbuffer()
+    r.set_option("visbuffer", 1)
+    b = r.render_frame(sc.desc, sc.settings)
+    b_ldr, b_hdr, _ = r.read_output()
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(a_ldr.view(np.uint32), b_ldr.view(np.uint32))
+    np.testing.assert_array_equal(a_hdr.view(np.uint32), b_hdr.view(np.uint32))
+    gb = r.read_gbuffer()                       # resolved now, from the visibility plane of that frame
+    for x, y in zip(ga, gb):
+        np.testing.assert_array_equal(x.view(np.uint32), y.view(np.uint32))
+    r.pass_shade(sc.desc, sc.settings)          # and the G-buffer API keeps working after such a frame
+    np.testing.assert_array_equal(r.read_output()[0].view(np.uint32), a_ldr.view(np.uint32))
+
+
 def test_fused_kernel_equals_two_kernel_pass(pair):
     """ARCTIC_OPT_FUSED: the single persistent kernel (LDS queues between the material and light halves) runs the same
     per-pixel arithmetic as k_material + k_light; only the grouping of pixels into waves differs."""

@@ -20,7 +20,7 @@ for cfg in [int(a) for a in sys.argv[1:]] or (3, 2, 1):
             for i in range(N): r.render_frame_device(sc.desc, sc.settings, out.data_ptr())
             r.flush(); dt = (time.perf_counter() - t) / N
             print(f"config {cfg}{' + environment map' if env is not None else ''}: {sc.width}x{sc.height} {sc.n_triangles} tris, {len(sc.lights)} lights, "
-                  f"whole frame ({'static sun: G-buffer prepass + shading' if cache else 'shadow raster + G-buffer prepass + shading'}) "
+                  f"whole frame ({'static sun: visibility prepass + shading' if cache else 'shadow raster + visibility prepass + shading'}) "
                   f"{dt*1e3:.3f} ms = {1/dt:.0f} fps, {sc.width*sc.height/dt/1e6:.0f} Mpx/s", flush=True)
         ms, ms_mat, ms_light = r.time_shade_split(sc.desc, sc.settings, warmup=3, iters=N)
         r.set_option("count_light_evals", 1); r.pass_shade(sc.desc, sc.settings); r.flush(); st = r.stats(); r.set_option("count_light_evals", 0)
