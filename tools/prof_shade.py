@@ -11,7 +11,8 @@ if mode=="nolights": r.update_lights(sc.lights[:0])
 if mode=="nocull": r.set_option("culling",0)
 if mode.startswith("dbg"): r.set_option("debug", int(mode[3:])); r.update_lights(sc.lights[:0])
 for i in range(5):
-    if mode == "frame": r.render_frame(sc.desc, sc.settings, out=None) if False else (r.pass_shadow_map(sc.desc), r.pass_gbuffer(sc.desc), r.pass_shade(sc.desc, sc.settings))
+    if mode == "frame": (r.pass_shadow_map(sc.desc), r.pass_gbuffer(sc.desc), r.pass_shade(sc.desc, sc.settings))   # every pass, through the G-buffer
+    elif mode == "render_frame": r.render_frame_device(sc.desc, sc.settings, None)                                   # what the application calls
     else: r.pass_shade(sc.desc, sc.settings)
 r.flush()
 r.close()
