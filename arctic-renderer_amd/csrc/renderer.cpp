@@ -83,6 +83,7 @@ struct ArcticRenderer {
     PassTables tables[2];   // [0] forward pass, [1] shadow pass
     DevBuf d_xverts, d_recs, d_rec_of, d_items, d_geo_counters, d_stage;
     uint32_t item_cap = 0;          // entries of d_items (work-item table of the rasteriser)
+    uint32_t item_cap_floor = 1u << 22;   // its smallest size (ARCTIC_OPT_ITEM_TABLE_FLOOR; tests shrink it to reach the overflow path)
     uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int keep_float = 0, count_evals = 0, culling = 1, debug = 0, hdr16 = 0;
     ShadeLaunch launch{};           // streams, events, band count and k_light's persistent grid
@@ -273,7 +274,7 @@ int run_geometry(ArcticRenderer *r, const ArcticScene *sc, bool shadow_pass) {
     // h_counts, refreshed asynchronously each pass) with 4x headroom; an overflow drops work, is flagged by the kernel and
     // reported by the next call that synchronises (arctic_flush / read-backs) -- and the table has grown by then.
     uint32_t *h = r->h_counts + (shadow_pass ? 2 : 0);
-    const uint64_t want = std::max<uint64_t>(1u << 22, 4ull * std::max(r->h_counts[1], r->h_counts[3]));
+    const uint64_t want = std::max<uint64_t>(r->item_cap_floor, 4ull * std::max(r->h_counts[1], r->h_counts[3]));
     if (want > r->item_cap) {
         HIPCHECK(r, r->d_items.ensure((size_t)want * 8));
         r->item_cap = (uint32_t)std::min<uint64_t>(want, 0x7FFFFFF0ull);
@@ -910,6 +911,10 @@ int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value) {
         break;
     case ARCTIC_OPT_HDR16: r->hdr16 = value != 0; break;
     case ARCTIC_OPT_VISBUFFER: r->visbuffer = value != 0; break;
+    case ARCTIC_OPT_ITEM_TABLE_FLOOR:
+        if (value < 64 || value > 0x7FFFFFF0ll) return r->fail(ARCTIC_E_INVALID, "set_option: item table floor out of range");
+        r->item_cap_floor = (uint32_t)value; r->item_cap = 0;
+        break;
     case ARCTIC_OPT_SHADOW_CACHE: r->shadow_cache = value != 0; r->shadow_key.clear(); break;
     case ARCTIC_OPT_BANDS:
         if (value < 1 || value > (int64_t)MAX_BANDS) return r->fail(ARCTIC_E_INVALID, "set_option: bands must be 1..%u", MAX_BANDS);

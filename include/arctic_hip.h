@@ -270,6 +270,8 @@ int arctic_stats(ArcticRenderer *r, uint64_t *out, uint32_t n);
                                           (byte-compared); 0 = every frame like the reference (renderer.cpp:300-337).  Same image either way. */
 #define ARCTIC_OPT_VISBUFFER        10 /* 1 (default) = arctic_render_frame shades straight from the visibility plane, no 76 B/px G-buffer round trip
                                           (bit-identical image; the G-buffer is materialised later if arctic_read_gbuffer / arctic_pass_shade ask); 0 = via the G-buffer */
+#define ARCTIC_OPT_ITEM_TABLE_FLOOR 11 /* smallest size (entries) of the rasteriser's work-item table, default 4 Mi; the table grows to 4x the largest
+                                          count seen.  A frame that overflows it returns ARCTIC_E_CAPACITY from the next synchronising call. */
 #define ARCTIC_OPT_BANDS             5 /* 1..16 interleaved screen bands the two shading kernels are pipelined over (default 1: no gain measured) */
 int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value);
 

@@ -111,3 +111,23 @@ def test_object_transforms_and_shared_meshes(pkg, oracle, hip):
             (S.translation(0, -0.8, 0.5) @ S.rotation_y(-50), 1), (np.eye(4), 7)]
     lights = pkg.scenes.random_lights(rng, 5, (-3, -2, 0.5), (3, 2, 3))
     check(both(pkg, oracle, hip, 128, 96, 256, mats, [sphere + (0,), box + (1,)], objs, lights, settings=(2, 2.2, 1.0)))
+
+
+def test_work_item_table_overflow_is_reported_and_recovers(pkg, hip):
+    """the rasteriser's work-item table is sized from earlier frames; a frame that needs more is dropped LOUDLY
+    (ARCTIC_E_CAPACITY at the next synchronising call) and the next one succeeds with the grown table."""
+    sc = pkg.scenes.config3(scale=0.1)
+    ref_r = sc.upload(hip.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights))
+    ref = ref_r.render_frame(sc.desc, sc.settings)
+    items = max(int(ref_r.stats()[1]), int(ref_r.stats()[3]))
+    ref_r.close()
+    assert items > 256
+    r = sc.upload(hip.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights))
+    r.set_option("item_table_floor", 64)
+    with pytest.raises(hip.ArcticError) as e:
+        r.render_frame(sc.desc, sc.settings)
+    assert e.value.code == -5 and "overflow" in str(e.value)
+    img = r.render_frame(sc.desc, sc.settings)     # the table has grown to 4x what that frame asked for
+    np.testing.assert_array_equal(img, ref)
+    np.testing.assert_array_equal(r.render_frame(sc.desc, sc.settings), ref)
+    r.close()
