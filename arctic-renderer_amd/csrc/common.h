@@ -15,6 +15,7 @@ namespace arctic {
 constexpr int TILE = 8;
 constexpr int TILE_PIXELS = 64;
 constexpr uint32_t NO_MATERIAL = 0xFFFFFFFFu;
+constexpr uint32_t MAX_TARGET = 16384;   // largest render target / shadow map side: keeps the 24.8 edge arithmetic of edges.h in 32-bit factors
 
 // G-buffer = the interpolated VSOut (forward.hlsl:41-48) minus SV_POSITION, 76 B / pixel, split by WHEN it is needed:
 //   first wave of loads, every pixel (28 B): texture coordinates, shadow lookup, material

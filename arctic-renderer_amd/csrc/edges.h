@@ -22,9 +22,12 @@ __device__ __forceinline__ void make_edges(const SetupRec &t, Edges &e) {
         e.bias[i] = top_left ? 0 : -1;
     }
 }
+// All four factors fit 32 bits: the coordinates are 24.8 fixed point inside the +-64 w guard band of a target of at most
+// 16 k pixels (|X| < 2^29), pixel centres are below 2^23 -- so the exact 64-bit value costs two 32x32->64 multiply-adds
+// (v_mad_i64_i32) instead of two full 64-bit multiplications.
 __device__ __forceinline__ int64_t edge_eval(const Edges &e, int i, int32_t px, int32_t py) {
-    int64_t Px = (int64_t)px * 256 + 128, Py = (int64_t)py * 256 + 128;
-    return e.dx[i] * (Py - e.y0[i]) - e.dy[i] * (Px - e.x0[i]);
+    const int32_t Px = px * 256 + 128, Py = py * 256 + 128;
+    return (int64_t)(int32_t)e.dx[i] * (int64_t)(Py - e.y0[i]) - (int64_t)(int32_t)e.dy[i] * (int64_t)(Px - e.x0[i]);
 }
 
 // perspective-correct barycentrics of pixel (px, py) with respect to the SOURCE triangle of record t (the weights the 18

@@ -460,6 +460,7 @@ int arctic_version(void) { return 100; }
 ArcticRenderer *arctic_create(const ArcticCreateInfo *info, char *err, uint64_t err_len) {
     auto say = [&](const char *m) { if (err && err_len) { std::snprintf(err, (size_t)err_len, "%s", m); } };
     if (!info || info->width == 0 || info->height == 0) { say("arctic_create: width/height must be > 0"); return nullptr; }
+    if (info->width > MAX_TARGET || info->height > MAX_TARGET || info->shadow_size > MAX_TARGET) { say("arctic_create: targets above 16384 pixels a side are not supported"); return nullptr; }
     uint32_t rb = info->row_begin, re = info->row_end;
     if (rb == 0 && re == 0) re = info->height;
     if (re > info->height || rb >= re) { say("arctic_create: bad row shard"); return nullptr; }
@@ -549,6 +550,7 @@ const char *arctic_last_error(const ArcticRenderer *r) { return r ? r->err.c_str
 int arctic_resize(ArcticRenderer *r, uint32_t width, uint32_t height) {
     if (!r) return ARCTIC_E_INVALID;
     if (width == 0 || height == 0) return r->fail(ARCTIC_E_INVALID, "resize: zero size");
+    if (width > MAX_TARGET || height > MAX_TARGET) return r->fail(ARCTIC_E_CAPACITY, "resize: targets above 16384 pixels a side are not supported");
     int rc = select_device(r);
     if (rc) return rc;
     HIPCHECK(r, hipStreamSynchronize(r->stream));
