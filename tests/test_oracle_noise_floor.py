@@ -33,3 +33,33 @@ def test_ggx_cancellation_is_the_cause(oracle):
         worst = max(worst, abs(got - want) / want)
     print(f"fp32 vs exact, relative: {worst:.2e}")
     assert 1e-4 < worst < 0.5
+
+
+def test_grazing_view_is_ill_conditioned_in_fp32(oracle):
+    """the second fp32 trap of the reference formula: at a grazing view n.wo -> 0+ the specular term is
+    ~ D F g(n.wi) * (n.wo / k) / (4 n.wo n.wi + 1e-4) ~ n.wo / 1e-4, and n.wo itself is a cancelling sum of three
+    products of O(1) numbers: its fp32 error (~1e-7 absolute) is several PERCENT of a value like 2e-6.  One ulp on
+    one input component moves the exact result by more than 1e-4 relative, so no fp32 implementation -- the
+    literal port, the HIP kernel, DXC's code on a D3D12 GPU -- can agree with another to 1e-4 on such a pixel.
+    (tools/fuzz_parity.py found one, 1 pixel in 1.6 M, with n.wo = 2.1e-6: HIP 8e-4, fp32 oracle 4e-4 from the
+    float64 value, on opposite sides.)"""
+    from test_oracle_kat import radiance64, unit
+    n = unit([-0.13776007, 0.98627985, -0.09096255])
+    t = unit(np.cross(n, [0.3, 0.1, -0.9]))
+    wi = unit([-0.5, 0.7, 0.2])
+    args = ((8.0, 8.0, 8.0), (0.16, 0.18, 0.12), 0.87, 0.4856)
+    rel = []
+    for tilt in (2e-6, 5e-6, 2e-5):
+        wo64 = unit(t + tilt * n)
+        wo32 = wo64.astype(np.float32)
+        exact = radiance64(n.astype(np.float32).astype(np.float64), wo32.astype(np.float64), wi.astype(np.float32).astype(np.float64), *args)
+        # sensitivity of the EXACT value to one fp32 ulp of one component of wo
+        bumped = wo32.copy()
+        bumped[1] = np.nextafter(bumped[1], np.float32(1.0))
+        moved = radiance64(n.astype(np.float32).astype(np.float64), bumped.astype(np.float64), wi.astype(np.float32).astype(np.float64), *args)
+        got = np.asarray(oracle.outgoing_radiance(n.astype(np.float32), wo32, wi.astype(np.float32), *args), np.float64)
+        rel.append((tilt, float(np.abs(moved - exact).max() / exact.max()), float(np.abs(got - exact).max() / exact.max())))
+    print("tilt, relative move of the exact value per input ulp, relative error of the fp32 evaluation:", rel)
+    assert rel[0][1] > 2e-4          # ONE ulp of ONE input component already moves the exact value by more than the 1e-4 bar at n.wo = 2e-6
+    assert rel[0][2] > 1e-4          # and the literal fp32 evaluation is off by more than that
+    assert rel[-1][1] < rel[0][1]    # and it fades as the view leaves the tangent plane
