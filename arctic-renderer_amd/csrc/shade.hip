@@ -387,7 +387,7 @@ __device__ __forceinline__ float through_half(float x) { return (float)(_Float16
 
 __device__ __forceinline__ void store_pixel(const ShadeParams &sp, size_t o, f3 color) {
     if (sp.hdr16) color = mk(through_half(color.x), through_half(color.y), through_half(color.z));
-    const f3 l = post_process(color, sp.tm_method, sp.inv_gamma, sp.exposure);
+    const f3 l = (sp.debug & 4) ? color : post_process(color, sp.tm_method, sp.inv_gamma, sp.exposure);   // bit 2: timing only
     reinterpret_cast<uint32_t *>(sp.out_rgba8)[o] = unorm8(l.x) | (unorm8(l.y) << 8) | (unorm8(l.z) << 16) | 0xFF000000u;
     if (sp.out_ldr) { sp.out_ldr[o * 3] = l.x; sp.out_ldr[o * 3 + 1] = l.y; sp.out_ldr[o * 3 + 2] = l.z; }
     if (sp.out_hdr) { sp.out_hdr[o * 3] = color.x; sp.out_hdr[o * 3 + 1] = color.y; sp.out_hdr[o * 3 + 2] = color.z; }
@@ -449,7 +449,8 @@ __device__ __forceinline__ unsigned long long material_tile(const ShadeParams &s
         const float u = cur.a.x, v = cur.a.y;
         if (!(sp.debug & 2)) lit = 1.0f - calculate_shadow(sp.shadow_map, sp.shadow_size, make_float4(cur.a.z, cur.a.w, cur.b0, cur.b1));
         const TexRef d0 = lds_desc(ldesc + mat * 3);
-        if (d0.packed) fetch_taps3(d0, u, v, t0, t1, t2);   // the usual case (equal-size images); waves mixing both kinds diverge
+        if (sp.debug & 1) { t0.t00 = t0.t10 = t0.t01 = t0.t11 = 0x808080u; t0.w00 = t0.w10 = t0.w01 = t0.w11 = 0.25f; t1 = t0; t2 = t0; }   // timing only
+        else if (d0.packed) fetch_taps3(d0, u, v, t0, t1, t2);   // the usual case (equal-size images); waves mixing both kinds diverge
         else { t0 = fetch_taps(d0, u, v); t1 = fetch_taps(lds_desc(ldesc + mat * 3 + 1), u, v); t2 = fetch_taps(lds_desc(ldesc + mat * 3 + 2), u, v); }
     }
     // exact culling 1: Lo of ps_main is a sum of terms each multiplied by (1 - shadow) (point lights too: forward.hlsl:222,

@@ -261,7 +261,7 @@ int arctic_stats(ArcticRenderer *r, uint64_t *out, uint32_t n);
 #define ARCTIC_OPT_COUNT_LIGHT_EVALS 2 /* 1 = shade counts evaluated lights (stats[5], atomics in the light loop: slower) and lit pixels (stats[6]);
                                           2 = lit pixels only (read back from the stream counters, the kernels run at full speed) */
 #define ARCTIC_OPT_CULLING           3 /* 0 = evaluate every light for every pixel; 1 = exact wave-level culling (default) */
-#define ARCTIC_OPT_DEBUG             4 /* timing experiments only (wrong images): bit 0 skip material textures, bit 1 skip shadow test */
+#define ARCTIC_OPT_DEBUG             4 /* timing experiments only (wrong images): bit 0 skip material textures, bit 1 skip shadow test, bit 2 skip tonemap */
 #define ARCTIC_OPT_HDR16             6 /* 1 = round ps_main's colour through binary16 before post_process, like the reference's
                                         R16G16B16A16_FLOAT colour target (forward_pass.cpp:149, renderer.cpp:128-144); default 0 = fp32 */
 #define ARCTIC_OPT_LIGHT_KERNEL      7 /* tuning: lights per loop trip of k_light (2 or 4) + 16 * persistent workgroups per CU */
