@@ -150,7 +150,7 @@ struct ShadeLaunch {
     hipStream_t main, aux;
     hipEvent_t band_done[MAX_BANDS], aux_done;
     uint32_t n_bands, light_blocks;
-    uint32_t lights_per_trip;   // k_light variant: 4 (two packed pairs per loop trip, 121 VGPRs) or 2 (one pair, 96 VGPRs)
+    uint32_t lights_per_trip;   // k_light variant: 4 (two packed pairs per loop trip, 112 VGPRs) or 2 (one pair, 98 VGPRs)
     hipEvent_t mid;   // optional: recorded between k_material and k_light (single band), for per-kernel timing
     uint32_t from_vis;              // 1: k_material_vis (attributes interpolated from the visibility plane) instead of k_material
     uint32_t fused, fused_blocks;   // 1: the whole pass as one persistent kernel (k_shade_fused) of fused_blocks workgroups

@@ -2,8 +2,9 @@
 //
 // Replaces ps_main of shaders/forward.hlsl:208-235 (material fetch :98-124, calculate_shadow
 // :68-96, Cook-Torrance GGX :126-193, point-light loop :224-231) and main of
-// shaders/post_process.hlsl:59-93 (Reinhard / exposure / ACES :39-57, gamma :34-37) with ONE
-// HIP kernel that reads the tile-major G-buffer written by geometry.hip and stores RGBA8.
+// shaders/post_process.hlsl:59-93 (Reinhard / exposure / ACES :39-57, gamma :34-37), plus the skybox lookup of
+// shaders/skybox.hlsl:61-90 for pixels without geometry; reads the tile-major G-buffer written by geometry.hip (or, for
+// whole frames, the visibility plane: k_material_vis) and stores RGBA8.
 //
 // Two kernels, each shaped for its own regime (MI355X has no pixel-shader scheduler to do this for us):
 //   k_material  1 wavefront = one 8x8 tile (lane l = pixel (l&7, l>>3)), 4 tiles per workgroup.  Reads the tile-major
