@@ -495,8 +495,43 @@ __device__ __forceinline__ void stage_material_lds(const ShadeParams &sp, float 
     for (uint32_t i = threadIdx.x; i < sp.n_materials * 3; i += 256) ldesc[i] = reinterpret_cast<const uint4 *>(sp.tex)[i];
 }
 
+// what happens to the live pixels of a tile.  Normally they are compacted into the lit-pixel stream for k_light (one
+// atomicAdd per wave, on one of LIT_SHARDS counters each on its own 128-byte line: a single counter would serialise at
+// ~88 atomics/us).  SUN_ONLY (no point lights: the reference's own scenes, BASELINE configs 1-2): the sun is evaluated
+// right here -- one light is not worth a 52-byte round trip through HBM and a second kernel -- with the formulas of
+// light_pixel for zero point lights (the images agree to fp32 rounding: the compiler contracts differently per kernel).
+template <bool SUN_ONLY>
+__device__ __forceinline__ void emit_live(const ShadeParams &sp, uint32_t ty, uint32_t tx, uint32_t bpr, uint32_t lane, unsigned long long m,
+                                          bool live, const LitRec &rec) {
+    if (m == 0ull) return;
+    if (SUN_ONLY) {
+        if (live) {
+            const f3 world = mk(rec.r0.x, rec.r0.y, rec.r0.z), n = mk(rec.r1.x, rec.r1.y, rec.r1.z), base = mk(rec.r2.x, rec.r2.y, rec.r2.z);
+            const f3 wo = normalize(mk(sp.eye[0], sp.eye[1], sp.eye[2]) - world);
+            const Pix px = make_pix(n, wo, world, base, rec.r2.w, rec.r1.w);
+            f3 sun = mk(0.0f, 0.0f, 0.0f);
+            const f3 d = mk(-sp.sun_dir[0], -sp.sun_dir[1], -sp.sun_dir[2]);
+            accumulate_light<false>(px, d, dot(n, d), mk(sp.sun_color[0], sp.sun_color[1], sp.sun_color[2]), sun);
+            store_pixel(sp, rec.px, sun * rec.r0.w + base * sp.ambient);   // r0.w = 1 - shadow
+        }
+        return;
+    }
+    const uint32_t shard = (ty * bpr + (tx >> 2)) % LIT_SHARDS;   // by screen position: lit regions spread over all shards
+    uint32_t first = (uint32_t)__ffsll((long long)m) - 1, slot0 = 0;
+    if (lane == first) slot0 = atomicAdd(sp.lit_count + (sp.band * LIT_SHARDS + shard) * LIT_COUNTER_STRIDE, (uint32_t)__popcll(m));
+    slot0 = __shfl(slot0, (int)first);
+    if (live) {
+        const size_t slot = (size_t)(sp.band * LIT_SHARDS + shard) * sp.lit_shard_cap + slot0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        sp.lit_r0[slot] = rec.r0;
+        sp.lit_r1[slot] = rec.r1;
+        sp.lit_r2[slot] = rec.r2;
+        sp.lit_px[slot] = rec.px;
+    }
+}
+
 // ---- kernel 1 of the two-kernel pass: material_tile over every tile, live pixels appended to the lit-pixel stream -----
 // LDS (dynamic): [0,256) sRGB LUT | texture descriptors, 4 dwords each
+template <bool SUN_ONLY>
 __global__ __launch_bounds__(256) void k_material(const ShadeParams sp) {
     extern __shared__ __align__(16) float smem[];
     float *lut = smem;
@@ -522,21 +557,7 @@ __global__ __launch_bounds__(256) void k_material(const ShadeParams sp) {
     const size_t gi = ((size_t)ty * sp.tiles_x + tx) * 64 + lane;
     const unsigned long long m = material_tile(sp, lut, ldesc, ty, tx, lane, cur, live, rec,
                                                [&](float4 &gc, float4 &gd, float4 &ge) { gc = sp.g.c[gi]; gd = sp.g.d[gi]; ge = sp.g.e[gi]; });
-    // wave-wide compaction of the live pixels into this workgroup's SHARD of the stream (one atomicAdd per wave, on one
-    // of LIT_SHARDS counters each on its own 128-byte line: a single counter would serialise at ~88 atomics/us)
-    if (m != 0ull) {
-        const uint32_t shard = (ty * bpr + (tx >> 2)) % LIT_SHARDS;   // by screen position: lit regions spread over all shards
-        uint32_t first = (uint32_t)__ffsll((long long)m) - 1, slot0 = 0;
-        if (lane == first) slot0 = atomicAdd(sp.lit_count + (sp.band * LIT_SHARDS + shard) * LIT_COUNTER_STRIDE, (uint32_t)__popcll(m));
-        slot0 = __shfl(slot0, (int)first);
-        if (live) {
-            const size_t slot = (size_t)(sp.band * LIT_SHARDS + shard) * sp.lit_shard_cap + slot0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            sp.lit_r0[slot] = rec.r0;
-            sp.lit_r1[slot] = rec.r1;
-            sp.lit_r2[slot] = rec.r2;
-            sp.lit_px[slot] = rec.px;
-        }
-    }
+    emit_live<SUN_ONLY>(sp, ty, tx, bpr, lane, m, live, rec);
 }
 
 // ---- kernel 1 without a G-buffer (whole frames): the same tile walk straight from the visibility plane ----------------
@@ -545,6 +566,7 @@ __global__ __launch_bounds__(256) void k_material(const ShadeParams sp) {
 // triangle, and interpolates uv + light-space position for every covered pixel and world position + tangent frame only
 // for the lit ones -- with the very operations of k_resolve (edges.h, fp contraction off), so the pixels are bit-identical
 // to the G-buffer path.  Everything after the attributes is material_tile, shared.
+template <bool SUN_ONLY>
 __global__ __launch_bounds__(256) void k_material_vis(const ShadeParams sp) {
     extern __shared__ __align__(16) float smem[];
     float *lut = smem;
@@ -588,19 +610,7 @@ __global__ __launch_bounds__(256) void k_material_vis(const ShadeParams sp) {
         gd = make_float4(interpolate_attr(B, A0, A1, A2, 3), interpolate_attr(B, A0, A1, A2, 4), interpolate_attr(B, A0, A1, A2, 5), interpolate_attr(B, A0, A1, A2, 6));
         ge = make_float4(interpolate_attr(B, A0, A1, A2, 7), interpolate_attr(B, A0, A1, A2, 8), interpolate_attr(B, A0, A1, A2, 9), interpolate_attr(B, A0, A1, A2, 10));
     });
-    if (m != 0ull) {   // lit-pixel stream, as k_material
-        const uint32_t shard = (ty * bpr + (tx >> 2)) % LIT_SHARDS;
-        uint32_t first = (uint32_t)__ffsll((long long)m) - 1, slot0 = 0;
-        if (lane == first) slot0 = atomicAdd(sp.lit_count + (sp.band * LIT_SHARDS + shard) * LIT_COUNTER_STRIDE, (uint32_t)__popcll(m));
-        slot0 = __shfl(slot0, (int)first);
-        if (live) {
-            const size_t slot = (size_t)(sp.band * LIT_SHARDS + shard) * sp.lit_shard_cap + slot0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            sp.lit_r0[slot] = rec.r0;
-            sp.lit_r1[slot] = rec.r1;
-            sp.lit_r2[slot] = rec.r2;
-            sp.lit_px[slot] = rec.px;
-        }
-    }
+    emit_live<SUN_ONLY>(sp, ty, tx, bpr, lane, m, live, rec);
 }
 
 // ---- the light half of ps_main for one lit pixel per lane: the sun + every point light, tonemap, store --------------
@@ -807,8 +817,15 @@ hipError_t launch_shade(const ShadeParams &sp0, const ShadeLaunch &L) {
     for (uint32_t k = 0; k < n_bands; ++k) {
         sp.band = k;
         const uint32_t groups = (row_groups - k + n_bands - 1) / n_bands;
-        if (L.from_vis) k_material_vis<<<groups * 8 * bpr, 256, lds_a, L.main>>>(sp);
-        else k_material<<<groups * 8 * bpr, 256, lds_a, L.main>>>(sp);
+        if (L.sun_only) {   // no point lights: the material kernel finishes every pixel, there is no stream and no k_light
+            if (L.from_vis) k_material_vis<true><<<groups * 8 * bpr, 256, lds_a, L.main>>>(sp);
+            else k_material<true><<<groups * 8 * bpr, 256, lds_a, L.main>>>(sp);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+            if (L.mid && n_bands == 1 && (e = hipEventRecord(L.mid, L.main)) != hipSuccess) return e;
+            continue;
+        }
+        if (L.from_vis) k_material_vis<false><<<groups * 8 * bpr, 256, lds_a, L.main>>>(sp);
+        else k_material<false><<<groups * 8 * bpr, 256, lds_a, L.main>>>(sp);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         hipStream_t ls = L.main;
         if (L.mid && n_bands == 1 && (e = hipEventRecord(L.mid, L.main)) != hipSuccess) return e;
