@@ -152,7 +152,7 @@ struct ShadeLaunch {
     uint32_t n_bands, light_blocks;
     uint32_t lights_per_trip;   // k_light variant: 4 (two packed pairs per loop trip, 112 VGPRs) or 2 (one pair, 98 VGPRs)
     hipEvent_t mid;   // optional: recorded between k_material and k_light (single band), for per-kernel timing
-    uint32_t sun_only;              // 1: no point lights -- the material kernel shades the sun itself, no stream, no k_light
+    uint32_t inline_mode;           // 0: k_material -> stream -> k_light; 1 / 2: the material kernel runs the light loop itself (scalar / packed pairs)
     uint32_t from_vis;              // 1: k_material_vis (attributes interpolated from the visibility plane) instead of k_material
     uint32_t fused, fused_blocks;   // 1: the whole pass as one persistent kernel (k_shade_fused) of fused_blocks workgroups
 };

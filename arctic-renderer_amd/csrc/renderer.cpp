@@ -78,7 +78,7 @@ struct ArcticRenderer {
     DevBuf d_lit0, d_lit1, d_lit2, d_litpx, d_litcount;   // lit-pixel stream between k_material and k_light
     bool have_gbuffer = false, have_output = false, have_vis = false;   // have_vis: d_vis holds the visibility of the current G-buffer
     int geo_owner = 0;              // whose records d_recs / d_rec_of / d_xverts hold: 1 forward pass, 2 shadow pass
-    bool sun_inline = true;         // scenes without point lights: the material kernel shades the sun itself (no stream, no k_light)
+    int light_path = 0;             // ARCTIC_OPT_LIGHT_PATH: 0 automatic, 1 stream (k_material + k_light), 2 inline scalar, 3 inline packed
     bool visbuffer = true;          // arctic_render_frame shades straight from the visibility plane (no G-buffer)
     // per-frame geometry scratch
     PassTables tables[2];   // [0] forward pass, [1] shadow pass
@@ -386,10 +386,12 @@ int fill_shade_params(ArcticRenderer *r, const ArcticScene *sc, const ArcticSett
 
 // one shading pass; alternates the two stream-counter sets (k_light clears the set the NEXT pass will fill)
 hipError_t shade_once(ArcticRenderer *r, ShadeParams &sp, const ShadeLaunch &L) {
-    if (sp.n_lights == 0 && r->sun_inline && !r->count_evals && L.n_bands == 1) {
-        // sun only: one kernel, the stream and its counters are not touched (both counter sets stay as they are)
-        ShadeLaunch S = L;
-        S.sun_only = 1; S.fused = 0;
+    // which way the lit pixels take (shade.hip, emit_live): automatic = inline, scalar loop up to 16 lights, packed above
+    uint32_t mode = r->light_path == 0 ? (sp.n_lights <= 16 ? 1u : 2u) : (uint32_t)r->light_path - 1u;
+    if (r->count_evals || L.n_bands != 1 || L.fused) mode = 0;   // statistics, bands and the fused kernel live on the stream path
+    if (mode) {
+        ShadeLaunch S = L;   // one kernel; the stream and its counters are not touched (both counter sets stay as they are)
+        S.inline_mode = mode; S.fused = 0;
         return launch_shade(sp, S);
     }
     if (L.fused) {   // one persistent kernel, no stream: the counter sets are left alone (the cleared one stays cleared)
@@ -505,7 +507,7 @@ ArcticRenderer *arctic_create(const ArcticCreateInfo *info, char *err, uint64_t 
         r->launch.light_blocks = (uint32_t)std::max(1, prop.multiProcessorCount) * 24;
         r->launch.n_bands = 1;
         r->launch.lights_per_trip = 4;
-        r->launch.fused = 0; r->launch.fused_blocks = 0; r->launch.sun_only = 0; r->launch.from_vis = 0;
+        r->launch.fused = 0; r->launch.fused_blocks = 0; r->launch.inline_mode = 0; r->launch.from_vis = 0;
         if (const char *f = std::getenv("ARCTIC_SHADE_FUSED")) r->launch.fused = std::atoi(f) ? 1u : 0u;   // default of ARCTIC_OPT_FUSED
         r->cu_count = (uint32_t)std::max(1, prop.multiProcessorCount);
         r->raster_blocks = (uint32_t)std::max(1, prop.multiProcessorCount) * 8;
@@ -920,7 +922,10 @@ int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value) {
         break;
     case ARCTIC_OPT_HDR16: r->hdr16 = value != 0; break;
     case ARCTIC_OPT_VISBUFFER: r->visbuffer = value != 0; break;
-    case ARCTIC_OPT_SUN_INLINE: r->sun_inline = value != 0; break;
+    case ARCTIC_OPT_LIGHT_PATH:
+        if (value < 0 || value > 3) return r->fail(ARCTIC_E_INVALID, "set_option: light path must be 0..3");
+        r->light_path = (int)value;
+        break;
     case ARCTIC_OPT_ITEM_TABLE_FLOOR:
         if (value < 64 || value > 0x7FFFFFF0ll) return r->fail(ARCTIC_E_INVALID, "set_option: item table floor out of range");
         r->item_cap_floor = (uint32_t)value; r->item_cap = 0;

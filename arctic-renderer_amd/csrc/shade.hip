@@ -495,16 +495,31 @@ __device__ __forceinline__ void stage_material_lds(const ShadeParams &sp, float 
     for (uint32_t i = threadIdx.x; i < sp.n_materials * 3; i += 256) ldesc[i] = reinterpret_cast<const uint4 *>(sp.tex)[i];
 }
 
-// what happens to the live pixels of a tile.  Normally they are compacted into the lit-pixel stream for k_light (one
-// atomicAdd per wave, on one of LIT_SHARDS counters each on its own 128-byte line: a single counter would serialise at
-// ~88 atomics/us).  SUN_ONLY (no point lights: the reference's own scenes, BASELINE configs 1-2): the sun is evaluated
-// right here -- one light is not worth a 52-byte round trip through HBM and a second kernel -- with the formulas of
-// light_pixel for zero point lights (the images agree to fp32 rounding: the compiler contracts differently per kernel).
-template <bool SUN_ONLY>
+// what happens to the live pixels of a tile -- three ways, chosen per pass by the host (ShadeLaunch::inline_mode):
+//   MODE 2  the light loop runs right here, packed pairs from LDS (light_pixel<2>).  Lit regions are contiguous, so most
+//           lit tiles are fully lit and the lanes idling at shadow boundaries cost less than the alternative's 52-byte
+//           record written and read back per lit pixel plus a second kernel: the default above 16 point lights
+//           (4K, 64 lights: 0.259 ms against 0.273 ms; still ahead at 256 lights).
+//   MODE 1  the same with a scalar loop over the lights read through the scalar cache: 66 VGPRs keep the occupancy of the
+//           memory-bound part (7 waves/SIMD against 5), which is what matters with few lights: the default up to 16
+//           (the reference's MAX_NUM_POINT_LIGHTS); sun only: 0.121 ms = 68 % of the HBM roof.
+//   MODE 0  the live pixels are compacted into the lit-pixel stream for k_light (one atomicAdd per wave, on one of
+//           LIT_SHARDS counters each on its own 128-byte line: a single counter would serialise at ~88 atomics/us):
+//           every lane of k_light is busy; used for the light-evaluation statistics and kept as an option.
+// All three evaluate the same formulas; images agree to fp32 rounding (the compiler contracts differently per kernel).
+template <int LIGHTS_PER_TRIP>
+__device__ __forceinline__ void light_pixel(const ShadeParams &sp, const float4 *llights, uint32_t lane, float4 r0, float4 r1, float4 r2, uint32_t o);
+__device__ __forceinline__ void stage_lights_lds(const ShadeParams &sp, float4 *llights);
+
+template <int MODE>
 __device__ __forceinline__ void emit_live(const ShadeParams &sp, uint32_t ty, uint32_t tx, uint32_t bpr, uint32_t lane, unsigned long long m,
-                                          bool live, const LitRec &rec) {
+                                          bool live, const LitRec &rec, const float4 *llights = nullptr) {
     if (m == 0ull) return;
-    if (SUN_ONLY) {
+    if (MODE == 2) {
+        if (live) light_pixel<2>(sp, llights, lane, rec.r0, rec.r1, rec.r2, rec.px);
+        return;
+    }
+    if (MODE == 1) {
         if (live) {
             const f3 world = mk(rec.r0.x, rec.r0.y, rec.r0.z), n = mk(rec.r1.x, rec.r1.y, rec.r1.z), base = mk(rec.r2.x, rec.r2.y, rec.r2.z);
             const f3 wo = normalize(mk(sp.eye[0], sp.eye[1], sp.eye[2]) - world);
@@ -512,6 +527,13 @@ __device__ __forceinline__ void emit_live(const ShadeParams &sp, uint32_t ty, ui
             f3 sun = mk(0.0f, 0.0f, 0.0f);
             const f3 d = mk(-sp.sun_dir[0], -sp.sun_dir[1], -sp.sun_dir[2]);
             accumulate_light<false>(px, d, dot(n, d), mk(sp.sun_color[0], sp.sun_color[1], sp.sun_color[2]), sun);
+            for (uint32_t i = 0; i < sp.n_lights; ++i) {   // a handful of point lights
+                const float4 lp = sp.lights[2 * i], lc = sp.lights[2 * i + 1];   // wave-uniform: scalar loads
+                const f3 dl = mk(lp.x, lp.y, lp.z) - world;
+                const float ndl = dot(n, dl);
+                if (sp.culling && ndl <= 0.0f) continue;      // n.wi <= 0: the term is multiplied by max(n.wi, 0) = 0
+                accumulate_light<true>(px, dl, ndl, mk(lc.x, lc.y, lc.z), sun);
+            }
             store_pixel(sp, rec.px, sun * rec.r0.w + base * sp.ambient);   // r0.w = 1 - shadow
         }
         return;
@@ -531,7 +553,7 @@ __device__ __forceinline__ void emit_live(const ShadeParams &sp, uint32_t ty, ui
 
 // ---- kernel 1 of the two-kernel pass: material_tile over every tile, live pixels appended to the lit-pixel stream -----
 // LDS (dynamic): [0,256) sRGB LUT | texture descriptors, 4 dwords each
-template <bool SUN_ONLY>
+template <int MODE>
 __global__ __launch_bounds__(256) void k_material(const ShadeParams sp) {
     extern __shared__ __align__(16) float smem[];
     float *lut = smem;
@@ -550,6 +572,8 @@ __global__ __launch_bounds__(256) void k_material(const ShadeParams sp) {
     TileHead cur;
     if (tile_ok) cur = load_head(sp.g, ((size_t)ty * sp.tiles_x + tx) * 64 + lane);   // in flight while LDS is staged
     stage_material_lds(sp, lut, ldesc);
+    float4 *llights = reinterpret_cast<float4 *>(smem + 256 + (size_t)sp.n_materials * 12);
+    if (MODE == 2) stage_lights_lds(sp, llights);
     __syncthreads();
     if (!tile_ok) return;
     bool live;
@@ -557,7 +581,7 @@ __global__ __launch_bounds__(256) void k_material(const ShadeParams sp) {
     const size_t gi = ((size_t)ty * sp.tiles_x + tx) * 64 + lane;
     const unsigned long long m = material_tile(sp, lut, ldesc, ty, tx, lane, cur, live, rec,
                                                [&](float4 &gc, float4 &gd, float4 &ge) { gc = sp.g.c[gi]; gd = sp.g.d[gi]; ge = sp.g.e[gi]; });
-    emit_live<SUN_ONLY>(sp, ty, tx, bpr, lane, m, live, rec);
+    emit_live<MODE>(sp, ty, tx, bpr, lane, m, live, rec, llights);
 }
 
 // ---- kernel 1 without a G-buffer (whole frames): the same tile walk straight from the visibility plane ----------------
@@ -566,7 +590,7 @@ __global__ __launch_bounds__(256) void k_material(const ShadeParams sp) {
 // triangle, and interpolates uv + light-space position for every covered pixel and world position + tangent frame only
 // for the lit ones -- with the very operations of k_resolve (edges.h, fp contraction off), so the pixels are bit-identical
 // to the G-buffer path.  Everything after the attributes is material_tile, shared.
-template <bool SUN_ONLY>
+template <int MODE>
 __global__ __launch_bounds__(256) void k_material_vis(const ShadeParams sp) {
     extern __shared__ __align__(16) float smem[];
     float *lut = smem;
@@ -581,6 +605,8 @@ __global__ __launch_bounds__(256) void k_material_vis(const ShadeParams sp) {
     unsigned long long key = ~0ull;
     if (tile_ok) key = sp.vis[gi];
     stage_material_lds(sp, lut, ldesc);
+    float4 *llights = reinterpret_cast<float4 *>(smem + 256 + (size_t)sp.n_materials * 12);
+    if (MODE == 2) stage_lights_lds(sp, llights);
     __syncthreads();
     if (!tile_ok) return;
     const int32_t px = (int32_t)(tx * 8 + (lane & 7));
@@ -610,7 +636,7 @@ __global__ __launch_bounds__(256) void k_material_vis(const ShadeParams sp) {
         gd = make_float4(interpolate_attr(B, A0, A1, A2, 3), interpolate_attr(B, A0, A1, A2, 4), interpolate_attr(B, A0, A1, A2, 5), interpolate_attr(B, A0, A1, A2, 6));
         ge = make_float4(interpolate_attr(B, A0, A1, A2, 7), interpolate_attr(B, A0, A1, A2, 8), interpolate_attr(B, A0, A1, A2, 9), interpolate_attr(B, A0, A1, A2, 10));
     });
-    emit_live<SUN_ONLY>(sp, ty, tx, bpr, lane, m, live, rec);
+    emit_live<MODE>(sp, ty, tx, bpr, lane, m, live, rec, llights);
 }
 
 // ---- the light half of ps_main for one lit pixel per lane: the sun + every point light, tonemap, store --------------
@@ -817,15 +843,18 @@ hipError_t launch_shade(const ShadeParams &sp0, const ShadeLaunch &L) {
     for (uint32_t k = 0; k < n_bands; ++k) {
         sp.band = k;
         const uint32_t groups = (row_groups - k + n_bands - 1) / n_bands;
-        if (L.sun_only) {   // no point lights: the material kernel finishes every pixel, there is no stream and no k_light
-            if (L.from_vis) k_material_vis<true><<<groups * 8 * bpr, 256, lds_a, L.main>>>(sp);
-            else k_material<true><<<groups * 8 * bpr, 256, lds_a, L.main>>>(sp);
+        if (L.inline_mode) {   // the material kernel finishes every pixel: no stream, no k_light
+            const size_t lds = lds_a + (L.inline_mode == 2 ? lds_b : 0);
+            if (L.from_vis && L.inline_mode == 2) k_material_vis<2><<<groups * 8 * bpr, 256, lds, L.main>>>(sp);
+            else if (L.from_vis) k_material_vis<1><<<groups * 8 * bpr, 256, lds, L.main>>>(sp);
+            else if (L.inline_mode == 2) k_material<2><<<groups * 8 * bpr, 256, lds, L.main>>>(sp);
+            else k_material<1><<<groups * 8 * bpr, 256, lds, L.main>>>(sp);
             if ((e = hipGetLastError()) != hipSuccess) return e;
             if (L.mid && n_bands == 1 && (e = hipEventRecord(L.mid, L.main)) != hipSuccess) return e;
             continue;
         }
-        if (L.from_vis) k_material_vis<false><<<groups * 8 * bpr, 256, lds_a, L.main>>>(sp);
-        else k_material<false><<<groups * 8 * bpr, 256, lds_a, L.main>>>(sp);
+        if (L.from_vis) k_material_vis<0><<<groups * 8 * bpr, 256, lds_a, L.main>>>(sp);
+        else k_material<0><<<groups * 8 * bpr, 256, lds_a, L.main>>>(sp);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         hipStream_t ls = L.main;
         if (L.mid && n_bands == 1 && (e = hipEventRecord(L.mid, L.main)) != hipSuccess) return e;

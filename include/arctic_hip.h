@@ -272,8 +272,9 @@ int arctic_stats(ArcticRenderer *r, uint64_t *out, uint32_t n);
                                           (bit-identical image; the G-buffer is materialised later if arctic_read_gbuffer / arctic_pass_shade ask); 0 = via the G-buffer */
 #define ARCTIC_OPT_ITEM_TABLE_FLOOR 11 /* smallest size (entries) of the rasteriser's work-item table, default 4 Mi; the table grows to 4x the largest
                                           count seen.  A frame that overflows it returns ARCTIC_E_CAPACITY from the next synchronising call. */
-#define ARCTIC_OPT_SUN_INLINE       12 /* 1 (default) = with zero point lights the material kernel evaluates the sun itself (one kernel, no lit-pixel stream);
-                                          0 = always k_material + k_light.  Same formulas (images agree to fp32 rounding, ~1e-7). */
+#define ARCTIC_OPT_LIGHT_PATH       12 /* how the lit pixels reach the light loop: 0 = automatic (default: inline, scalar loop up to 16 point lights, packed
+                                          pairs above), 1 = k_material -> lit-pixel stream -> k_light, 2 = inline scalar, 3 = inline packed.
+                                          Same formulas (images agree to fp32 rounding, ~1e-7). */
 #define ARCTIC_OPT_BANDS             5 /* 1..16 interleaved screen bands the two shading kernels are pipelined over (default 1: no gain measured) */
 int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value);
 

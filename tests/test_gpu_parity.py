@@ -123,31 +123,35 @@ def test_frame_from_visibility_plane_equals_frame_through_gbuffer(pair):
     np.testing.assert_array_equal(r.read_output()[0].view(np.uint32), a_ldr.view(np.uint32))
 
 
-def test_sun_only_scenes_are_shaded_by_one_kernel_to_the_same_bits(pair, pkg):
-    """ARCTIC_OPT_SUN_INLINE: with zero point lights the material kernel evaluates the sun itself (no stream, no k_light)."""
+def test_light_paths_agree(pair, pkg):
+    """ARCTIC_OPT_LIGHT_PATH: the lit pixels either go through the stream to k_light (1) or the material kernel runs the
+    light loop itself, scalar (2) or packed (3); 0 picks by light count.  Same formulas: the float images agree to fp32
+    rounding (the compiler contracts differently per kernel), each is within the parity bar of the oracle -- with the
+    scene's own lights and as a sun-only scene, through the G-buffer and through the visibility-plane frame."""
     sc, o, r = pair
     lights = sc.lights
-    outs = {}
     try:
-        r.update_lights(lights[:0])                       # every fixture scene as a sun-only scene
-        for mode in (0, 1):
-            r.set_option("sun_inline", mode)
-            r.pass_shadow_map(sc.desc); r.pass_gbuffer(sc.desc)
-            r.pass_shade(sc.desc, sc.settings)
-            ldr, hdr, rgba = (x.copy() for x in r.read_output())
-            frame = r.render_frame(sc.desc, sc.settings)  # and through the visibility-plane path
-            outs[mode] = (ldr, hdr, rgba, frame, r.read_output()[0].copy())
-        # same formulas; the compiler contracts multiply-adds differently in the two kernels, so fp32-rounding-level differences
-        for k in (0, 4):
-            assert np.abs(outs[0][k] - outs[1][k]).max() <= 2e-6
-        assert np.abs(outs[0][1] - outs[1][1]).max() <= 2e-6 * max(1.0, float(outs[0][1].max()))
-        for k in (2, 3):
-            assert np.abs(outs[0][k].astype(np.int16) - outs[1][k].astype(np.int16)).max() <= 1
-        o.update_lights(lights[:0])
-        o.pass_shade(sc.desc, sc.settings)
-        assert np.abs(o.read_output()[0] - outs[1][0]).max() <= TOL
+        for subset in (lights, lights[:0]):
+            r.update_lights(subset); o.update_lights(subset)
+            o.pass_shade(sc.desc, sc.settings)
+            ref = o.read_output()[0]
+            outs = {}
+            for path in (1, 2, 3, 0):
+                r.set_option("light_path", path)
+                r.pass_shadow_map(sc.desc); r.pass_gbuffer(sc.desc)
+                r.pass_shade(sc.desc, sc.settings)
+                ldr, hdr, rgba = (x.copy() for x in r.read_output())
+                frame = r.render_frame(sc.desc, sc.settings)
+                outs[path] = (ldr, hdr, rgba, frame, r.read_output()[0].copy())
+                assert np.abs(ldr - ref).max() <= TOL and np.abs(outs[path][4] - ref).max() <= TOL
+            for path in (2, 3, 0):
+                for k in (0, 4):
+                    assert np.abs(outs[1][k] - outs[path][k]).max() <= 3e-6
+                assert np.abs(outs[1][1] - outs[path][1]).max() <= 3e-6 * max(1.0, float(outs[1][1].max()))
+                for k in (2, 3):
+                    assert np.abs(outs[1][k].astype(np.int16) - outs[path][k].astype(np.int16)).max() <= 1
     finally:
-        r.set_option("sun_inline", 1)
+        r.set_option("light_path", 0)
         r.update_lights(lights); o.update_lights(lights)
         r.pass_shadow_map(sc.desc); r.pass_gbuffer(sc.desc)
 
