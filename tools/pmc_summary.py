@@ -21,14 +21,16 @@ for path in glob.glob(os.path.join(root, "**", "*kernel_stats.csv"), recursive=T
     for row in csv.DictReader(open(path)):
         k = next((k for k in KERNELS if k + "(" in row["Name"] or k + "<" in row["Name"]), None)
         if k:
-            out[f"{k}.avg_ns_under_kernel_trace[{os.path.basename(os.path.dirname(os.path.dirname(path)))}]"] = float(row["AverageNs"])
+            import re
+            full = re.search(r"(k_\w+(<\d+>)?)\(", row["Name"]).group(1)   # with its template argument: k_material<2>, k_light<4>
+            out[f"{full}.avg_ns_under_kernel_trace[{os.path.basename(os.path.dirname(os.path.dirname(path)))}] ({row['Calls']} calls)"] = float(row["AverageNs"])
 dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
 json.dump(out, open(os.path.join(dst, f"{tag}_pmc_counters.json"), "w"), indent=1)
-f = {k: out.get(f"{k}.FETCH_SIZE", 0.0) for k in ("k_material", "k_light")}
-w = {k: out.get(f"{k}.WRITE_SIZE", 0.0) for k in ("k_material", "k_light")}
+f = {k: out[f"{k}.FETCH_SIZE"] for k in KERNELS if f"{k}.FETCH_SIZE" in out}
+w = {k: out[f"{k}.WRITE_SIZE"] for k in KERNELS if f"{k}.WRITE_SIZE" in out}
 if any(f.values()):
     json.dump({"command": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace -- python3 tools/prof_shade.py full",
-               "config": "config 3: 3840x2160, 64 point lights, shadow 4000^2, ACES; one shading pass = k_material + k_light",
+               "config": "config 3: 3840x2160, 64 point lights, shadow 4000^2, ACES; one shading pass = the kernels listed (k_material<2> alone by default)",
                "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w,
                "correction": "reads doubled (gfx950 FETCH_SIZE counts 128-B requests as 64 B); writes as reported",
                "hbm_bytes_per_launch": int(round((2 * sum(f.values()) + sum(w.values())) * 1024)),
