@@ -389,6 +389,9 @@ hipError_t shade_once(ArcticRenderer *r, ShadeParams &sp, const ShadeLaunch &L) 
     // which way the lit pixels take (shade.hip, emit_live): automatic = inline, scalar loop up to 16 lights, packed above
     uint32_t mode = r->light_path == 0 ? (sp.n_lights <= 16 ? 1u : 2u) : (uint32_t)r->light_path - 1u;
     if (r->count_evals || L.n_bands != 1 || L.fused) mode = 0;   // statistics, bands and the fused kernel live on the stream path
+    // the packed inline kernel keeps descriptors AND light pairs in LDS; past the 64 KiB a workgroup gets by default (hundreds of
+    // materials with thousands of lights) the two tables go back to separate kernels
+    if (mode == 2 && (256 + (size_t)sp.n_materials * 12) * 4 + (size_t)((sp.n_lights + 3) / 4) * 96 > 64 * 1024) mode = 0;
     if (mode) {
         ShadeLaunch S = L;   // one kernel; the stream and its counters are not touched (both counter sets stay as they are)
         S.inline_mode = mode; S.fused = 0;

@@ -131,3 +131,46 @@ def test_work_item_table_overflow_is_reported_and_recovers(pkg, hip):
     np.testing.assert_array_equal(img, ref)
     np.testing.assert_array_equal(r.render_frame(sc.desc, sc.settings), ref)
     r.close()
+
+
+@pytest.mark.parametrize("n_mat,n_lights", [(1, 2048), (400, 2048), (400, 40)], ids=["2048-lights", "400-materials-2048-lights", "400-materials-40-lights"])
+def test_large_light_and_material_tables(pkg, oracle, hip, n_mat, n_lights):
+    """the tables the kernels keep in LDS at their limits: with both at once the packed inline kernel would need more than
+    64 KiB and the library takes the stream path instead -- same image either way."""
+    rng = np.random.default_rng(n_mat * 7 + n_lights)
+    w, h = 96, 64
+    mats = [tuple(rng.integers(40, 220, (4, 4, 4), dtype=np.uint8) for _ in range(3)) for _ in range(n_mat)]
+    for d, n, m in mats:
+        n[..., :2] = rng.integers(118, 138, (4, 4, 2)); n[..., 2] = 255
+        m[..., 1] = rng.integers(40, 255, (4, 4)); m[..., 2] = 0
+    quad = tri_mesh(pkg, [(-1, -1, 0), (1, -1, 0), (1, 1, 0), (-1, 1, 0)])
+    idx = np.array([0, 1, 2, 0, 2, 3], np.uint32)
+    meshes = [(quad, idx, k) for k in range(n_mat)]
+    cols = int(np.ceil(np.sqrt(n_mat)))
+    objs = []
+    for k in range(n_mat):
+        s = pkg.scene.scaling(3.2 / cols, 2.2 / cols, 1.0)
+        t = pkg.scene.translation(-3.2 + (k % cols + 0.5) * 6.4 / cols, -2.2 + (k // cols + 0.5) * 4.4 / cols, 0.0)
+        objs.append((t @ s, k))
+    lights = pkg.scene.make_lights(rng.uniform((-3, -2, 0.3), (3, 2, 2.5), (n_lights, 3)), rng.uniform(0.0, 0.02, (n_lights, 3)))
+    outs = []
+    for cls in (oracle.Oracle, hip.Renderer):
+        r = cls(w, h, 0, n_lights)
+        for m in mats:
+            r.create_material(*m)
+        for v, i, mat in meshes:
+            r.create_mesh(v, i, mat)
+        r.update_lights(lights)
+        if cls is hip.Renderer:
+            r.set_option("keep_float_output", 1)
+        desc = camera_scene(pkg, pkg.scene.make_objects(objs), w, h, lights)
+        r.render_frame(desc, (0, 2.2, 1.0))
+        outs.append(r.read_output()[0].copy())
+        if cls is hip.Renderer:
+            for path in (1, 3) if n_lights > 16 else (1, 2):
+                r.set_option("light_path", path)
+                r.render_frame(desc, (0, 2.2, 1.0))
+                assert np.abs(r.read_output()[0] - outs[-1]).max() <= 3e-6
+        r.close()
+    assert outs[0].max() > 0.2
+    assert np.abs(outs[0] - outs[1]).max() <= TOL
