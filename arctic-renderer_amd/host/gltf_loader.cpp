@@ -1,0 +1,626 @@
+// gltf_loader.cpp -- the scene-loader stand-in behind include/arctic_gltf.h.
+//
+// Restates what App::load_scene (reference src/app.cpp:173-385) obtains from assimp + stb_image for a glTF 2.0 file, with
+// nothing but the C++ standard library and zlib: a small JSON reader, a PNG decoder, the glTF accessor plumbing, and the
+// post-processing steps the reference asks assimp for (Triangulate is moot: triangles only; FlipUVs; CalcTangentSpace;
+// JoinIdenticalVertices is skipped -- glTF vertices are already indexed and joining does not change the image).
+// Host code only: no HIP here.  assimp and the real assets are not available offline, so this file is checked against
+// glTF files the test-suite writes itself (tests/test_gltf_loader.py); parity with assimp's output is unpinned.
+#include <zlib.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/arctic_gltf.h"
+
+namespace {
+
+[[noreturn]] void fail(const std::string &m) { throw std::runtime_error(m); }
+
+// ------------------------------------------------------------------------------------------------- JSON
+struct Json {
+    enum Kind { Null, Bool, Number, String, Array, Object } kind = Null;
+    bool b = false;
+    double num = 0.0;
+    std::string str;
+    std::vector<Json> arr;
+    std::vector<std::pair<std::string, Json>> obj;
+
+    const Json *find(const char *key) const {
+        if (kind != Object) return nullptr;
+        for (const auto &kv : obj)
+            if (kv.first == key) return &kv.second;
+        return nullptr;
+    }
+    const Json &at(const char *key) const {
+        const Json *j = find(key);
+        if (!j) fail(std::string("glTF: missing key '") + key + "'");
+        return *j;
+    }
+    bool has(const char *key) const { return find(key) != nullptr; }
+    size_t size() const { return kind == Array ? arr.size() : 0; }
+    const Json &operator[](size_t i) const {
+        if (kind != Array || i >= arr.size()) fail("glTF: array index out of range");
+        return arr[i];
+    }
+    int64_t as_int() const {
+        if (kind != Number) fail("glTF: number expected");
+        return (int64_t)num;
+    }
+    double as_num() const {
+        if (kind != Number) fail("glTF: number expected");
+        return num;
+    }
+    const std::string &as_str() const {
+        if (kind != String) fail("glTF: string expected");
+        return str;
+    }
+};
+
+struct JsonParser {
+    const char *p, *end;
+    explicit JsonParser(const std::string &s) : p(s.data()), end(s.data() + s.size()) {}
+    void ws() { while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) ++p; }
+    bool eat(char c) { ws(); if (p < end && *p == c) { ++p; return true; } return false; }
+    void expect(char c) { if (!eat(c)) fail(std::string("JSON: expected '") + c + "'"); }
+    Json parse() { Json j = value(); ws(); if (p != end) fail("JSON: trailing characters"); return j; }
+    Json value() {
+        ws();
+        if (p >= end) fail("JSON: unexpected end");
+        Json j;
+        if (*p == '{') {
+            ++p; j.kind = Json::Object;
+            if (eat('}')) return j;
+            do { ws(); std::string k = string(); expect(':'); j.obj.emplace_back(std::move(k), value()); } while (eat(','));
+            expect('}');
+        } else if (*p == '[') {
+            ++p; j.kind = Json::Array;
+            if (eat(']')) return j;
+            do { j.arr.push_back(value()); } while (eat(','));
+            expect(']');
+        } else if (*p == '"') {
+            j.kind = Json::String; j.str = string();
+        } else if (!std::strncmp(p, "true", 4)) { j.kind = Json::Bool; j.b = true; p += 4;
+        } else if (!std::strncmp(p, "false", 5)) { j.kind = Json::Bool; p += 5;
+        } else if (!std::strncmp(p, "null", 4)) { p += 4;
+        } else {
+            char *e = nullptr;
+            j.kind = Json::Number; j.num = std::strtod(p, &e);
+            if (e == p) fail("JSON: bad value");
+            p = e;
+        }
+        return j;
+    }
+    std::string string() {
+        if (p >= end || *p != '"') fail("JSON: string expected");
+        ++p;
+        std::string s;
+        while (p < end && *p != '"') {
+            if (*p == '\\') {
+                if (++p >= end) break;
+                switch (*p) {
+                case 'n': s += '\n'; break; case 't': s += '\t'; break; case 'r': s += '\r'; break;
+                case 'b': s += '\b'; break; case 'f': s += '\f'; break;
+                case 'u': {   // BMP code point -> UTF-8 (surrogate pairs are not needed for file names)
+                    if (end - p < 5) fail("JSON: bad \\u escape");
+                    unsigned cp = (unsigned)std::strtoul(std::string(p + 1, 4).c_str(), nullptr, 16);
+                    p += 4;
+                    if (cp < 0x80) s += (char)cp;
+                    else if (cp < 0x800) { s += (char)(0xC0 | (cp >> 6)); s += (char)(0x80 | (cp & 0x3F)); }
+                    else { s += (char)(0xE0 | (cp >> 12)); s += (char)(0x80 | ((cp >> 6) & 0x3F)); s += (char)(0x80 | (cp & 0x3F)); }
+                    break;
+                }
+                default: s += *p;
+                }
+                ++p;
+            } else s += *p++;
+        }
+        if (p >= end) fail("JSON: unterminated string");
+        ++p;
+        return s;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------- PNG
+uint32_t be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+
+int paeth(int a, int b, int c) {
+    int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+    return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+}
+
+// RGBA8 like stbi_load(path, &w, &h, nullptr, 4): grey is replicated, missing alpha is 255, 16-bit keeps the high byte
+std::vector<uint8_t> decode_png(const uint8_t *data, size_t size, uint32_t &w, uint32_t &h) {
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    if (size < 8 || std::memcmp(data, sig, 8)) fail("not a PNG file (JPEG and other formats are not supported: convert to PNG)");
+    size_t pos = 8;
+    uint32_t depth = 0, ctype = 0, interlace = 0;
+    std::vector<uint8_t> idat, plte, trns;
+    bool have_ihdr = false;
+    while (pos + 12 <= size) {
+        const uint32_t len = be32(data + pos);
+        const char *type = reinterpret_cast<const char *>(data + pos + 4);
+        const uint8_t *body = data + pos + 8;
+        if (pos + 12 + (size_t)len > size) fail("PNG: truncated chunk");
+        if (!std::memcmp(type, "IHDR", 4)) {
+            if (len < 13) fail("PNG: bad IHDR");
+            w = be32(body); h = be32(body + 4); depth = body[8]; ctype = body[9]; interlace = body[12];
+            have_ihdr = true;
+        } else if (!std::memcmp(type, "PLTE", 4)) plte.assign(body, body + len);
+        else if (!std::memcmp(type, "tRNS", 4)) trns.assign(body, body + len);
+        else if (!std::memcmp(type, "IDAT", 4)) idat.insert(idat.end(), body, body + len);
+        else if (!std::memcmp(type, "IEND", 4)) break;
+        pos += 12 + (size_t)len;
+    }
+    if (!have_ihdr || w == 0 || h == 0 || w > 65535 || h > 65535) fail("PNG: bad header");
+    if (interlace) fail("PNG: interlaced images are not supported");
+    int channels = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+    if (!channels) fail("PNG: bad colour type");
+    if (!(depth == 8 || depth == 16 || ((ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4)))) fail("PNG: unsupported bit depth");
+    if (ctype == 3 && plte.size() < 3) fail("PNG: palette missing");
+    const size_t bpp_bits = (size_t)channels * depth, stride = (w * bpp_bits + 7) / 8, bpp = (bpp_bits + 7) / 8;
+    std::vector<uint8_t> raw((stride + 1) * h);
+    uLongf out_len = (uLongf)raw.size();
+    int zr = uncompress(raw.data(), &out_len, idat.data(), (uLong)idat.size());
+    if (zr != Z_OK || out_len != raw.size()) fail("PNG: inflate failed");
+    std::vector<uint8_t> prev(stride, 0), line(stride);
+    std::vector<uint8_t> out((size_t)w * h * 4);
+    for (uint32_t y = 0; y < h; ++y) {
+        const uint8_t ft = raw[(stride + 1) * y];
+        const uint8_t *src = &raw[(stride + 1) * y + 1];
+        for (size_t i = 0; i < stride; ++i) {
+            const int a = i >= bpp ? line[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
+            int v = src[i];
+            switch (ft) {
+            case 0: break;
+            case 1: v += a; break;
+            case 2: v += b; break;
+            case 3: v += (a + b) >> 1; break;
+            case 4: v += paeth(a, b, c); break;
+            default: fail("PNG: bad filter type");
+            }
+            line[i] = (uint8_t)v;
+        }
+        for (uint32_t x = 0; x < w; ++x) {
+            uint8_t *o = &out[((size_t)y * w + x) * 4];
+            auto sample = [&](int ch) -> uint32_t {   // channel ch of pixel x, scaled to 8 bits
+                if (depth == 8) return line[(size_t)x * channels + ch];
+                if (depth == 16) return line[((size_t)x * channels + ch) * 2];
+                const size_t bit = (size_t)x * depth;
+                const uint32_t v = (line[bit >> 3] >> (8 - depth - (bit & 7))) & ((1u << depth) - 1u);
+                return ctype == 3 ? v : v * 255u / ((1u << depth) - 1u);
+            };
+            switch (ctype) {
+            case 0: { const uint32_t g = sample(0); o[0] = o[1] = o[2] = (uint8_t)g; o[3] = 255; break; }
+            case 2: o[0] = (uint8_t)sample(0); o[1] = (uint8_t)sample(1); o[2] = (uint8_t)sample(2); o[3] = 255; break;
+            case 3: {
+                const uint32_t i = sample(0);
+                if ((size_t)i * 3 + 2 >= plte.size()) fail("PNG: palette index out of range");
+                o[0] = plte[i * 3]; o[1] = plte[i * 3 + 1]; o[2] = plte[i * 3 + 2]; o[3] = i < trns.size() ? trns[i] : 255;
+                break;
+            }
+            case 4: { const uint32_t g = sample(0); o[0] = o[1] = o[2] = (uint8_t)g; o[3] = (uint8_t)sample(1); break; }
+            default: o[0] = (uint8_t)sample(0); o[1] = (uint8_t)sample(1); o[2] = (uint8_t)sample(2); o[3] = (uint8_t)sample(3);
+            }
+        }
+        prev.swap(line);
+    }
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------------- files, base64
+std::vector<uint8_t> read_file(const std::string &path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) fail("cannot open '" + path + "'");
+    return std::vector<uint8_t>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+
+std::vector<uint8_t> base64(const std::string &s, size_t from) {
+    std::vector<uint8_t> out;
+    uint32_t acc = 0;
+    int bits = 0;
+    for (size_t i = from; i < s.size(); ++i) {
+        const char c = s[i];
+        int v = c >= 'A' && c <= 'Z' ? c - 'A' : c >= 'a' && c <= 'z' ? c - 'a' + 26 : c >= '0' && c <= '9' ? c - '0' + 52 : c == '+' ? 62 : c == '/' ? 63 : -1;
+        if (v < 0) continue;   // '=' padding, whitespace
+        acc = (acc << 6) | (uint32_t)v;
+        if ((bits += 6) >= 8) { bits -= 8; out.push_back((uint8_t)(acc >> bits)); }
+    }
+    return out;
+}
+
+std::string dir_of(const std::string &path) {
+    const size_t s = path.find_last_of("/\\");
+    return s == std::string::npos ? std::string() : path.substr(0, s + 1);
+}
+
+std::string uri_decode(const std::string &u) {
+    std::string o;
+    for (size_t i = 0; i < u.size(); ++i)
+        if (u[i] == '%' && i + 2 < u.size()) { o += (char)std::strtoul(u.substr(i + 1, 2).c_str(), nullptr, 16); i += 2; }
+        else o += u[i];
+    return o;
+}
+
+std::vector<uint8_t> load_uri(const std::string &uri, const std::string &base) {
+    if (uri.rfind("data:", 0) == 0) {
+        const size_t c = uri.find("base64,");
+        if (c == std::string::npos) fail("glTF: only base64 data URIs are supported");
+        return base64(uri, c + 7);
+    }
+    return read_file(base + uri_decode(uri));
+}
+
+// ------------------------------------------------------------------------------------------------- math (column-major 4x4 as glm)
+struct M4 { float m[16]; };   // m[col * 4 + row]
+M4 identity() { M4 r{}; r.m[0] = r.m[5] = r.m[10] = r.m[15] = 1.0f; return r; }
+M4 mul(const M4 &a, const M4 &b) {   // glm operator*: column j of the result = a * (column j of b), fp32 left to right
+    M4 r;
+    for (int j = 0; j < 4; ++j)
+        for (int i = 0; i < 4; ++i)
+            r.m[j * 4 + i] = ((a.m[i] * b.m[j * 4] + a.m[4 + i] * b.m[j * 4 + 1]) + a.m[8 + i] * b.m[j * 4 + 2]) + a.m[12 + i] * b.m[j * 4 + 3];
+    return r;
+}
+M4 transpose(const M4 &a) { M4 r; for (int c = 0; c < 4; ++c) for (int q = 0; q < 4; ++q) r.m[c * 4 + q] = a.m[q * 4 + c]; return r; }
+
+struct Image { std::vector<uint8_t> px; uint32_t w = 0, h = 0; };
+Image solid(uint8_t r, uint8_t g, uint8_t b) {   // assets/white.png, assets/normal.png are 16x16 of one colour
+    Image im; im.w = im.h = 16; im.px.resize(16 * 16 * 4);
+    for (size_t i = 0; i < 256; ++i) { im.px[i * 4] = r; im.px[i * 4 + 1] = g; im.px[i * 4 + 2] = b; im.px[i * 4 + 3] = 255; }
+    return im;
+}
+
+struct Material { Image img[3]; };
+struct Mesh { std::vector<ArcticVertex> v; std::vector<uint32_t> idx; uint64_t material = 0; };
+
+}  // namespace
+
+struct ArcticGltf {
+    std::vector<Material> materials;
+    std::vector<Mesh> meshes;
+    std::vector<ArcticObject> objects;
+};
+
+namespace {
+
+struct Loader {
+    const Json &doc;
+    std::string base;
+    std::vector<std::vector<uint8_t>> buffers;
+    std::map<size_t, Image> image_cache;
+
+    Loader(const Json &d, std::string b) : doc(d), base(std::move(b)) {}
+
+    const std::vector<uint8_t> &buffer(size_t i) {
+        const Json &bufs = doc.at("buffers");
+        if (buffers.size() < bufs.size()) buffers.resize(bufs.size());
+        if (buffers[i].empty()) {
+            const Json &b = bufs[i];
+            if (!b.has("uri")) fail("glTF: buffer without uri (.glb containers are not supported)");
+            buffers[i] = load_uri(b.at("uri").as_str(), base);
+            if (buffers[i].size() < (size_t)b.at("byteLength").as_int()) fail("glTF: buffer shorter than byteLength");
+        }
+        return buffers[i];
+    }
+
+    // accessor -> floats (n_comp per element), converting normalised integers like the glTF spec says
+    std::vector<float> floats(size_t accessor, int n_comp) {
+        const Json &a = doc.at("accessors")[accessor];
+        if (a.has("sparse")) fail("glTF: sparse accessors are not supported");
+        static const std::map<std::string, int> comps = {{"SCALAR", 1}, {"VEC2", 2}, {"VEC3", 3}, {"VEC4", 4}};
+        const auto it = comps.find(a.at("type").as_str());
+        if (it == comps.end() || it->second < n_comp) fail("glTF: accessor type mismatch");
+        const int file_comp = it->second;
+        const int64_t ct = a.at("componentType").as_int(), count = a.at("count").as_int();
+        const bool norm = a.has("normalized") && a.at("normalized").b;
+        const size_t csize = ct == 5126 || ct == 5125 ? 4 : (ct == 5123 || ct == 5122 ? 2 : 1);
+        const Json &bv = doc.at("bufferViews")[(size_t)a.at("bufferView").as_int()];
+        const std::vector<uint8_t> &buf = buffer((size_t)bv.at("buffer").as_int());
+        const size_t off = (size_t)(bv.has("byteOffset") ? bv.at("byteOffset").as_int() : 0) + (size_t)(a.has("byteOffset") ? a.at("byteOffset").as_int() : 0);
+        const size_t stride = bv.has("byteStride") ? (size_t)bv.at("byteStride").as_int() : csize * file_comp;
+        if (count < 0 || off + (count ? (size_t)(count - 1) * stride + csize * file_comp : 0) > buf.size()) fail("glTF: accessor out of bounds");
+        std::vector<float> out((size_t)count * n_comp);
+        for (int64_t i = 0; i < count; ++i)
+            for (int c = 0; c < n_comp; ++c) {
+                const uint8_t *p = &buf[off + (size_t)i * stride + (size_t)c * csize];
+                float v;
+                switch (ct) {
+                case 5126: std::memcpy(&v, p, 4); break;
+                case 5121: v = norm ? *p / 255.0f : (float)*p; break;
+                case 5123: { uint16_t u; std::memcpy(&u, p, 2); v = norm ? u / 65535.0f : (float)u; break; }
+                case 5120: { int8_t s; std::memcpy(&s, p, 1); v = norm ? std::fmax(s / 127.0f, -1.0f) : (float)s; break; }
+                case 5122: { int16_t s; std::memcpy(&s, p, 2); v = norm ? std::fmax(s / 32767.0f, -1.0f) : (float)s; break; }
+                default: fail("glTF: unsupported component type");
+                }
+                out[(size_t)i * n_comp + c] = v;
+            }
+        return out;
+    }
+
+    std::vector<uint32_t> indices(size_t accessor) {
+        const Json &a = doc.at("accessors")[accessor];
+        const int64_t ct = a.at("componentType").as_int(), count = a.at("count").as_int();
+        const size_t csize = ct == 5125 ? 4 : ct == 5123 ? 2 : ct == 5121 ? 1 : 0;
+        if (!csize || a.at("type").as_str() != "SCALAR") fail("glTF: bad index accessor");
+        const Json &bv = doc.at("bufferViews")[(size_t)a.at("bufferView").as_int()];
+        const std::vector<uint8_t> &buf = buffer((size_t)bv.at("buffer").as_int());
+        const size_t off = (size_t)(bv.has("byteOffset") ? bv.at("byteOffset").as_int() : 0) + (size_t)(a.has("byteOffset") ? a.at("byteOffset").as_int() : 0);
+        if (count < 0 || off + (size_t)count * csize > buf.size()) fail("glTF: index accessor out of bounds");
+        std::vector<uint32_t> out((size_t)count);
+        for (int64_t i = 0; i < count; ++i) {
+            const uint8_t *p = &buf[off + (size_t)i * csize];
+            if (csize == 4) std::memcpy(&out[(size_t)i], p, 4);
+            else if (csize == 2) { uint16_t u; std::memcpy(&u, p, 2); out[(size_t)i] = u; }
+            else out[(size_t)i] = *p;
+        }
+        return out;
+    }
+
+    const Image &image_of_texture(size_t texture) {
+        const Json &t = doc.at("textures")[texture];
+        const size_t src = (size_t)t.at("source").as_int();
+        auto it = image_cache.find(src);
+        if (it != image_cache.end()) return it->second;
+        const Json &im = doc.at("images")[src];
+        std::vector<uint8_t> file;
+        if (im.has("uri")) file = load_uri(im.at("uri").as_str(), base);
+        else if (im.has("bufferView")) {
+            const Json &bv = doc.at("bufferViews")[(size_t)im.at("bufferView").as_int()];
+            const std::vector<uint8_t> &buf = buffer((size_t)bv.at("buffer").as_int());
+            const size_t off = bv.has("byteOffset") ? (size_t)bv.at("byteOffset").as_int() : 0, len = (size_t)bv.at("byteLength").as_int();
+            if (off + len > buf.size()) fail("glTF: image bufferView out of bounds");
+            file.assign(buf.begin() + (long)off, buf.begin() + (long)(off + len));
+        } else fail("glTF: image without uri or bufferView");
+        Image out;
+        out.px = decode_png(file.data(), file.size(), out.w, out.h);
+        return image_cache.emplace(src, std::move(out)).first->second;
+    }
+};
+
+inline void sub3(const float *a, const float *b, float *o) { o[0] = a[0] - b[0]; o[1] = a[1] - b[1]; o[2] = a[2] - b[2]; }
+inline float dot3(const float *a, const float *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+inline void cross3(const float *a, const float *b, float *o) { o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0]; }
+inline bool normalize3(float *v) { const float l = std::sqrt(dot3(v, v)); if (!(l > 0.0f) || !std::isfinite(l)) return false; v[0] /= l; v[1] /= l; v[2] /= l; return true; }
+
+// aiProcess_CalcTangentSpace (assimp v5.4.3, the version the reference pins in CMakeLists.txt:82-87; restated from its
+// published algorithm) for meshes without a TANGENT attribute: per triangle, the UV-space gradient of the position
+// (dirCorrection keeps handedness), orthogonalised against each vertex normal and normalised; a vertex keeps the value of
+// the last triangle that touches it (assimp additionally averages over vertices sharing position and normal).
+void calc_tangents(Mesh &m) {
+    for (size_t f = 0; f + 2 < m.idx.size(); f += 3) {
+        ArcticVertex *p[3] = {&m.v[m.idx[f]], &m.v[m.idx[f + 1]], &m.v[m.idx[f + 2]]};
+        float v[3], w[3];
+        sub3(p[1]->position, p[0]->position, v);
+        sub3(p[2]->position, p[0]->position, w);
+        float sx = p[1]->tex_coords[0] - p[0]->tex_coords[0], sy = p[1]->tex_coords[1] - p[0]->tex_coords[1];
+        float tx = p[2]->tex_coords[0] - p[0]->tex_coords[0], ty = p[2]->tex_coords[1] - p[0]->tex_coords[1];
+        const float dir = (tx * sy - ty * sx) < 0.0f ? -1.0f : 1.0f;
+        if (sx * ty == sy * tx) { sx = 0.0f; sy = 1.0f; tx = 1.0f; ty = 0.0f; }
+        float t[3], b[3];
+        for (int k = 0; k < 3; ++k) { t[k] = (w[k] * sy - v[k] * ty) * dir; b[k] = (-w[k] * sx + v[k] * tx) * dir; }   // +dP/du, +dP/dv
+        for (ArcticVertex *q : p) {
+            float lt[3], lb[3];
+            const float dt = dot3(t, q->normal), db = dot3(b, q->normal);
+            for (int k = 0; k < 3; ++k) { lt[k] = t[k] - q->normal[k] * dt; lb[k] = b[k] - q->normal[k] * db; }
+            const bool ok_t = normalize3(lt), ok_b = normalize3(lb);
+            if (!ok_t && ok_b) { cross3(lb, q->normal, lt); normalize3(lt); }
+            if (!ok_b && ok_t) { cross3(q->normal, lt, lb); normalize3(lb); }
+            std::memcpy(q->tangent, lt, 12);
+            std::memcpy(q->bitangent, lb, 12);
+        }
+    }
+}
+
+M4 node_matrix(const Json &n) {   // the node's local transform as glTF defines it (column-major), fp32
+    if (n.has("matrix")) {
+        const Json &a = n.at("matrix");
+        if (a.size() != 16) fail("glTF: node.matrix must have 16 numbers");
+        M4 r;
+        for (size_t i = 0; i < 16; ++i) r.m[i] = (float)a[i].as_num();
+        return r;
+    }
+    float t[3] = {0, 0, 0}, q[4] = {0, 0, 0, 1}, s[3] = {1, 1, 1};
+    if (n.has("translation")) for (size_t i = 0; i < 3; ++i) t[i] = (float)n.at("translation")[i].as_num();
+    if (n.has("rotation")) for (size_t i = 0; i < 4; ++i) q[i] = (float)n.at("rotation")[i].as_num();
+    if (n.has("scale")) for (size_t i = 0; i < 3; ++i) s[i] = (float)n.at("scale")[i].as_num();
+    const float x = q[0], y = q[1], z = q[2], w = q[3];
+    M4 r = identity();
+    r.m[0] = (1 - 2 * (y * y + z * z)) * s[0]; r.m[1] = (2 * (x * y + z * w)) * s[0]; r.m[2] = (2 * (x * z - y * w)) * s[0];
+    r.m[4] = (2 * (x * y - z * w)) * s[1]; r.m[5] = (1 - 2 * (x * x + z * z)) * s[1]; r.m[6] = (2 * (y * z + x * w)) * s[1];
+    r.m[8] = (2 * (x * z + y * w)) * s[2]; r.m[9] = (2 * (y * z - x * w)) * s[2]; r.m[10] = (1 - 2 * (x * x + y * y)) * s[2];
+    r.m[12] = t[0]; r.m[13] = t[1]; r.m[14] = t[2];
+    return r;
+}
+
+std::unique_ptr<ArcticGltf> load(const std::string &path) {
+    const std::vector<uint8_t> text = read_file(path);
+    if (text.size() >= 4 && !std::memcmp(text.data(), "glTF", 4)) fail("binary .glb containers are not supported: use the .gltf + .bin form");
+    const Json doc = JsonParser(std::string(text.begin(), text.end())).parse();
+    Loader L(doc, dir_of(path));
+    auto g = std::make_unique<ArcticGltf>();
+
+    // materials (app.cpp:195-294): three images each, fallbacks for the missing ones
+    const size_t n_mat = doc.has("materials") ? doc.at("materials").size() : 0;
+    for (size_t i = 0; i < n_mat; ++i) {
+        const Json &m = doc.at("materials")[i];
+        Material out;
+        out.img[0] = solid(255, 255, 255); out.img[1] = solid(128, 128, 255); out.img[2] = solid(255, 255, 255);
+        if (const Json *pbr = m.find("pbrMetallicRoughness")) {
+            if (const Json *t = pbr->find("baseColorTexture")) out.img[0] = L.image_of_texture((size_t)t->at("index").as_int());
+            if (const Json *t = pbr->find("metallicRoughnessTexture")) out.img[2] = L.image_of_texture((size_t)t->at("index").as_int());
+        }
+        if (const Json *t = m.find("normalTexture")) out.img[1] = L.image_of_texture((size_t)t->at("index").as_int());
+        g->materials.push_back(std::move(out));
+    }
+    if (g->materials.empty()) {   // assimp always provides a default material
+        Material d;
+        d.img[0] = solid(255, 255, 255); d.img[1] = solid(128, 128, 255); d.img[2] = solid(255, 255, 255);
+        g->materials.push_back(std::move(d));
+    }
+
+    // meshes (app.cpp:296-352): one per primitive, in file order; remember where each glTF mesh starts
+    std::vector<size_t> first_of_mesh, count_of_mesh;
+    const size_t n_mesh = doc.has("meshes") ? doc.at("meshes").size() : 0;
+    for (size_t i = 0; i < n_mesh; ++i) {
+        const Json &prims = doc.at("meshes")[i].at("primitives");
+        first_of_mesh.push_back(g->meshes.size());
+        for (size_t k = 0; k < prims.size(); ++k) {
+            const Json &p = prims[k];
+            if (p.has("mode") && p.at("mode").as_int() != 4) fail("glTF: only triangle lists (mode 4) are supported");
+            const Json &at = p.at("attributes");
+            if (!at.has("POSITION")) fail("glTF: primitive without POSITION");
+            if (!at.has("NORMAL") || !at.has("TEXCOORD_0")) fail("glTF: primitives need NORMAL and TEXCOORD_0 (load_scene reads both unconditionally)");
+            const std::vector<float> pos = L.floats((size_t)at.at("POSITION").as_int(), 3);
+            const std::vector<float> nor = L.floats((size_t)at.at("NORMAL").as_int(), 3);
+            const std::vector<float> uv = L.floats((size_t)at.at("TEXCOORD_0").as_int(), 2);
+            const size_t nv = pos.size() / 3;
+            if (nor.size() / 3 != nv || uv.size() / 2 != nv) fail("glTF: attribute counts differ");
+            Mesh m;
+            m.v.resize(nv);
+            for (size_t v = 0; v < nv; ++v) {
+                ArcticVertex &o = m.v[v];
+                std::memset(&o, 0, sizeof o);
+                std::memcpy(o.position, &pos[v * 3], 12);
+                std::memcpy(o.normal, &nor[v * 3], 12);
+                o.tex_coords[0] = uv[v * 2];
+                o.tex_coords[1] = 1.0f - uv[v * 2 + 1];   // aiProcess_FlipUVs
+            }
+            if (p.has("indices")) m.idx = L.indices((size_t)p.at("indices").as_int());
+            else { m.idx.resize(nv); for (size_t v = 0; v < nv; ++v) m.idx[v] = (uint32_t)v; }
+            if (m.idx.size() % 3) fail("glTF: index count is not a multiple of 3");
+            for (uint32_t ix : m.idx) if (ix >= nv) fail("glTF: index out of range");
+            if (at.has("TANGENT")) {   // the importer takes the file's tangents: bitangent = cross(normal, tangent) * w
+                const std::vector<float> tan = L.floats((size_t)at.at("TANGENT").as_int(), 4);
+                if (tan.size() / 4 != nv) fail("glTF: attribute counts differ");
+                for (size_t v = 0; v < nv; ++v) {
+                    std::memcpy(m.v[v].tangent, &tan[v * 4], 12);
+                    float b[3];
+                    cross3(m.v[v].normal, m.v[v].tangent, b);
+                    for (int c = 0; c < 3; ++c) m.v[v].bitangent[c] = b[c] * tan[v * 4 + 3];
+                }
+            } else calc_tangents(m);
+            m.material = p.has("material") ? (uint64_t)p.at("material").as_int() : 0;
+            if (m.material >= g->materials.size()) fail("glTF: material index out of range");
+            g->meshes.push_back(std::move(m));
+        }
+        count_of_mesh.push_back(prims.size());
+    }
+
+    // objects (app.cpp:354-382): depth-first from the root with an explicit stack (children are visited last to first),
+    // every node matrix transposed by assimp_to_mat4 (app.cpp:540-564) and accumulated as parent * child
+    const size_t n_nodes = doc.has("nodes") ? doc.at("nodes").size() : 0;
+    std::vector<size_t> roots;
+    if (doc.has("scenes") && doc.at("scenes").size()) {
+        const size_t sc = doc.has("scene") ? (size_t)doc.at("scene").as_int() : 0;
+        const Json &s = doc.at("scenes")[sc];
+        if (s.has("nodes")) for (size_t i = 0; i < s.at("nodes").size(); ++i) roots.push_back((size_t)s.at("nodes")[i].as_int());
+    }
+    struct Item { long node; M4 parent; };   // node -1: the synthetic root assimp creates when the scene has several roots
+    std::vector<Item> stack;
+    if (roots.size() == 1) stack.push_back({(long)roots[0], identity()});
+    else if (!roots.empty()) stack.push_back({-1, identity()});
+    while (!stack.empty()) {
+        const Item it = stack.back();
+        stack.pop_back();
+        M4 trs;
+        std::vector<size_t> children;
+        long mesh = -1;
+        if (it.node < 0) { trs = mul(it.parent, identity()); children = roots; }
+        else {
+            if ((size_t)it.node >= n_nodes) fail("glTF: node index out of range");
+            const Json &n = doc.at("nodes")[(size_t)it.node];
+            trs = mul(it.parent, transpose(node_matrix(n)));
+            if (n.has("children")) for (size_t i = 0; i < n.at("children").size(); ++i) children.push_back((size_t)n.at("children")[i].as_int());
+            if (n.has("mesh")) mesh = (long)n.at("mesh").as_int();
+        }
+        for (size_t c : children) stack.push_back({(long)c, trs});
+        if (mesh >= 0) {
+            if ((size_t)mesh >= n_mesh) fail("glTF: mesh index out of range");
+            for (size_t k = 0; k < count_of_mesh[(size_t)mesh]; ++k) {
+                ArcticObject o;
+                std::memset(&o, 0, sizeof o);
+                std::memcpy(o.trs, trs.m, sizeof o.trs);
+                o.mesh_idx = first_of_mesh[(size_t)mesh] + k;
+                g->objects.push_back(o);
+            }
+        }
+        if (g->objects.size() > 10000000) fail("glTF: node graph too large (cycle?)");
+    }
+    return g;
+}
+
+void say(char *err, uint64_t err_len, const char *m) { if (err && err_len) std::snprintf(err, (size_t)err_len, "%s", m); }
+
+}  // namespace
+
+extern "C" {
+
+ArcticGltf *arctic_gltf_load(const char *path, char *err, uint64_t err_len) {
+    if (!path) { say(err, err_len, "arctic_gltf_load: null path"); return nullptr; }
+    try {
+        return load(path).release();
+    } catch (const std::exception &e) {
+        say(err, err_len, e.what());
+        return nullptr;
+    }
+}
+void arctic_gltf_free(ArcticGltf *g) { delete g; }
+uint64_t arctic_gltf_material_count(const ArcticGltf *g) { return g ? g->materials.size() : 0; }
+uint64_t arctic_gltf_mesh_count(const ArcticGltf *g) { return g ? g->meshes.size() : 0; }
+uint64_t arctic_gltf_object_count(const ArcticGltf *g) { return g ? g->objects.size() : 0; }
+
+int arctic_gltf_material_image(const ArcticGltf *g, uint64_t i, int k, const uint8_t **rgba, uint32_t *w, uint32_t *h) {
+    if (!g || i >= g->materials.size() || k < 0 || k > 2 || !rgba || !w || !h) return ARCTIC_E_INVALID;
+    const Image &im = g->materials[i].img[k];
+    *rgba = im.px.data(); *w = im.w; *h = im.h;
+    return ARCTIC_OK;
+}
+int arctic_gltf_mesh(const ArcticGltf *g, uint64_t i, const ArcticVertex **vertices, uint64_t *n_vertices, const uint32_t **indices,
+                     uint64_t *n_indices, uint64_t *material) {
+    if (!g || i >= g->meshes.size() || !vertices || !n_vertices || !indices || !n_indices || !material) return ARCTIC_E_INVALID;
+    const Mesh &m = g->meshes[i];
+    *vertices = m.v.data(); *n_vertices = m.v.size(); *indices = m.idx.data(); *n_indices = m.idx.size(); *material = m.material;
+    return ARCTIC_OK;
+}
+const ArcticObject *arctic_gltf_objects(const ArcticGltf *g) { return g && !g->objects.empty() ? g->objects.data() : nullptr; }
+
+int arctic_gltf_upload(const ArcticGltf *g, ArcticRenderer *r) {
+    if (!g || !r) return ARCTIC_E_INVALID;
+    for (const Material &m : g->materials) {
+        int rc = arctic_create_material(r, m.img[0].px.data(), m.img[0].w, m.img[0].h, m.img[1].px.data(), m.img[1].w, m.img[1].h,
+                                        m.img[2].px.data(), m.img[2].w, m.img[2].h);
+        if (rc < 0) return rc;
+    }
+    for (const Mesh &m : g->meshes) {
+        int rc = arctic_create_mesh(r, m.v.data(), m.v.size(), m.idx.data(), m.idx.size(), m.material);
+        if (rc < 0) return rc;
+    }
+    return ARCTIC_OK;
+}
+
+uint8_t *arctic_png_decode(const uint8_t *data, uint64_t size, uint32_t *w, uint32_t *h, char *err, uint64_t err_len) {
+    if (!data || !w || !h) { say(err, err_len, "arctic_png_decode: null argument"); return nullptr; }
+    try {
+        std::vector<uint8_t> px = decode_png(data, (size_t)size, *w, *h);
+        uint8_t *out = static_cast<uint8_t *>(std::malloc(px.size()));
+        if (!out) fail("out of memory");
+        std::memcpy(out, px.data(), px.size());
+        return out;
+    } catch (const std::exception &e) {
+        say(err, err_len, e.what());
+        return nullptr;
+    }
+}
+void arctic_png_free(uint8_t *p) { std::free(p); }
+
+}  // extern "C"

@@ -1,0 +1,289 @@
+"""The scene-loader stand-in (include/arctic_gltf.h) against glTF files this test writes itself: the real
+SciFiHelmet / FlightHelmet / Sponza assets and assimp are not available offline, so what is checked is the restated
+behaviour of App::load_scene (reference src/app.cpp:173-385, 540-564) -- parity with assimp's own output is unpinned."""
+import base64
+import json
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+
+def png_bytes(img, color_type=6, depth=8, palette=None, filters=(0, 1, 2, 3, 4)):
+    """minimal PNG writer (all five filter types in rotation) for (h, w, C) uint8/uint16 arrays."""
+    img = np.asarray(img)
+    h, w = img.shape[:2]
+    bpp = max(1, img.shape[2] * depth // 8) if img.ndim == 3 else max(1, depth // 8)
+    rows = []
+    prev = np.zeros(0, np.uint8)
+    for y in range(h):
+        if depth == 16:
+            line = img[y].astype(">u2").tobytes()
+        elif depth == 8:
+            line = img[y].astype(np.uint8).tobytes()
+        else:   # packed 1/2/4 bit samples, one channel
+            vals = img[y].reshape(-1).astype(np.uint8)
+            per = 8 // depth
+            vals = np.concatenate([vals, np.zeros((-len(vals)) % per, np.uint8)]).reshape(-1, per)
+            line = bytes(int(sum(int(v) << (8 - depth * (k + 1)) for k, v in enumerate(r))) for r in vals)
+        cur = np.frombuffer(line, np.uint8).astype(np.int32)
+        pr = prev.astype(np.int32) if len(prev) else np.zeros_like(cur)
+        a = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]]) if len(cur) > bpp else np.zeros_like(cur)
+        c = np.concatenate([np.zeros(bpp, np.int32), pr[:-bpp]]) if len(cur) > bpp else np.zeros_like(cur)
+        ft = filters[y % len(filters)]
+        if ft == 0: f = cur
+        elif ft == 1: f = cur - a
+        elif ft == 2: f = cur - pr
+        elif ft == 3: f = cur - ((a + pr) >> 1)
+        else:
+            pa, pb, pc = np.abs(pr - c), np.abs(a - c), np.abs(a + pr - 2 * c)
+            pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, pr, c))
+            f = cur - pred
+        rows.append(bytes([ft]) + (f & 255).astype(np.uint8).tobytes())
+        prev = cur.astype(np.uint8)
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+    raw = zlib.compress(b"".join(rows), 6)
+    mid = len(raw) // 2
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, color_type, 0, 0, 0))
+    if palette is not None:
+        out += chunk(b"PLTE", np.asarray(palette, np.uint8).tobytes())
+    return out + chunk(b"IDAT", raw[:mid]) + chunk(b"IDAT", raw[mid:]) + chunk(b"IEND", b"")   # two IDAT chunks on purpose
+
+
+@pytest.fixture(scope="module")
+def gltf(pkg):
+    from importlib import import_module
+    m = import_module("arctic_renderer_amd.gltf")
+    m.build()
+    return m
+
+
+def test_png_decoder(gltf):
+    rng = np.random.default_rng(3)
+    rgba = rng.integers(0, 256, (13, 17, 4), dtype=np.uint8)
+    np.testing.assert_array_equal(gltf.png_decode(png_bytes(rgba, 6)), rgba)
+    rgb = rng.integers(0, 256, (9, 31, 3), dtype=np.uint8)
+    out = gltf.png_decode(png_bytes(rgb, 2))
+    np.testing.assert_array_equal(out[..., :3], rgb); assert (out[..., 3] == 255).all()
+    grey = rng.integers(0, 256, (8, 8, 1), dtype=np.uint8)
+    out = gltf.png_decode(png_bytes(grey, 0))
+    np.testing.assert_array_equal(out[..., 0], grey[..., 0]); np.testing.assert_array_equal(out[..., 1], out[..., 2])
+    ga = rng.integers(0, 256, (5, 7, 2), dtype=np.uint8)
+    out = gltf.png_decode(png_bytes(ga, 4))
+    np.testing.assert_array_equal(out[..., 0], ga[..., 0]); np.testing.assert_array_equal(out[..., 3], ga[..., 1])
+    rgb16 = rng.integers(0, 65536, (6, 5, 3), dtype=np.uint16)
+    np.testing.assert_array_equal(gltf.png_decode(png_bytes(rgb16, 2, depth=16))[..., :3], (rgb16 >> 8).astype(np.uint8))   # stb keeps the high byte
+    pal = rng.integers(0, 256, (16, 3), dtype=np.uint8)
+    idx = rng.integers(0, 16, (7, 9, 1), dtype=np.uint8)
+    np.testing.assert_array_equal(gltf.png_decode(png_bytes(idx, 3, depth=4, palette=pal))[..., :3], pal[idx[..., 0]])
+    bits = rng.integers(0, 2, (5, 19, 1), dtype=np.uint8)
+    np.testing.assert_array_equal(gltf.png_decode(png_bytes(bits, 0, depth=1))[..., 0], bits[..., 0] * 255)
+    with pytest.raises(ValueError):
+        gltf.png_decode(b"\xff\xd8\xff\xe0 not a png")
+    for name, want in (("white.png", (255, 255, 255)), ("normal.png", (128, 128, 255))):   # the reference's fallback textures, when it is mounted
+        path = os.path.join("/root/reference/assets", name)
+        if os.path.exists(path):
+            img = gltf.png_decode(open(path, "rb").read())
+            assert (img[..., :3] == want).all() and img.shape[2] == 4
+
+
+def write_scene(tmp, embed=False):
+    rng = np.random.default_rng(11)
+    # mesh 0: two primitives (a quad with indices + TANGENT, a lone triangle without tangents, u16 / u8 indices); mesh 1: quad, no indices
+    quad_p = np.array([(-1, -1, 0), (1, -1, 0), (1, 1, 0), (-1, 1, 0)], np.float32)
+    quad_n = np.tile(np.float32([0, 0, 1]), (4, 1))
+    quad_uv = np.array([(0, 1), (1, 1), (1, 0), (0, 0)], np.float32)          # glTF convention: v down
+    quad_t = np.tile(np.float32([1, 0, 0, -1]), (4, 1))                       # handedness -1
+    quad_i = np.array([0, 1, 2, 0, 2, 3], np.uint16)
+    tri_p = np.array([(0, 0, 0), (2, 0, 0), (0, 0, -2)], np.float32)
+    tri_n = np.tile(np.float32([0, 1, 0]), (3, 1))
+    tri_uv = np.array([(0.25, 0.75), (0.75, 0.75), (0.25, 0.25)], np.float32)
+    tri_i = np.array([0, 1, 2], np.uint8)
+    soup_p = np.array([(0, 0, 0), (1, 0, 0), (0, 1, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0)], np.float32)
+    soup_n = np.tile(np.float32([0, 0, 1]), (6, 1))
+    soup_uv = soup_p[:, :2].copy()
+    blobs, views, accessors = [], [], []
+
+    def add(arr, type_, ctype, target=None, stride=None):
+        data = arr.tobytes()
+        if stride:   # interleave with padding to exercise byteStride
+            rec = arr.reshape(len(arr), -1)
+            data = b"".join(r.tobytes() + b"\0" * (stride - r.nbytes) for r in rec)
+        off = sum(len(b) for b in blobs)
+        pad = (-off) % 4
+        blobs.append(b"\0" * pad + data)
+        v = {"buffer": 0, "byteOffset": off + pad, "byteLength": len(data)}
+        if stride: v["byteStride"] = stride
+        views.append(v)
+        accessors.append({"bufferView": len(views) - 1, "componentType": ctype, "count": len(arr), "type": type_})
+        return len(accessors) - 1
+    a = {k: add(*v) for k, v in dict(qp=(quad_p, "VEC3", 5126, None, 16), qn=(quad_n, "VEC3", 5126), quv=(quad_uv, "VEC2", 5126), qt=(quad_t, "VEC4", 5126),
+                                     qi=(quad_i, "SCALAR", 5123), tp=(tri_p, "VEC3", 5126), tn=(tri_n, "VEC3", 5126), tuv=(tri_uv, "VEC2", 5126),
+                                     ti=(tri_i, "SCALAR", 5121), sp=(soup_p, "VEC3", 5126), sn=(soup_n, "VEC3", 5126), suv=(soup_uv, "VEC2", 5126)).items()}
+    binary = b"".join(blobs)
+    imgs = {"base.png": rng.integers(0, 256, (8, 8, 4), dtype=np.uint8), "nrm.png": rng.integers(0, 256, (4, 16, 3), dtype=np.uint8),
+            "mr.png": rng.integers(0, 256, (16, 4, 3), dtype=np.uint8)}
+    for name, im in imgs.items():
+        open(os.path.join(tmp, name), "wb").write(png_bytes(im, 6 if im.shape[2] == 4 else 2))
+    doc = {
+        "asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": [0, 3]}],
+        "nodes": [
+            {"name": "a", "children": [1, 2], "translation": [1.0, 2.0, 3.0]},
+            {"name": "b", "mesh": 0, "rotation": [0.0, 0.7071068, 0.0, 0.7071068], "scale": [2.0, 1.0, 0.5]},
+            {"name": "c", "mesh": 1, "matrix": [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, -4, 5, 6, 1]},
+            {"name": "d", "mesh": 1},
+        ],
+        "meshes": [
+            {"primitives": [{"attributes": {"POSITION": a["qp"], "NORMAL": a["qn"], "TEXCOORD_0": a["quv"], "TANGENT": a["qt"]}, "indices": a["qi"], "material": 0},
+                            {"attributes": {"POSITION": a["tp"], "NORMAL": a["tn"], "TEXCOORD_0": a["tuv"]}, "indices": a["ti"], "material": 1}]},
+            {"primitives": [{"attributes": {"POSITION": a["sp"], "NORMAL": a["sn"], "TEXCOORD_0": a["suv"]}, "material": 1}]},
+        ],
+        "materials": [
+            {"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}, "metallicRoughnessTexture": {"index": 2}}, "normalTexture": {"index": 1}},
+            {"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}}},     # normal + metal-rough fall back
+        ],
+        "textures": [{"source": 0}, {"source": 1}, {"source": 2}],
+        "images": [{"uri": "base.png"}, {"uri": "nrm.png"}, {"uri": "mr%2Epng"}],
+        "buffers": [{"byteLength": len(binary), "uri": "data:application/octet-stream;base64," + base64.b64encode(binary).decode() if embed else "scene.bin"}],
+        "bufferViews": views, "accessors": accessors,
+    }
+    if not embed:
+        open(os.path.join(tmp, "scene.bin"), "wb").write(binary)
+    path = os.path.join(tmp, "embedded.gltf" if embed else "scene.gltf")
+    json.dump(doc, open(path, "w"))
+    return path, imgs, dict(quad_p=quad_p, quad_uv=quad_uv, quad_i=quad_i, tri_p=tri_p, tri_uv=tri_uv, soup_p=soup_p)
+
+
+@pytest.mark.parametrize("embed", [False, True], ids=["external-bin", "base64"])
+def test_load_scene_conventions(gltf, tmp_path, embed):
+    path, imgs, geo = write_scene(str(tmp_path), embed)
+    sc = gltf.load(path)
+    # ---- materials: three RGBA8 images each, fallbacks for missing ones (app.cpp:195-294)
+    assert len(sc.materials) == 2
+    np.testing.assert_array_equal(sc.materials[0][0], imgs["base.png"])
+    np.testing.assert_array_equal(sc.materials[0][1][..., :3], imgs["nrm.png"]); assert (sc.materials[0][1][..., 3] == 255).all()
+    np.testing.assert_array_equal(sc.materials[0][2][..., :3], imgs["mr.png"])
+    assert (sc.materials[1][1][..., :3] == (128, 128, 255)).all() and (sc.materials[1][2] == 255).all()
+    # ---- meshes: one per primitive, FlipUVs, tangents (app.cpp:296-352)
+    assert [m[2] for m in sc.meshes] == [0, 1, 1] and [len(m[1]) for m in sc.meshes] == [6, 3, 6]
+    v, ix, _ = sc.meshes[0]
+    np.testing.assert_array_equal(v["position"], geo["quad_p"])
+    np.testing.assert_array_equal(v["tex_coords"], np.stack([geo["quad_uv"][:, 0], 1 - geo["quad_uv"][:, 1]], -1))
+    np.testing.assert_array_equal(ix, geo["quad_i"].astype(np.uint32))
+    np.testing.assert_array_equal(v["tangent"], np.tile(np.float32([1, 0, 0]), (4, 1)))
+    np.testing.assert_array_equal(v["bitangent"], np.tile(np.float32([0, -1, 0]), (4, 1)))     # cross(n, t) * w = (0,1,0) * -1
+    v, ix, _ = sc.meshes[1]   # no TANGENT: from the UV gradients of the FLIPPED uvs, orthonormal to the normal
+    uvf = np.stack([geo["tri_uv"][:, 0], 1 - geo["tri_uv"][:, 1]], -1)
+    np.testing.assert_array_equal(v["tex_coords"], uvf.astype(np.float32))
+    e1, e2 = geo["tri_p"][1] - geo["tri_p"][0], geo["tri_p"][2] - geo["tri_p"][0]
+    d1, d2 = uvf[1] - uvf[0], uvf[2] - uvf[0]
+    det = d1[0] * d2[1] - d2[0] * d1[1]
+    t_ref = (e1 * d2[1] - e2 * d1[1]) / det          # dP/du
+    b_ref = (e2 * d1[0] - e1 * d2[0]) / det          # dP/dv
+    for k in range(3):
+        assert abs(np.dot(v["tangent"][k], v["normal"][k])) < 1e-6 and abs(np.linalg.norm(v["tangent"][k]) - 1) < 1e-6
+        # assimp's dirCorrection flips BOTH vectors when the UV winding is mirrored: they are +-(dP/du, dP/dv) together
+        s = np.sign(np.dot(v["tangent"][k], t_ref))
+        np.testing.assert_allclose(v["tangent"][k], s * t_ref / np.linalg.norm(t_ref), atol=1e-6)
+        np.testing.assert_allclose(v["bitangent"][k], s * b_ref / np.linalg.norm(b_ref), atol=1e-6)
+    v, ix, _ = sc.meshes[2]   # no index accessor: 0..n-1
+    np.testing.assert_array_equal(ix, np.arange(6, dtype=np.uint32))
+    # ---- objects: stack order (children last-to-first), one per primitive, matrices through assimp_to_mat4 (transposed) as parent * child
+    def local(n):
+        if "matrix" in n:
+            return np.float32(n["matrix"]).reshape(4, 4).T          # math matrix from the column-major array
+        m = np.eye(4, dtype=np.float32)
+        x, y, z, w = np.float32(n.get("rotation", [0, 0, 0, 1]))
+        r = np.float32([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                        [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                        [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        m[:3, :3] = r * np.float32(n.get("scale", [1, 1, 1]))[None, :]
+        m[:3, 3] = np.float32(n.get("translation", [0, 0, 0]))
+        return m
+    nodes = json.load(open(path))["nodes"]
+    A, B, Cn = local(nodes[0]), local(nodes[1]), local(nodes[2])
+    # two scene roots -> synthetic identity root; pop order: d (pushed last), then a; a's children: c popped before b
+    want = [(np.eye(4, dtype=np.float32), 2), (A.T @ Cn.T, 2), (A.T @ B.T, 0), (A.T @ B.T, 1)]
+    assert len(sc.objects) == len(want)
+    for o, (m, mesh) in zip(sc.objects, want):
+        assert int(o["mesh_idx"]) == mesh
+        np.testing.assert_allclose(o["trs"].reshape(4, 4).T, m, atol=1e-6)      # trs is glm memory order (column-major)
+    # the quirk, spelled out: a pure translation ends up in the bottom ROW of the math matrix, not in its last column
+    assert np.allclose(sc.objects[1]["trs"].reshape(4, 4).T[3, :3], [1 - 4, 2 + 5, 3 + 6]) and np.allclose(sc.objects[1]["trs"].reshape(4, 4).T[:3, 3], 0)
+
+
+def test_errors(gltf, tmp_path):
+    with pytest.raises(ValueError, match="cannot open"):
+        gltf.load(str(tmp_path / "missing.gltf"))
+    p = tmp_path / "bad.gltf"
+    p.write_text("{ not json")
+    with pytest.raises(ValueError):
+        gltf.load(str(p))
+    p = tmp_path / "glb.gltf"
+    p.write_bytes(b"glTF\x02\x00\x00\x00")
+    with pytest.raises(ValueError, match="glb"):
+        gltf.load(str(p))
+    path, _, _ = write_scene(str(tmp_path))
+    doc = json.load(open(path))
+    doc["images"][0]["uri"] = "photo.jpg"
+    (tmp_path / "photo.jpg").write_bytes(b"\xff\xd8\xff\xe0" + b"\0" * 32)
+    json.dump(doc, open(path, "w"))
+    with pytest.raises(ValueError, match="PNG"):
+        gltf.load(path)
+
+
+def test_loaded_scene_renders_on_the_oracle(gltf, oracle, pkg, tmp_path):
+    """end to end on the CPU: the loader's output drives the Renderer surface like App::load_scene does."""
+    path, _, _ = write_scene(str(tmp_path))
+    sc = gltf.load(path)
+    o = sc.upload(oracle.Oracle(96, 64, 0, 16))
+    # identity transforms for the picture (the transposed translations of the test scene distort it, as in the reference)
+    objs = sc.objects.copy()
+    objs["trs"] = np.eye(4, dtype=np.float32).reshape(16)
+    desc = pkg.scene.SceneDesc(camera=dict(eye=(0.3, 0.4, 4.0), rotation=(0.0, -90.0), aspect=1.5, fov_y=60.0, z_near_far=(0.1, 100.0)),
+                               ambient=0.2, sun=dict(position=(2, 10, 6), rotation=(-55.0, -110.0), color=(8, 8, 8)), objects=objs)
+    img = o.render_frame(desc, (0, 2.2, 1.0))
+    assert (img[..., :3].sum(-1) > 0).mean() > 0.1
+
+
+@pytest.mark.gpu
+def test_loaded_scene_renders_on_the_gpu_like_on_the_oracle(gltf, oracle, hip, pkg, tmp_path):
+    """load_scene's replacement end to end: arctic_gltf_upload feeds the HIP renderer through the C-ABI; the frame matches
+    the oracle fed with the same loader output."""
+    import ctypes as C
+    path, _, _ = write_scene(str(tmp_path))
+    sc = gltf.load(path)
+    objs = sc.objects.copy()
+    objs["trs"] = np.eye(4, dtype=np.float32).reshape(16)
+    desc = pkg.scene.SceneDesc(camera=dict(eye=(0.3, 0.4, 4.0), rotation=(0.0, -90.0), aspect=1.5, fov_y=60.0, z_near_far=(0.1, 100.0)),
+                               ambient=0.2, sun=dict(position=(2, 10, 6), rotation=(-55.0, -110.0), color=(8, 8, 8)), objects=objs,
+                               point_lights=pkg.scene.make_lights([(0.5, 0.5, 2.0)], [(3.0, 2.0, 1.0)]))
+    o = sc.upload(oracle.Oracle(192, 128, 256, 16))
+    o.update_lights(desc.point_lights)
+    ref = o.render_frame(desc, (2, 2.2, 1.0))
+    r = hip.Renderer(192, 128, 256, 16)
+    L = gltf.lib()
+    err = C.create_string_buffer(256)
+    h = L.arctic_gltf_load(os.fsencode(path), err, 256)
+    assert h and L.arctic_gltf_upload(h, r.h) == 0            # the C entry point a C++ host would call
+    L.arctic_gltf_free(h)
+    r.update_lights(desc.point_lights)
+    img = r.render_frame(desc, (2, 2.2, 1.0))
+    d = np.abs(img.astype(np.int16) - ref.astype(np.int16))
+    assert d.max() <= 1 and (d != 0).mean() < 2e-3 and (img[..., :3].sum(-1) > 0).mean() > 0.1
+    r.close(); o.close()
+
+
+def test_library_exports_every_symbol_of_its_header(gltf):
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "include", "arctic_gltf.h")).read()
+    names = set(re.findall(r"\b(arctic_(?:gltf|png)_\w+)\s*\(", text))
+    assert len(names) >= 10
+    L = gltf.lib()
+    for n in names:
+        assert hasattr(L, n), n
