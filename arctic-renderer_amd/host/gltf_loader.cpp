@@ -297,6 +297,7 @@ struct Loader {
     const Json &doc;
     std::string base;
     std::vector<std::vector<uint8_t>> buffers;
+    std::vector<uint8_t> glb_bin;   // the BIN chunk of a .glb: buffer 0 when that buffer has no uri
     std::map<size_t, Image> image_cache;
 
     Loader(const Json &d, std::string b) : doc(d), base(std::move(b)) {}
@@ -306,8 +307,9 @@ struct Loader {
         if (buffers.size() < bufs.size()) buffers.resize(bufs.size());
         if (buffers[i].empty()) {
             const Json &b = bufs[i];
-            if (!b.has("uri")) fail("glTF: buffer without uri (.glb containers are not supported)");
-            buffers[i] = load_uri(b.at("uri").as_str(), base);
+            if (b.has("uri")) buffers[i] = load_uri(b.at("uri").as_str(), base);
+            else if (i == 0 && !glb_bin.empty()) buffers[i] = glb_bin;
+            else fail("glTF: buffer without uri");
             if (buffers[i].size() < (size_t)b.at("byteLength").as_int()) fail("glTF: buffer shorter than byteLength");
         }
         return buffers[i];
@@ -443,10 +445,26 @@ M4 node_matrix(const Json &n) {   // the node's local transform as glTF defines 
 }
 
 std::unique_ptr<ArcticGltf> load(const std::string &path) {
-    const std::vector<uint8_t> text = read_file(path);
-    if (text.size() >= 4 && !std::memcmp(text.data(), "glTF", 4)) fail("binary .glb containers are not supported: use the .gltf + .bin form");
-    const Json doc = JsonParser(std::string(text.begin(), text.end())).parse();
+    const std::vector<uint8_t> file = read_file(path);
+    std::string text(file.begin(), file.end());
+    std::vector<uint8_t> glb_bin;
+    if (file.size() >= 4 && !std::memcmp(file.data(), "glTF", 4)) {   // .glb: 12-byte header, then a JSON chunk and an optional BIN chunk
+        auto le32 = [&](size_t o) { uint32_t v; if (o + 4 > file.size()) fail("glb: truncated"); std::memcpy(&v, &file[o], 4); return v; };
+        if (le32(4) != 2) fail("glb: only container version 2 is supported");
+        size_t pos = 12;
+        bool have_json = false;
+        while (pos + 8 <= file.size()) {
+            const uint32_t len = le32(pos), type = le32(pos + 4);
+            if (pos + 8 + (size_t)len > file.size()) fail("glb: truncated chunk");
+            if (type == 0x4E4F534Au) { text.assign(file.begin() + (long)pos + 8, file.begin() + (long)(pos + 8 + len)); have_json = true; }
+            else if (type == 0x004E4942u && glb_bin.empty()) glb_bin.assign(file.begin() + (long)pos + 8, file.begin() + (long)(pos + 8 + len));
+            pos += 8 + (size_t)len + ((4 - len % 4) % 4);
+        }
+        if (!have_json) fail("glb: no JSON chunk");
+    }
+    const Json doc = JsonParser(text).parse();
     Loader L(doc, dir_of(path));
+    L.glb_bin = std::move(glb_bin);
     auto g = std::make_unique<ArcticGltf>();
 
     // materials (app.cpp:195-294): three images each, fallbacks for the missing ones

@@ -11,8 +11,9 @@
  *   - missing textures fall back to a white image / a flat normal map (assets/white.png, assets/normal.png);
  *   - node matrices go through assimp_to_mat4 (app.cpp:540-564), which feeds assimp's row-major elements to glm's
  *     column-major constructor, i.e. TRANSPOSES them, and are accumulated as parent * child in that transposed form.
- * Supported: .gltf (JSON) with external or base64 buffers, float attributes, u8/u16/u32 indices, PNG images (8/16 bit,
- * grey / RGB / palette / alpha, non-interlaced).  Not supported: .glb, JPEG (no decoder here), sparse accessors, Draco.
+ * Supported: .gltf (JSON) with external or base64 buffers and .glb containers, float / normalised-integer attributes,
+ * u8/u16/u32 indices, PNG images by uri or bufferView (1-16 bit, grey / RGB / palette / alpha, non-interlaced).
+ * Not supported: JPEG (no decoder here), sparse accessors, Draco.
  * Nothing here runs on the GPU; parity with assimp's output is unpinned (assimp is not available offline).
  */
 #ifndef ARCTIC_GLTF_H

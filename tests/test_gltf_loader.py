@@ -216,6 +216,33 @@ def test_load_scene_conventions(gltf, tmp_path, embed):
     assert np.allclose(sc.objects[1]["trs"].reshape(4, 4).T[3, :3], [1 - 4, 2 + 5, 3 + 6]) and np.allclose(sc.objects[1]["trs"].reshape(4, 4).T[:3, 3], 0)
 
 
+def test_glb_container(gltf, tmp_path):
+    """the binary container: JSON chunk + BIN chunk (buffer 0 without uri), images through bufferViews."""
+    path, imgs, geo = write_scene(str(tmp_path))
+    doc = json.load(open(path))
+    binary = open(os.path.join(str(tmp_path), "scene.bin"), "rb").read()
+    binary += b"\0" * ((-len(binary)) % 4)
+    for k, name in enumerate(("base.png", "nrm.png", "mr.png")):       # move the images into the BIN chunk
+        data = open(os.path.join(str(tmp_path), name), "rb").read()
+        doc["bufferViews"].append({"buffer": 0, "byteOffset": len(binary), "byteLength": len(data)})
+        doc["images"][k] = {"bufferView": len(doc["bufferViews"]) - 1, "mimeType": "image/png"}
+        binary += data + b"\0" * ((-len(data)) % 4)
+    doc["buffers"] = [{"byteLength": len(binary)}]
+    js = json.dumps(doc).encode()
+    js += b" " * ((-len(js)) % 4)
+    glb = tmp_path / "scene.glb"
+    glb.write_bytes(b"glTF" + struct.pack("<II", 2, 12 + 8 + len(js) + 8 + len(binary)) + struct.pack("<I", len(js)) + b"JSON" + js +
+                    struct.pack("<I", len(binary)) + b"BIN\0" + binary)
+    a, b = gltf.load(path), gltf.load(str(glb))
+    assert len(a.materials) == len(b.materials) and len(a.meshes) == len(b.meshes)
+    for ma, mb in zip(a.materials, b.materials):
+        for x, y in zip(ma, mb):
+            np.testing.assert_array_equal(x, y)
+    for (va, ia, ka), (vb, ib, kb) in zip(a.meshes, b.meshes):
+        assert va.tobytes() == vb.tobytes() and ia.tobytes() == ib.tobytes() and ka == kb
+    assert a.objects.tobytes() == b.objects.tobytes()
+
+
 def test_errors(gltf, tmp_path):
     with pytest.raises(ValueError, match="cannot open"):
         gltf.load(str(tmp_path / "missing.gltf"))
@@ -223,8 +250,8 @@ def test_errors(gltf, tmp_path):
     p.write_text("{ not json")
     with pytest.raises(ValueError):
         gltf.load(str(p))
-    p = tmp_path / "glb.gltf"
-    p.write_bytes(b"glTF\x02\x00\x00\x00")
+    p = tmp_path / "broken.glb"
+    p.write_bytes(b"glTF\x02\x00\x00\x00\x10\x00\x00\x00")
     with pytest.raises(ValueError, match="glb"):
         gltf.load(str(p))
     path, _, _ = write_scene(str(tmp_path))
