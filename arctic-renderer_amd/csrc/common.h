@@ -166,7 +166,7 @@ hipError_t launch_vertex(const ObjectRec *objs, const uint32_t *block_obj, const
                          uint32_t n_blocks, const GeomParams *gp, XVert *xv, int clip_only, hipStream_t s);
 hipError_t launch_setup(const ObjectRec *objs, const uint32_t *block_obj, const uint32_t *block_first, uint32_t n_blocks,
                         const GeomParams *gp, const XVert *xv, SetupRec *recs, uint32_t *rec_of /*8 per source triangle*/,
-                        uint2 *items, uint32_t item_cap, uint32_t *counters /*records, items, overflow: zeroed before*/, hipStream_t s);
+                        uint2 *items, uint32_t item_cap, uint32_t rec_cap, uint32_t *counters /*records, items, overflow: zeroed before*/, hipStream_t s);
 hipError_t launch_raster_vis(const SetupRec *recs, const uint2 *items, uint32_t item_cap, const uint32_t *counters, uint32_t grid_blocks,
                              const GeomParams *gp, unsigned long long *vis, hipStream_t s);
 hipError_t launch_raster_depth(const SetupRec *recs, const uint2 *items, uint32_t item_cap, const uint32_t *counters, uint32_t grid_blocks,

@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void k_setup(const ObjectRec *__restrict__ obj
                                                const uint32_t *__restrict__ block_first, const GeomParams *__restrict__ gpp,
                                                const XVert *__restrict__ xv, SetupRec *__restrict__ recs,
                                                uint32_t *__restrict__ rec_of, uint2 *__restrict__ items, uint32_t item_cap,
-                                               uint32_t *__restrict__ counters) {
+                                               uint32_t rec_cap, uint32_t *__restrict__ counters) {
     const uint32_t oi = block_obj[blockIdx.x];
     const ObjectRec &ob = objs[oi];
     const uint32_t ti = block_first[blockIdx.x] + threadIdx.x;
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void k_setup(const ObjectRec *__restrict__ obj
     for (int f = 1; __syncthreads_or(f + 1 < n); ++f) {
         SetupRec t;
         const bool has = (f + 1 < n) && setup_triangle(poly[0], poly[f], poly[f + 1], gp, t);
-        const uint32_t nb = has ? tiles_of(t) : 0u;
+        uint32_t nb = has ? tiles_of(t) : 0u;
         const unsigned long long m = __ballot(has);
         const uint32_t iincl = wave_inclusive_sum(nb, lane);
         const uint32_t itotal = __shfl(iincl, 63);
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void k_setup(const ObjectRec *__restrict__ obj
             const uint32_t ni = s_count[0][1] + s_count[1][1] + s_count[2][1] + s_count[3][1];
             s_base[0] = nr ? atomicAdd(&counters[0], nr) : 0u;
             s_base[1] = ni ? atomicAdd(&counters[1], ni) : 0u;
-            if (s_base[1] + ni > item_cap) counters[2] = 1;   // table full: reported by the host
+            if (s_base[1] + ni > item_cap || s_base[0] + nr > rec_cap) counters[2] = 1;   // a table is full: reported by the host
         }
         __syncthreads();
         uint32_t rbase = s_base[0], ibase = s_base[1];
@@ -264,8 +264,8 @@ __global__ __launch_bounds__(256) void k_setup(const ObjectRec *__restrict__ obj
         const uint32_t r = rbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
         if (has) {
             t.src_tri = src; t.object = oi; t.order_id = src * 8u + produced; t.pad = 0;
-            recs[r] = t;
-            rec_of[src * 8u + produced] = r;
+            if (r < rec_cap) { recs[r] = t; rec_of[src * 8u + produced] = r; }
+            else nb = 0;   // record table full (flagged above; k_raster then does nothing)
             ++produced;
         }
         // small records: the lane writes its own items; large ones (a wall across the screen is thousands of blocks): the
@@ -363,6 +363,7 @@ template <bool DEPTH_ONLY>
 __global__ __launch_bounds__(256) void k_raster(const SetupRec *__restrict__ recs, const uint2 *__restrict__ items, uint32_t item_cap,
                                                 const uint32_t *__restrict__ counters, const GeomParams *__restrict__ gpp,
                                                 unsigned long long *__restrict__ vis, uint32_t *__restrict__ depth_bits) {
+    if (counters[2]) return;   // a table overflowed in k_setup: entries are missing, the host reports the frame as dropped
     const uint32_t n_items = min(counters[1], item_cap);
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t stride = gridDim.x * 4;
@@ -481,9 +482,9 @@ hipError_t launch_vertex(const ObjectRec *objs, const uint32_t *block_obj, const
 
 hipError_t launch_setup(const ObjectRec *objs, const uint32_t *block_obj, const uint32_t *block_first, uint32_t n_blocks,
                         const GeomParams *gp, const XVert *xv, SetupRec *recs, uint32_t *rec_of, uint2 *items, uint32_t item_cap,
-                        uint32_t *counters, hipStream_t s) {
+                        uint32_t rec_cap, uint32_t *counters, hipStream_t s) {
     if (n_blocks == 0) return hipSuccess;
-    k_setup<<<n_blocks, 256, 0, s>>>(objs, block_obj, block_first, gp, xv, recs, rec_of, items, item_cap, counters);
+    k_setup<<<n_blocks, 256, 0, s>>>(objs, block_obj, block_first, gp, xv, recs, rec_of, items, item_cap, rec_cap, counters);
     return hipGetLastError();
 }
 

@@ -84,6 +84,7 @@ struct ArcticRenderer {
     PassTables tables[2];   // [0] forward pass, [1] shadow pass
     DevBuf d_xverts, d_recs, d_rec_of, d_items, d_geo_counters, d_stage;
     uint32_t item_cap = 0;          // entries of d_items (work-item table of the rasteriser)
+    bool recs_worst_case = false;   // record table at 7 per source triangle (after an overflow of the 2-per-triangle table)
     uint32_t item_cap_floor = 1u << 22;   // its smallest size (ARCTIC_OPT_ITEM_TABLE_FLOOR; tests shrink it to reach the overflow path)
     uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int keep_float = 0, count_evals = 0, culling = 1, debug = 0, hdr16 = 0;
@@ -270,7 +271,9 @@ int run_geometry(ArcticRenderer *r, const ArcticScene *sc, bool shadow_pass) {
     // count has to come back to the host -- the frame stays asynchronous.
     const uint64_t slots64 = 7ull * n_src;
     if (slots64 > 0x0FFFFFF0ull) return r->fail(ARCTIC_E_CAPACITY, "scene too large: %u triangles", n_src);
-    const uint32_t n_slots = (uint32_t)slots64;
+    // ... but 7 x 128 B per source triangle is a lot of memory for what only heavy clipping can produce: the table starts at
+    // 2 records per source triangle and goes to the worst case only after a frame has overflowed it (flagged like the item table)
+    const uint32_t n_slots = r->recs_worst_case ? (uint32_t)slots64 : (uint32_t)std::min<uint64_t>(slots64, 2ull * n_src + 4096);
     // work-item table: explicit (record, 16x16 block) pairs.  Its size follows the largest count seen so far (pinned
     // h_counts, refreshed asynchronously each pass) with 4x headroom; an overflow drops work, is flagged by the kernel and
     // reported by the next call that synchronises (arctic_flush / read-backs) -- and the table has grown by then.
@@ -285,7 +288,7 @@ int run_geometry(ArcticRenderer *r, const ArcticScene *sc, bool shadow_pass) {
     uint32_t *counters = r->d_geo_counters.as<uint32_t>() + (shadow_pass ? 4 : 0);
     HIPCHECK(r, hipMemsetAsync(counters, 0, 16, r->stream));
     HIPCHECK(r, launch_setup(objs, T.tblock_obj, T.tblock_first, n_tblocks, d_gp, r->d_xverts.as<XVert>(), r->d_recs.as<SetupRec>(),
-                             r->d_rec_of.as<uint32_t>(), r->d_items.as<uint2>(), r->item_cap, counters, r->stream));
+                             r->d_rec_of.as<uint32_t>(), r->d_items.as<uint2>(), r->item_cap, n_slots, counters, r->stream));
     // counts for arctic_stats() and the overflow flag: copied to pinned memory, looked at only when the stream has been synchronised
     HIPCHECK(r, hipMemcpyAsync(h, counters, 8, hipMemcpyDeviceToHost, r->stream));
     HIPCHECK(r, hipMemcpyAsync(r->h_counts + 4 + (shadow_pass ? 1 : 0), counters + 2, 4, hipMemcpyDeviceToHost, r->stream));
@@ -455,9 +458,10 @@ int check_item_overflow(ArcticRenderer *r) {
     if (!r->h_counts || !(r->h_counts[4] | r->h_counts[5])) return ARCTIC_OK;
     const uint32_t need = std::max(r->h_counts[1], r->h_counts[3]);
     r->h_counts[4] = r->h_counts[5] = 0;
+    r->recs_worst_case = true;   // whichever table it was: the record table takes its worst-case size from now on
     r->have_gbuffer = false; r->have_output = false; r->have_vis = false; r->shadow_key.clear();
-    return r->fail(ARCTIC_E_CAPACITY, "rasteriser work-item table overflowed (%u items needed, %u slots): the last frame is incomplete; "
-                   "the table grows on the next pass -- render the frame again", need, r->item_cap);
+    return r->fail(ARCTIC_E_CAPACITY, "a rasteriser table overflowed (%u work items needed, %u slots; or more than 2 records per source triangle): the last frame "
+                   "is incomplete; the tables grow on the next pass -- render the frame again", need, r->item_cap);
 }
 
 bool valid_scene(const ArcticScene *sc) { return sc && (sc->n_objects == 0 || sc->objects); }

@@ -174,3 +174,43 @@ def test_large_light_and_material_tables(pkg, oracle, hip, n_mat, n_lights):
         r.close()
     assert outs[0].max() > 0.2
     assert np.abs(outs[0] - outs[1]).max() <= TOL
+
+
+def test_record_table_overflow_is_reported_and_recovers(pkg, oracle, hip):
+    """the setup-record table starts at 2 records per source triangle; a scene whose triangles are nearly all clipped into
+    three (one vertex behind the camera, one beyond the far plane) overflows it: loud error, then the worst-case table."""
+    rng = np.random.default_rng(5)
+    n = 6000
+    pts = np.zeros((n, 3, 3), np.float32)
+    cx, cy = rng.uniform(-1.5, 1.5, n), rng.uniform(-1.0, 1.0, n)
+    pts[:, 0] = np.stack([cx - 0.2, cy - 0.2, np.full(n, 9.0)], -1)        # behind the eye (z = 4, looking down -z)
+    pts[:, 1] = np.stack([cx + 0.3, cy - 0.1, rng.uniform(-3, 1, n)], -1)  # inside the frustum
+    pts[:, 2] = np.stack([cx * 40, cy * 40 + 30, np.full(n, -400.0)], -1)  # beyond the far plane (z_far = 100)
+    v = tri_mesh(pkg, pts.reshape(-1, 3))
+    mats = [pkg.scenes.fallback_textures()]
+    desc = camera_scene(pkg, pkg.scene.make_objects([(np.eye(4, dtype=np.float32), 0)]), 160, 96)
+    # make every triangle face the camera: the orientation of a (clipped) triangle on screen is the sign of det[x y w] of its
+    # clip-space vertices; flip the index order where it differs, and let the oracle say which sign is "front"
+    pv = np.asarray(oracle.frame_constants(desc)[0], np.float64).reshape(4, 4).T          # math matrix from glm memory order
+    clip = np.concatenate([pts.astype(np.float64), np.ones((n, 3, 1))], -1) @ pv.T
+    sign = np.sign(np.linalg.det(clip[..., [0, 1, 3]]))
+    best = None
+    for front in (1.0, -1.0):
+        order = np.where((sign == front)[:, None], np.array([0, 1, 2])[None, :], np.array([0, 2, 1])[None, :])
+        idx = (np.arange(n)[:, None] * 3 + order).reshape(-1).astype(np.uint32)
+        o = oracle.Oracle(160, 96, 0, 16); o.create_material(*mats[0]); o.create_mesh(v, idx, 0)
+        ref = o.render_frame(desc, (0, 2.2, 1.0))
+        if best is None or int(o.stats()[0]) > best[0]:
+            best = (int(o.stats()[0]), idx, ref)
+        o.close()
+    n_recs, idx, ref = best
+    assert n_recs > 2 * n + 4096, f"the test scene does not overflow the record table ({n_recs} records)"
+    r = hip.Renderer(160, 96, 0, 16); r.create_material(*mats[0]); r.create_mesh(v, idx, 0)
+    with pytest.raises(hip.ArcticError) as e:
+        r.render_frame(desc, (0, 2.2, 1.0))
+    assert e.value.code == -5
+    img = r.render_frame(desc, (0, 2.2, 1.0))
+    assert int(r.stats()[0]) == n_recs
+    d = np.abs(img.astype(np.int16) - ref.astype(np.int16))
+    assert d.max() <= 1 and (d != 0).mean() < 2e-3 and (img[..., :3].sum(-1) > 0).mean() > 0.2
+    r.close()
