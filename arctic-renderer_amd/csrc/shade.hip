@@ -304,8 +304,9 @@ struct LightSums {
                   __builtin_fmaf(p.kdb.z * p.omF0.z, A2, __builtin_fmaf(p.F0.z, B2, p.omF0.z * C2)));
     }
 };
-__device__ __forceinline__ void accumulate_pair(const Pix &p, v2 dx, v2 dy, v2 dz, v2 nd, v2 cr, v2 cg, v2 cb, LightSums &S) {
-    const v2 inv = rsq2(fma2(dz, dz, fma2(dy, dy, dx * dx)));
+// d2 = |d|^2 is computed by the caller next to n.d: two independent dependency chains the scheduler can interleave
+__device__ __forceinline__ void accumulate_pair(const Pix &p, v2 dx, v2 dy, v2 dz, v2 d2, v2 nd, v2 cr, v2 cg, v2 cb, LightSums &S) {
+    const v2 inv = rsq2(d2);
     const v2 ndwi = max02(nd * inv);
     const v2 hx = fma2(dx, inv, splat(p.wo.x)), hy = fma2(dy, inv, splat(p.wo.y)), hz = fma2(dz, inv, splat(p.wo.z));
     const v2 hh = fma2(hz, hz, fma2(hy, hy, hx * hx)), rh = rsq2(hh);
@@ -675,13 +676,13 @@ __device__ __forceinline__ void light_pixel(const ShadeParams &sp, const float4 
         const float4 A1 = llights[6 * q + 3], B1 = llights[6 * q + 4], C1 = llights[6 * q + 5];
         const v2 dx0 = (v2){A0.x, A0.y} - wx, dy0 = (v2){A0.z, A0.w} - wy, dz0 = (v2){B0.x, B0.y} - wz;
         const v2 dx1 = (v2){A1.x, A1.y} - wx, dy1 = (v2){A1.z, A1.w} - wy, dz1 = (v2){B1.x, B1.y} - wz;
-        const v2 nd0 = fma2(splat(n.z), dz0, fma2(splat(n.y), dy0, splat(n.x) * dx0));
-        const v2 nd1 = fma2(splat(n.z), dz1, fma2(splat(n.y), dy1, splat(n.x) * dx1));
+        const v2 nd0 = fma2(splat(n.z), dz0, fma2(splat(n.y), dy0, splat(n.x) * dx0)), d20 = fma2(dz0, dz0, fma2(dy0, dy0, dx0 * dx0));
+        const v2 nd1 = fma2(splat(n.z), dz1, fma2(splat(n.y), dy1, splat(n.x) * dx1)), d21 = fma2(dz1, dz1, fma2(dy1, dy1, dx1 * dx1));
         // exact culling 2: n.wi <= 0 zeroes a light (forward.hlsl:191-192); skip the trip when that holds for all four
         // lights in every lane of the wave
         if (sp.culling && __ballot(nd0.x > 0.0f || nd0.y > 0.0f || nd1.x > 0.0f || nd1.y > 0.0f) == 0ull) continue;
-        accumulate_pair(px, dx0, dy0, dz0, nd0, (v2){B0.z, B0.w}, (v2){C0.x, C0.y}, (v2){C0.z, C0.w}, S);
-        accumulate_pair(px, dx1, dy1, dz1, nd1, (v2){B1.z, B1.w}, (v2){C1.x, C1.y}, (v2){C1.z, C1.w}, S);
+        accumulate_pair(px, dx0, dy0, dz0, d20, nd0, (v2){B0.z, B0.w}, (v2){C0.x, C0.y}, (v2){C0.z, C0.w}, S);
+        accumulate_pair(px, dx1, dy1, dz1, d21, nd1, (v2){B1.z, B1.w}, (v2){C1.x, C1.y}, (v2){C1.z, C1.w}, S);
         if (sp.light_evals) {
             const unsigned long long active = __ballot(1);
             const uint32_t k = min(4u, sp.n_lights - 4 * q);
@@ -692,9 +693,14 @@ __device__ __forceinline__ void light_pixel(const ShadeParams &sp, const float4 
     for (uint32_t p = 0; p < n_pairs; ++p) {
         const float4 A = llights[3 * p], Bq = llights[3 * p + 1], C = llights[3 * p + 2];
         const v2 dx = (v2){A.x, A.y} - wx, dy = (v2){A.z, A.w} - wy, dz = (v2){Bq.x, Bq.y} - wz;
-        const v2 nd = fma2(splat(n.z), dz, fma2(splat(n.y), dy, splat(n.x) * dx));
+        // n.d and |d|^2 interleaved by hand: a v_pk_fma that consumes the previous one's result costs a wait state
+        const v2 t0 = splat(n.x) * dx, u0 = dx * dx;
+        const v2 t1 = fma2(splat(n.y), dy, t0), u1 = fma2(dy, dy, u0);
+        const v2 nd = fma2(splat(n.z), dz, t1);
+        v2 d2 = fma2(dz, dz, u1);
+        asm volatile("" : "+v"(d2));   // keep |d|^2 up here (the compiler would sink it below the branch, back into one serial chain)
         if (sp.culling && __ballot(nd.x > 0.0f || nd.y > 0.0f) == 0ull) continue;
-        accumulate_pair(px, dx, dy, dz, nd, (v2){Bq.z, Bq.w}, (v2){C.x, C.y}, (v2){C.z, C.w}, S);
+        accumulate_pair(px, dx, dy, dz, d2, nd, (v2){Bq.z, Bq.w}, (v2){C.x, C.y}, (v2){C.z, C.w}, S);
         if (sp.light_evals) {
             const unsigned long long active = __ballot(1);
             const uint32_t k = min(2u, sp.n_lights > 2 * p ? sp.n_lights - 2 * p : 0u);
