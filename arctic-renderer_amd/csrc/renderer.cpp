@@ -9,6 +9,8 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <dlfcn.h>
+
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -20,6 +22,35 @@
 using namespace arctic;
 
 namespace {
+
+// Optional profiler ranges named like the reference's Tracy zones ("Shadow Map Pass", "Forward Pass": shadow_map_pass.cpp:116,
+// forward_pass.cpp:164): roctx is loaded at run time only when ARCTIC_OPT_MARKERS is set, so the library has no link-time
+// dependency on it.  Host-side ranges around the enqueue of each pass (rocprofv3 --marker-trace shows them).
+struct Markers {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    bool tried = false, on = false;
+    void enable(bool want) {
+        on = want;
+        if (want && !tried) {
+            tried = true;
+            void *h = dlopen("libroctx64.so", RTLD_NOW | RTLD_LOCAL);
+            if (!h) h = dlopen("/opt/rocm/lib/libroctx64.so", RTLD_NOW | RTLD_LOCAL);
+            if (h) {
+                push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+                pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+            }
+        }
+    }
+    bool available() const { return push && pop; }
+};
+Markers g_markers;
+struct Range {
+    bool live;
+    explicit Range(const char *name) : live(g_markers.on && g_markers.available()) { if (live) g_markers.push(name); }
+    ~Range() { if (live) g_markers.pop(); }
+};
+
 
 struct DevBuf {
     void *p = nullptr;
@@ -303,6 +334,7 @@ int run_geometry(ArcticRenderer *r, const ArcticScene *sc, bool shadow_pass) {
 
 int pass_shadow_map(ArcticRenderer *r, const ArcticScene *sc) {
     if (r->shadow_size == 0) return ARCTIC_OK;
+    Range zone("Shadow Map Pass");
     size_t n = (size_t)r->shadow_size * r->shadow_size;
     HIPCHECK(r, launch_fill_u32(r->d_shadow.as<uint32_t>(), 0x3F800000u, n, r->stream));   // clear to 1.0 (shadow_map_pass.cpp:124-131)
     return run_geometry(r, sc, true);
@@ -310,6 +342,7 @@ int pass_shadow_map(ArcticRenderer *r, const ArcticScene *sc) {
 
 // visibility only: vertex -> setup -> raster of the camera view
 int pass_visibility(ArcticRenderer *r, const ArcticScene *sc) {
+    Range zone("Forward Pass: visibility");
     HIPCHECK(r, launch_fill_u64(r->d_vis.as<unsigned long long>(), ~0ull, r->n_tiles() * TILE_PIXELS, r->stream));
     r->have_gbuffer = false;
     int rc = run_geometry(r, sc, false);
@@ -320,6 +353,7 @@ int pass_visibility(ArcticRenderer *r, const ArcticScene *sc) {
 
 // visibility -> the 76 B/pixel G-buffer.  Valid while the records of the forward pass are still in place.
 int resolve_gbuffer(ArcticRenderer *r) {
+    Range zone("Forward Pass: G-buffer");
     if (!r->have_vis || r->geo_owner != 1)
         return r->fail(ARCTIC_E_STATE, "no G-buffer: the frame was shaded from the visibility plane and a later pass has replaced its records (run arctic_pass_gbuffer)");
     HIPCHECK(r, launch_resolve(r->d_vis.as<unsigned long long>(), r->d_recs.as<SetupRec>(), r->d_rec_of.as<uint32_t>(), r->tables[0].objs,
@@ -416,6 +450,7 @@ hipError_t shade_once(ArcticRenderer *r, ShadeParams &sp, const ShadeLaunch &L) 
 }
 
 int pass_shade(ArcticRenderer *r, const ArcticScene *sc, const ArcticSettings *st, void *d_out, bool from_vis = false) {
+    Range zone("Forward Pass: shading + Skybox Pass + Post Process Pass");
     ShadeParams sp;
     int rc = fill_shade_params(r, sc, st, d_out, sp, from_vis);
     if (rc != ARCTIC_OK) return rc;
@@ -929,6 +964,10 @@ int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value) {
         break;
     case ARCTIC_OPT_HDR16: r->hdr16 = value != 0; break;
     case ARCTIC_OPT_VISBUFFER: r->visbuffer = value != 0; break;
+    case ARCTIC_OPT_MARKERS:
+        g_markers.enable(value != 0);
+        if (value && !g_markers.available()) return r->fail(ARCTIC_E_STATE, "set_option: libroctx64.so could not be loaded");
+        break;
     case ARCTIC_OPT_LIGHT_PATH:
         if (value < 0 || value > 3) return r->fail(ARCTIC_E_INVALID, "set_option: light path must be 0..3");
         r->light_path = (int)value;

@@ -275,6 +275,7 @@ int arctic_stats(ArcticRenderer *r, uint64_t *out, uint32_t n);
 #define ARCTIC_OPT_LIGHT_PATH       12 /* how the lit pixels reach the light loop: 0 = automatic (default: inline, scalar loop up to 16 point lights, packed
                                           pairs above), 1 = k_material -> lit-pixel stream -> k_light, 2 = inline scalar, 3 = inline packed.
                                           Same formulas (images agree to fp32 rounding, ~1e-7). */
+#define ARCTIC_OPT_MARKERS          13 /* 1 = roctx ranges around each pass, named like the reference's Tracy zones (process-wide; libroctx64 is loaded on demand) */
 #define ARCTIC_OPT_BANDS             5 /* 1..16 interleaved screen bands the two shading kernels are pipelined over (default 1: no gain measured) */
 int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value);
 

@@ -214,3 +214,15 @@ def test_record_table_overflow_is_reported_and_recovers(pkg, oracle, hip):
     d = np.abs(img.astype(np.int16) - ref.astype(np.int16))
     assert d.max() <= 1 and (d != 0).mean() < 2e-3 and (img[..., :3].sum(-1) > 0).mean() > 0.2
     r.close()
+
+
+def test_profiler_markers_option(pkg, hip):
+    """ARCTIC_OPT_MARKERS: roctx ranges named like the reference's Tracy zones; rendering is unchanged."""
+    sc = pkg.scenes.config2(scale=0.1)
+    r = sc.upload(hip.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights))
+    a = r.render_frame(sc.desc, sc.settings)
+    r.set_option("markers", 1)
+    b = r.render_frame(sc.desc, sc.settings)
+    r.set_option("markers", 0)
+    np.testing.assert_array_equal(a, b)
+    r.close()
