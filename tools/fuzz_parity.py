@@ -58,10 +58,25 @@ for case in range(n_cases):
     mism = float((orgba != hrgba).mean())
     cov = float((og[1] != 0xFFFFFFFF).mean())
     ok = sm_ok and gb_ok and err <= 1e-4 and ill_ok and np.abs(orgba.astype(int) - hrgba.astype(int)).max() <= 1 and np.array_equal(img, hrgba)
+    shard_note = ""
+    if ok and case % 3 == 0:   # a random interleaved shard of the same frame must reproduce its rows byte for byte
+        from importlib import import_module
+        sh = import_module("arctic_renderer_amd.sharding")
+        world, band = int(rng.integers(2, 6)), int(rng.choice([8, 16]))
+        k = int(rng.integers(0, world))
+        rows = sh.owned_rows(sc.height, k, world, band)
+        if len(rows):
+            rs = sc.upload(pkg.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights, band_rows=band, shard=(k, world)))
+            if env is not None:
+                rs.create_hdri(env)
+            same = bool(np.array_equal(rs.render_frame(desc, settings), img[rows]))
+            rs.close()
+            ok = ok and same
+            shard_note = f", shard {k}/{world} band {band} {'==' if same else '!='}"
     bad += not ok
     worst["ldr"], worst["rgba"] = max(worst["ldr"], err), max(worst["rgba"], mism)
     print(f"case {case:2d} config {cfg} {sc.width}x{sc.height} tm {settings[0]} sky {env is not None} coverage {cov:.2f}: shadow map {'==' if sm_ok else '!='}, "
-          f"G-buffer {'==' if gb_ok else '!='}, max |ldr err| {err:.2e}, fp32-ill-conditioned pixels {n_ill} (HIP max {worst_ill:.1e}), rgba8 mismatch {mism:.1e} -> {'ok' if ok else 'FAIL'}", flush=True)
+          f"G-buffer {'==' if gb_ok else '!='}, max |ldr err| {err:.2e}, fp32-ill-conditioned pixels {n_ill} (HIP max {worst_ill:.1e}), rgba8 mismatch {mism:.1e}{shard_note} -> {'ok' if ok else 'FAIL'}", flush=True)
     if only >= 0:
         ys, xs = np.nonzero(e_hip > 2e-5)
         print("pixels above 2e-5:", len(ys))
