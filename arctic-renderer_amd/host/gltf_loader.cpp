@@ -8,6 +8,7 @@
 // glTF files the test-suite writes itself (tests/test_gltf_loader.py); parity with assimp's output is unpinned.
 #include <zlib.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -142,7 +143,7 @@ int paeth(int a, int b, int c) {
 // RGBA8 like stbi_load(path, &w, &h, nullptr, 4): grey is replicated, missing alpha is 255, 16-bit keeps the high byte
 std::vector<uint8_t> decode_png(const uint8_t *data, size_t size, uint32_t &w, uint32_t &h) {
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
-    if (size < 8 || std::memcmp(data, sig, 8)) fail("not a PNG file (JPEG and other formats are not supported: convert to PNG)");
+    if (size < 8 || std::memcmp(data, sig, 8)) fail("not a PNG or baseline JPEG file");
     size_t pos = 8;
     uint32_t depth = 0, ctype = 0, interlace = 0;
     std::vector<uint8_t> idat, plte, trns;
@@ -216,6 +217,200 @@ std::vector<uint8_t> decode_png(const uint8_t *data, size_t size, uint32_t &w, u
         prev.swap(line);
     }
     return out;
+}
+
+// ------------------------------------------------------------------------------------------------- JPEG (baseline)
+// Baseline sequential DCT, Huffman, 8-bit, 1 or 3 components, any sampling factors up to 2x2, restart intervals -- what the
+// Khronos sample assets use.  Float IDCT, chroma upsampled by pixel replication, JFIF YCbCr -> RGB: stb_image (which the
+// reference uses) has its own integer IDCT and a smoothing upsampler, so results can differ from it by an LSB or two.
+struct JpegBits {
+    const uint8_t *p, *end;
+    uint32_t acc = 0;
+    int n = 0;
+    bool hit_marker = false;
+    void fill() {
+        while (n <= 24) {
+            int b = 0;
+            if (!hit_marker && p < end) {
+                b = *p++;
+                if (b == 0xFF) {
+                    const int c = p < end ? *p : 0xD9;
+                    if (c == 0) ++p;                      // stuffed zero
+                    else { hit_marker = true; --p; b = 0; }   // a marker: feed zeros until the caller deals with it
+                }
+            }
+            acc |= (uint32_t)b << (24 - n);
+            n += 8;
+        }
+    }
+    int bits(int k) {
+        if (k == 0) return 0;
+        if (n < k) fill();
+        const int v = (int)(acc >> (32 - k));
+        acc <<= k; n -= k;
+        return v;
+    }
+    void reset() { acc = 0; n = 0; hit_marker = false; }
+};
+struct JpegHuff {
+    uint8_t count[17] = {0}, symbol[256] = {0};
+    int mincode[17] = {0}, maxcode[18] = {0}, valptr[17] = {0};
+    void build() {
+        int code = 0, k = 0;
+        for (int len = 1; len <= 16; ++len) {
+            valptr[len] = k; mincode[len] = code;
+            code += count[len]; k += count[len];
+            maxcode[len] = count[len] ? code - 1 : -1;
+            code <<= 1;
+        }
+    }
+    int decode(JpegBits &br) const {
+        int code = 0;
+        for (int len = 1; len <= 16; ++len) {
+            code = (code << 1) | br.bits(1);
+            if (maxcode[len] >= 0 && code <= maxcode[len] && code >= mincode[len]) return symbol[valptr[len] + code - mincode[len]];
+        }
+        fail("JPEG: bad Huffman code");
+    }
+};
+inline int jpeg_extend(int v, int t) { return t == 0 ? 0 : (v < (1 << (t - 1)) ? v - (1 << t) + 1 : v); }
+
+std::vector<uint8_t> decode_jpeg(const uint8_t *data, size_t size, uint32_t &w, uint32_t &h) {
+    static const uint8_t zz[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                                   35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+    if (size < 4 || data[0] != 0xFF || data[1] != 0xD8) fail("not a JPEG file");
+    uint16_t qt[4][64] = {};
+    JpegHuff dc[4], ac[4];
+    struct Comp { int id = 0, hs = 1, vs = 1, tq = 0, td = 0, ta = 0, pred = 0, bw = 0, bh = 0; std::vector<uint8_t> plane; } comp[3];
+    int ncomp = 0, restart = 0, hmax = 1, vmax = 1;
+    bool have_sof = false;
+    size_t pos = 2;
+    auto be16 = [&](size_t o) { if (o + 2 > size) fail("JPEG: truncated"); return (int)((data[o] << 8) | data[o + 1]); };
+    for (;;) {
+        if (pos + 4 > size) fail("JPEG: no scan found");
+        if (data[pos] != 0xFF) { ++pos; continue; }
+        const int m = data[pos + 1];
+        if (m == 0xFF) { ++pos; continue; }
+        pos += 2;
+        if (m == 0xD8 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) continue;
+        const int len = be16(pos);
+        if (len < 2 || pos + (size_t)len > size) fail("JPEG: bad segment length");
+        const uint8_t *seg = data + pos + 2;
+        const int n = len - 2;
+        if (m == 0xDB) {   // DQT
+            for (int o = 0; o < n;) {
+                const int pq = seg[o] >> 4, tq = seg[o] & 15; ++o;
+                if (tq > 3) fail("JPEG: bad quantisation table id");
+                for (int i = 0; i < 64; ++i) { qt[tq][zz[i]] = pq ? (uint16_t)((seg[o] << 8) | seg[o + 1]) : seg[o]; o += pq ? 2 : 1; }
+            }
+        } else if (m == 0xC4) {   // DHT
+            for (int o = 0; o < n;) {
+                const int tc = seg[o] >> 4, th = seg[o] & 15; ++o;
+                if (th > 3) fail("JPEG: bad Huffman table id");
+                JpegHuff &t = tc ? ac[th] : dc[th];
+                int total = 0;
+                for (int i = 1; i <= 16; ++i) { t.count[i] = seg[o++]; total += t.count[i]; }
+                if (total > 256 || o + total > n) fail("JPEG: bad Huffman table");
+                std::memcpy(t.symbol, seg + o, (size_t)total); o += total;
+                t.build();
+            }
+        } else if (m == 0xC0 || m == 0xC1) {   // SOF0 / SOF1 (sequential Huffman)
+            if (seg[0] != 8) fail("JPEG: only 8-bit precision is supported");
+            h = (uint32_t)((seg[1] << 8) | seg[2]); w = (uint32_t)((seg[3] << 8) | seg[4]); ncomp = seg[5];
+            if ((ncomp != 1 && ncomp != 3) || !w || !h) fail("JPEG: unsupported component count or size");
+            for (int c = 0; c < ncomp; ++c) {
+                comp[c].id = seg[6 + c * 3]; comp[c].hs = seg[7 + c * 3] >> 4; comp[c].vs = seg[7 + c * 3] & 15; comp[c].tq = seg[8 + c * 3];
+                if (comp[c].hs < 1 || comp[c].hs > 2 || comp[c].vs < 1 || comp[c].vs > 2 || comp[c].tq > 3) fail("JPEG: unsupported sampling factors");
+                hmax = std::max(hmax, comp[c].hs); vmax = std::max(vmax, comp[c].vs);
+            }
+            have_sof = true;
+        } else if (m == 0xC2) fail("JPEG: progressive files are not supported (re-save as baseline or PNG)");
+        else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) fail("JPEG: unsupported coding process");
+        else if (m == 0xDD) restart = (seg[0] << 8) | seg[1];
+        else if (m == 0xDA) {   // SOS: the one interleaved scan of a baseline file
+            if (!have_sof) fail("JPEG: scan before frame header");
+            if (seg[0] != ncomp) fail("JPEG: non-interleaved scans are not supported");
+            for (int i = 0; i < ncomp; ++i) {
+                const int id = seg[1 + i * 2];
+                int c = 0;
+                while (c < ncomp && comp[c].id != id) ++c;
+                if (c == ncomp) fail("JPEG: scan refers to an unknown component");
+                comp[c].td = seg[2 + i * 2] >> 4; comp[c].ta = seg[2 + i * 2] & 15;
+            }
+            pos += (size_t)len;
+            break;
+        }
+        pos += (size_t)len;
+    }
+    const int mcux = (int)((w + 8u * hmax - 1) / (8u * hmax)), mcuy = (int)((h + 8u * vmax - 1) / (8u * vmax));
+    for (int c = 0; c < ncomp; ++c) {
+        comp[c].bw = mcux * comp[c].hs * 8; comp[c].bh = mcuy * comp[c].vs * 8;
+        comp[c].plane.assign((size_t)comp[c].bw * comp[c].bh, 0);
+    }
+    // cos table of the 8-point IDCT
+    float ct[8][8];
+    for (int x = 0; x < 8; ++x) for (int u = 0; u < 8; ++u) ct[x][u] = (u ? 1.0f : 0.70710678f) * 0.5f * std::cos((2 * x + 1) * u * 3.14159265358979f / 16.0f);
+    JpegBits br{data + pos, data + size};
+    int until_restart = restart;
+    for (int my = 0; my < mcuy; ++my)
+        for (int mx = 0; mx < mcux; ++mx) {
+            if (restart && until_restart == 0) {   // RSTn: byte-align, skip the marker, reset the predictors
+                const uint8_t *q = br.p;
+                while (q + 1 < br.end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) ++q;
+                br.p = q + 2 <= br.end ? q + 2 : br.end;
+                br.reset();
+                for (int c = 0; c < ncomp; ++c) comp[c].pred = 0;
+                until_restart = restart;
+            }
+            for (int c = 0; c < ncomp; ++c)
+                for (int by = 0; by < comp[c].vs; ++by)
+                    for (int bx = 0; bx < comp[c].hs; ++bx) {
+                        float blk[64] = {0};
+                        const int t = dc[comp[c].td].decode(br);
+                        comp[c].pred += jpeg_extend(br.bits(t), t);
+                        blk[0] = (float)(comp[c].pred * qt[comp[c].tq][0]);
+                        for (int k = 1; k < 64;) {
+                            const int rs = ac[comp[c].ta].decode(br), r = rs >> 4, sz = rs & 15;
+                            if (sz == 0) { if (r == 15) { k += 16; continue; } break; }
+                            k += r;
+                            if (k > 63) fail("JPEG: coefficient index out of range");
+                            blk[zz[k]] = (float)(jpeg_extend(br.bits(sz), sz) * qt[comp[c].tq][zz[k]]);
+                            ++k;
+                        }
+                        float tmp[64];
+                        for (int y = 0; y < 8; ++y)
+                            for (int x = 0; x < 8; ++x) { float a = 0; for (int u = 0; u < 8; ++u) a += ct[x][u] * blk[y * 8 + u]; tmp[y * 8 + x] = a; }
+                        uint8_t *dst = &comp[c].plane[(size_t)((my * comp[c].vs + by) * 8) * comp[c].bw + (size_t)(mx * comp[c].hs + bx) * 8];
+                        for (int x = 0; x < 8; ++x)
+                            for (int y = 0; y < 8; ++y) {
+                                float a = 0;
+                                for (int v = 0; v < 8; ++v) a += ct[y][v] * tmp[v * 8 + x];
+                                const int px = (int)std::lrint(a + 128.0f);
+                                dst[(size_t)y * comp[c].bw + x] = (uint8_t)(px < 0 ? 0 : px > 255 ? 255 : px);
+                            }
+                    }
+            if (restart) --until_restart;
+        }
+    std::vector<uint8_t> out((size_t)w * h * 4);
+    for (uint32_t y = 0; y < h; ++y)
+        for (uint32_t x = 0; x < w; ++x) {
+            auto at = [&](int c) { return (int)comp[c].plane[(size_t)(y * comp[c].vs / vmax) * comp[c].bw + x * comp[c].hs / hmax]; };
+            uint8_t *o = &out[((size_t)y * w + x) * 4];
+            if (ncomp == 1) { o[0] = o[1] = o[2] = (uint8_t)at(0); }
+            else {
+                const float Y = (float)at(0), cb = (float)at(1) - 128.0f, cr = (float)at(2) - 128.0f;
+                const float rgb[3] = {Y + 1.402f * cr, Y - 0.344136f * cb - 0.714136f * cr, Y + 1.772f * cb};
+                for (int k = 0; k < 3; ++k) { const int v = (int)std::lrint(rgb[k]); o[k] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); }
+            }
+            o[3] = 255;
+        }
+    return out;
+}
+
+// either format, by signature (stbi_load does the same)
+std::vector<uint8_t> decode_image(const uint8_t *data, size_t size, uint32_t &w, uint32_t &h) {
+    if (size >= 2 && data[0] == 0xFF && data[1] == 0xD8) return decode_jpeg(data, size, w, h);
+    return decode_png(data, size, w, h);
 }
 
 // ------------------------------------------------------------------------------------------------- files, base64
@@ -384,7 +579,7 @@ struct Loader {
             file.assign(buf.begin() + (long)off, buf.begin() + (long)(off + len));
         } else fail("glTF: image without uri or bufferView");
         Image out;
-        out.px = decode_png(file.data(), file.size(), out.w, out.h);
+        out.px = decode_image(file.data(), file.size(), out.w, out.h);
         return image_cache.emplace(src, std::move(out)).first->second;
     }
 };
@@ -629,7 +824,7 @@ int arctic_gltf_upload(const ArcticGltf *g, ArcticRenderer *r) {
 uint8_t *arctic_png_decode(const uint8_t *data, uint64_t size, uint32_t *w, uint32_t *h, char *err, uint64_t err_len) {
     if (!data || !w || !h) { say(err, err_len, "arctic_png_decode: null argument"); return nullptr; }
     try {
-        std::vector<uint8_t> px = decode_png(data, (size_t)size, *w, *h);
+        std::vector<uint8_t> px = decode_image(data, (size_t)size, *w, *h);   // PNG or baseline JPEG, by signature
         uint8_t *out = static_cast<uint8_t *>(std::malloc(px.size()));
         if (!out) fail("out of memory");
         std::memcpy(out, px.data(), px.size());

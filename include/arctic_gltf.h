@@ -12,8 +12,9 @@
  *   - node matrices go through assimp_to_mat4 (app.cpp:540-564), which feeds assimp's row-major elements to glm's
  *     column-major constructor, i.e. TRANSPOSES them, and are accumulated as parent * child in that transposed form.
  * Supported: .gltf (JSON) with external or base64 buffers and .glb containers, float / normalised-integer attributes,
- * u8/u16/u32 indices, PNG images by uri or bufferView (1-16 bit, grey / RGB / palette / alpha, non-interlaced).
- * Not supported: JPEG (no decoder here), sparse accessors, Draco.
+ * u8/u16/u32 indices, images by uri or bufferView: PNG (1-16 bit, grey / RGB / palette / alpha, non-interlaced) and
+ * baseline JPEG (8 bit, 1 or 3 components, sampling up to 2x2, restart intervals; float IDCT and replicated chroma, so an
+ * LSB or two away from stb_image's integer pipeline).  Not supported: progressive JPEG, sparse accessors, Draco.
  * Nothing here runs on the GPU; parity with assimp's output is unpinned (assimp is not available offline).
  */
 #ifndef ARCTIC_GLTF_H
@@ -43,7 +44,7 @@ const ArcticObject *arctic_gltf_objects(const ArcticGltf *g);
 /* convenience: create_material / create_mesh for everything in the file, in order (what load_scene does). */
 int arctic_gltf_upload(const ArcticGltf *g, ArcticRenderer *r);
 
-/* the PNG decoder alone (tests): returns a malloc'ed RGBA8 image, NULL on failure */
+/* the image decoders alone (tests): PNG or baseline JPEG by signature; returns a malloc'ed RGBA8 image, NULL on failure */
 uint8_t *arctic_png_decode(const uint8_t *data, uint64_t size, uint32_t *w, uint32_t *h, char *err, uint64_t err_len);
 void arctic_png_free(uint8_t *p);
 

@@ -256,10 +256,10 @@ def test_errors(gltf, tmp_path):
         gltf.load(str(p))
     path, _, _ = write_scene(str(tmp_path))
     doc = json.load(open(path))
-    doc["images"][0]["uri"] = "photo.jpg"
-    (tmp_path / "photo.jpg").write_bytes(b"\xff\xd8\xff\xe0" + b"\0" * 32)
+    doc["images"][0]["uri"] = "photo.webp"
+    (tmp_path / "photo.webp").write_bytes(b"RIFF\0\0\0\0WEBPVP8 " + b"\0" * 32)
     json.dump(doc, open(path, "w"))
-    with pytest.raises(ValueError, match="PNG"):
+    with pytest.raises(ValueError, match="PNG or baseline JPEG"):
         gltf.load(path)
 
 
@@ -314,3 +314,131 @@ def test_library_exports_every_symbol_of_its_header(gltf):
     L = gltf.lib()
     for n in names:
         assert hasattr(L, n), n
+
+
+# ------------------------------------------------------------------------------------------- baseline JPEG
+ZZ = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+      35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63]
+DCT = np.array([[(np.sqrt(0.5) if u == 0 else 1.0) * 0.5 * np.cos((2 * x + 1) * u * np.pi / 16) for u in range(8)] for x in range(8)])   # [x][u]
+
+
+def jpeg_bytes(rgb, sub=(1, 1), quant=4, restart=0):
+    """minimal baseline JPEG writer for the test: fixed-length Huffman codes (any prefix code is legal), one interleaved
+    scan, luma sampled (sub x sub... ) relative to chroma.  Returns (bytes, reference decode) where the reference is the
+    textbook decoder arithmetic in float64."""
+    h, w = rgb.shape[:2]
+    hs, vs = sub
+    r, g, b = [rgb[..., k].astype(np.float64) for k in range(3)]
+    ycc = [0.299 * r + 0.587 * g + 0.114 * b, -0.168736 * r - 0.331264 * g + 0.5 * b + 128, 0.5 * r - 0.418688 * g - 0.081312 * b + 128]
+    mw, mh = -(-w // (8 * hs)), -(-h // (8 * vs))
+    planes = []
+    for c, p in enumerate(ycc):
+        fh, fv = (hs, vs) if c == 0 else (1, 1)
+        full = np.pad(p, ((0, mh * 8 * vs - h), (0, mw * 8 * hs - w)), mode="edge")
+        if c:   # chroma: average the hs x vs block
+            full = full.reshape(mh * 8, vs, mw * 8, hs).mean((1, 3))
+        planes.append(full)
+    q = np.full(64, quant, np.int64)
+    ac_syms = [0x00, 0xF0] + [(run << 4) | size for run in range(16) for size in range(1, 11)]
+    ac_code = {s: i for i, s in enumerate(ac_syms)}          # 8-bit codes 0..161
+    bits = []
+
+    def put(v, n):
+        for k in range(n - 1, -1, -1):
+            bits.append((v >> k) & 1)
+
+    def amp(v):
+        if v == 0:
+            return 0, 0
+        n = int(abs(v)).bit_length()
+        return n, (v if v > 0 else v + (1 << n) - 1)
+    coeffs = [np.zeros((p.shape[0] // 8, p.shape[1] // 8, 64), np.int64) for p in planes]
+    for c, p in enumerate(planes):
+        for by in range(p.shape[0] // 8):
+            for bx in range(p.shape[1] // 8):
+                blk = p[by * 8:by * 8 + 8, bx * 8:bx * 8 + 8] - 128.0
+                f = DCT.T @ blk @ DCT                                    # F[v][u]
+                coeffs[c][by, bx] = np.rint(f.reshape(64) / q).astype(np.int64)
+    pred = [0, 0, 0]
+    out = bytearray()
+    count = 0
+
+    def flush():
+        nonlocal bits
+        while len(bits) % 8:
+            bits.append(1)
+        by = np.packbits(np.array(bits, np.uint8)).tobytes() if bits else b""
+        for v in by:
+            out.append(v)
+            if v == 0xFF:
+                out.append(0)
+        bits = []
+    for my in range(mh):
+        for mx in range(mw):
+            if restart and count and count % restart == 0:
+                flush()
+                out.extend(bytes([0xFF, 0xD0 + ((count // restart - 1) % 8)]))
+                pred = [0, 0, 0]
+            for c in range(3):
+                fh, fv = (hs, vs) if c == 0 else (1, 1)
+                for by in range(fv):
+                    for bx in range(fh):
+                        z = coeffs[c][my * fv + by, mx * fh + bx][ZZ]
+                        n, a = amp(int(z[0]) - pred[c]); pred[c] = int(z[0])
+                        put(n, 4); put(a, n)
+                        run = 0
+                        last = max([k for k in range(1, 64) if z[k] != 0], default=0)
+                        for k in range(1, last + 1):
+                            if z[k] == 0:
+                                run += 1
+                                if run == 16:
+                                    put(ac_code[0xF0], 8); run = 0
+                                continue
+                            n, a = amp(int(z[k]))
+                            put(ac_code[(run << 4) | n], 8); put(a, n); run = 0
+                        if last < 63:
+                            put(ac_code[0x00], 8)
+            count += 1
+    flush()
+
+    def seg(m, body):
+        return bytes([0xFF, m]) + struct.pack(">H", len(body) + 2) + body
+    dht_dc = bytes([0x00]) + bytes([0, 0, 0, 12] + [0] * 12) + bytes(range(12))
+    dht_ac = bytes([0x10]) + bytes([0] * 7 + [len(ac_syms)] + [0] * 8) + bytes(ac_syms)
+    sof = struct.pack(">BHHB", 8, h, w, 3) + bytes([1, (hs << 4) | vs, 0, 2, 0x11, 0, 3, 0x11, 0])
+    sos = bytes([3, 1, 0x00, 2, 0x00, 3, 0x00, 0, 63, 0])
+    data = (b"\xff\xd8" + seg(0xE0, b"JFIF\0\1\1\0\0\1\0\1\0\0") + seg(0xDB, bytes([0]) + bytes([quant] * 64)) + seg(0xC0, sof) + seg(0xC4, dht_dc) + seg(0xC4, dht_ac)
+            + (seg(0xDD, struct.pack(">H", restart)) if restart else b"") + seg(0xDA, sos) + bytes(out) + b"\xff\xd9")
+    # reference decode (float64): dequantise, IDCT, +128, round, clamp; chroma replicated; JFIF conversion
+    rec = []
+    for c, p in enumerate(planes):
+        o = np.zeros_like(p)
+        for by in range(p.shape[0] // 8):
+            for bx in range(p.shape[1] // 8):
+                f = (coeffs[c][by, bx] * q).reshape(8, 8).astype(np.float64)
+                o[by * 8:by * 8 + 8, bx * 8:bx * 8 + 8] = DCT @ f @ DCT.T
+        o = np.clip(np.rint(o + 128), 0, 255)
+        if c:
+            o = np.repeat(np.repeat(o, vs, 0), hs, 1)
+        rec.append(o[:h, :w])
+    Y, cb, cr = rec[0], rec[1] - 128, rec[2] - 128
+    ref = np.stack([Y + 1.402 * cr, Y - 0.344136 * cb - 0.714136 * cr, Y + 1.772 * cb], -1)
+    return data, np.clip(np.rint(ref), 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("sub,restart,size", [((1, 1), 0, (24, 40)), ((2, 2), 0, (37, 53)), ((2, 1), 3, (16, 48)), ((2, 2), 2, (50, 33))],
+                         ids=["444", "420-ragged", "422-restart", "420-restart-ragged"])
+def test_baseline_jpeg_decoder(gltf, sub, restart, size):
+    rng = np.random.default_rng(sum(size) + restart)
+    h, w = size
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([127 + 100 * np.sin(xx / 7.0 + yy / 11.0), 127 + 90 * np.cos(xx / 5.0), 40 + 3.0 * yy + 20 * rng.random((h, w))], -1)
+    img = np.clip(img, 0, 255).astype(np.uint8)
+    data, ref = jpeg_bytes(img, sub=sub, quant=3, restart=restart)
+    out = gltf.png_decode(data)                      # the image entry point picks the decoder by signature
+    assert out.shape == (h, w, 4) and (out[..., 3] == 255).all()
+    d = np.abs(out[..., :3].astype(np.int16) - ref.astype(np.int16))
+    assert d.max() <= 1 and (d != 0).mean() < 0.02, (d.max(), (d != 0).mean())     # float32 vs float64 rounding
+    assert np.abs(out[..., :3].astype(np.int16) - img.astype(np.int16)).mean() < 6  # and it is the picture that went in
+    with pytest.raises(ValueError, match="progressive"):
+        gltf.png_decode(data.replace(b"\xff\xc0", b"\xff\xc2", 1))
