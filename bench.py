@@ -168,7 +168,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # outside the timed region: the exchange step alone (gathered bytes / gather time per link)
+    gather_ms = None
     if world > 1:
+        try:
+            torch.cuda.synchronize(); dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                sharding.gather_rows(outs[0], gathered[0], rank, world)
+            torch.cuda.synchronize(); dist.barrier()
+            gather_ms = (time.perf_counter() - t0) / 10 * 1e3
+        except Exception as exc:   # a measurement extra must never cost the bench line
+            log(f"[bench] gather timing skipped: {exc}")
         r.set_stream(None)
     if world > 1 and rank == 0 and os.environ.get("ARCTIC_BENCH_VERIFY") == "1":
         # the multi-rank invariant, end to end: the gathered, de-interleaved frame == a single-device frame, byte for byte
@@ -234,7 +245,11 @@ def main():
             "config": {"workload": f"BASELINE configs[{args.config - 1}]: {sc.name}, {sc.width}x{sc.height}, 1 dir + {len(sc.lights)} point lights, "
                                    f"shadow {sc.shadow_size}^2 PCF 5x5, tonemap {sc.settings[0]}, {len(sc.materials)} materials; shading pass over a resident G-buffer",
                        "triangles": sc.n_triangles, "shaded_pixels": shaded, "sharding": f"{BAND}-row bands round-robin over {world} ranks, RCCL gather to rank 0" if world > 1 else "none",
-                       "scale": args.scale},
+                       "scale": args.scale,
+                       "exchange": None if gather_ms is None else {
+                           "gather_ms": round(gather_ms, 4), "bytes_per_sender": int(pad) * sc.width * 4,
+                           "GBps_per_link": round(int(pad) * sc.width * 4 / (gather_ms * 1e-3) / 1e9, 2),
+                           "note": "one padded shard per rank into rank 0, timed alone (synchronous), outside the timed steps"}},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "kernel": "k_material<2> (material fetch + shadow test + packed light loop + tonemap: the whole pass)" if len(sc.lights) > 16 else "k_material<1> (the whole pass, scalar light loop)", "kernel_ms": round(pass_ms, 4),
