@@ -108,7 +108,10 @@ struct ShadeParams {
     const float *srgb_lut;       // 256 floats, sRGB8 -> linear
     const float *shadow_map;     // S*S floats row-major, or null
     uint32_t shadow_size;
+    const float2 *shadow_bounds; // conservative (min, max) of the map per 4x4-aligned 8x8 texel block (k_shadow_bounds), or null
+    uint32_t bounds_pitch;       // entries per row of shadow_bounds = shadow_bounds_pitch(S)
     const float4 *lights;        // 2 float4 per light
+    const float4 *light_pairs;   // the same lights as pairs, 3 float4 per pair {x0,x1,y0,y1} {z0,z1,r0,r1} {g0,g1,b0,b1}; an odd count is padded with a black light
     uint32_t n_lights;
     float eye[3];
     float sun_dir[3];
@@ -124,16 +127,11 @@ struct ShadeParams {
     uint8_t *out_rgba8;          // rows*width*4, row-major
     float *out_ldr;              // optional rows*width*3
     float *out_hdr;              // optional rows*width*3
-    unsigned long long *light_evals;  // optional counter
+    unsigned long long *stats;   // STATS kernels only: [0] point-light evaluations, [1] lit pixels, [2] evaluations with n.wi > 0,
+                                 // [3] (tile, light) pairs with n.wi <= 0 in every lit lane, [4] tiles with a lit pixel
     int32_t culling;
-    // lit-pixel stream written by k_material, read by k_light (capacity = pixels of the shard)
-    float4 *lit_r0, *lit_r1, *lit_r2;   // (world.xyz, 1-shadow) (n.xyz, roughness) (base.xyz, metalness)
-    uint32_t *lit_px;                   // pixel index y*width + x inside the shard
-    uint32_t *lit_count;                // LIT_SHARDS counters per band, LIT_COUNTER_STRIDE apart: this pass's set ...
     // whole frames without a G-buffer (k_material_vis): the visibility plane and what the prepass left behind
     const unsigned long long *vis; const SetupRec *recs; const uint32_t *rec_of; const ObjectRec *objs; const XVert *xv;
-    uint32_t *tickets;                  // fused kernel: 8 per-XCD tile tickets + 1 exit counter, 128 B apart, zero between passes
-    uint32_t *lit_count_next;           // ... and the other set, which k_light clears for the next pass
     // skybox (skybox.hlsl:61-90): environment map for pixels without geometry; env == null -> black
     const float4 *env;                  // RGBA32F equirect, row-major
     uint32_t env_w, env_h;
@@ -142,23 +140,16 @@ struct ShadeParams {
     int32_t band_tiles, shard_index, shard_count, tile_y0;   // local tile row -> global row (see row_global)
     int32_t hdr16;                      // 1: round ps_main's colour through binary16 like the reference's RGBA16F target
     int32_t debug;                      // timing experiments only: 1 skip material textures, 2 skip shadow test
-    uint32_t lit_shard_cap;             // records per shard of one band: ceil(band workgroups / LIT_SHARDS) * 256, cannot overflow
-    uint32_t band, n_bands;             // set by launch_shade
 };
-constexpr uint32_t MAX_BANDS = 16;
 struct ShadeLaunch {
-    hipStream_t main, aux;
-    hipEvent_t band_done[MAX_BANDS], aux_done;
-    uint32_t n_bands, light_blocks;
-    uint32_t lights_per_trip;   // k_light variant: 4 (two packed pairs per loop trip, 112 VGPRs) or 2 (one pair, 98 VGPRs)
-    hipEvent_t mid;   // optional: recorded between k_material and k_light (single band), for per-kernel timing
-    uint32_t inline_mode;           // 0: k_material -> stream -> k_light; 1 / 2: the material kernel runs the light loop itself (scalar / packed pairs)
-    uint32_t from_vis;              // 1: k_material_vis (attributes interpolated from the visibility plane) instead of k_material
-    uint32_t fused, fused_blocks;   // 1: the whole pass as one persistent kernel (k_shade_fused) of fused_blocks workgroups
+    hipStream_t stream;
+    uint32_t loop;       // 1: scalar light loop; 2: two lights at a time in packed fp32 (both read the lights through the scalar cache)
+    uint32_t from_vis;   // 1: k_material_vis (attributes interpolated from the visibility plane) instead of k_material
+    uint32_t stats;      // 1: the counting variant (ShadeParams::stats)
 };
-constexpr uint32_t LIT_SHARDS = 256, LIT_COUNTER_STRIDE = 32;
-constexpr uint32_t MAX_LDS_MATERIALS = 512;   // 24 KiB of descriptors
-constexpr uint32_t MAX_SHADE_LIGHTS = 2048;    // 48 KiB of light pairs in LDS
+constexpr uint32_t N_SHADE_STATS = 5;
+// the shadow-bounds table: one entry per 4x4 texel block; only for maps the 4x4 window argument covers (S <= 5000)
+inline uint32_t shadow_bounds_pitch(uint32_t S) { return S >= 4 && S <= 5000 ? (S + 3) / 4 : 0; }
 
 // ---- kernel launchers (geometry.hip, shade.hip) ---------------------------------------------
 // every launcher enqueues on `s` and returns the launch error, never synchronises.
@@ -176,8 +167,7 @@ hipError_t launch_resolve(const unsigned long long *vis, const SetupRec *recs, c
 hipError_t launch_fill_u64(unsigned long long *p, unsigned long long v, size_t n, hipStream_t s);
 hipError_t launch_fill_u32(uint32_t *p, uint32_t v, size_t n, hipStream_t s);
 hipError_t launch_shade(const ShadeParams &sp, const ShadeLaunch &L);
-size_t fused_lds_bytes(uint32_t n_materials, uint32_t n_lights);
-int fused_blocks_per_cu(size_t lds_bytes, uint32_t lights_per_trip);
+hipError_t launch_shadow_bounds(const float *map, uint32_t S, float2 *blocks, float2 *bounds, hipStream_t s);
 hipError_t launch_post_process(const float4 *hdr, uint32_t w, uint32_t h, int32_t tm, float inv_gamma, float exposure,
                                uint8_t *rgba8, float *ldr, hipStream_t s);
 hipError_t launch_gbuffer_tile(GBuffer g, float *attrs, uint32_t *mat, uint32_t width, uint32_t rows,

@@ -101,15 +101,16 @@ struct ArcticRenderer {
     std::vector<Mesh> meshes;
     std::vector<TexDesc> tex;        // 3 per material (device pointers)
     std::vector<void *> tex_allocs;
-    DevBuf d_tex, d_lut, d_lights, d_shadow, d_env;
+    DevBuf d_tex, d_lut, d_lights, d_light_pairs, d_shadow, d_env;
+    DevBuf d_shadow_blocks, d_shadow_bounds;   // min/max of the shadow map per 4x4 texel block / per 4x4-aligned 8x8 block (k_shadow_bounds)
+    bool bounds_valid = false;      // false whenever d_shadow has been written since the table was built
     uint32_t env_w = 0, env_h = 0;
     uint32_t n_lights = 0;
     // frame targets
     DevBuf d_vis, d_p0, d_p1, d_p2, d_p3, d_p4, d_rgba8, d_ldr, d_hdr, d_counter;
-    DevBuf d_lit0, d_lit1, d_lit2, d_litpx, d_litcount;   // lit-pixel stream between k_material and k_light
     bool have_gbuffer = false, have_output = false, have_vis = false;   // have_vis: d_vis holds the visibility of the current G-buffer
     int geo_owner = 0;              // whose records d_recs / d_rec_of / d_xverts hold: 1 forward pass, 2 shadow pass
-    int light_path = 0;             // ARCTIC_OPT_LIGHT_PATH: 0 automatic, 1 stream (k_material + k_light), 2 inline scalar, 3 inline packed
+    int light_path = 0;             // ARCTIC_OPT_LIGHT_PATH: 0 automatic, 1 scalar light loop, 2 packed pairs
     bool visbuffer = true;          // arctic_render_frame shades straight from the visibility plane (no G-buffer)
     // per-frame geometry scratch
     PassTables tables[2];   // [0] forward pass, [1] shadow pass
@@ -118,15 +119,12 @@ struct ArcticRenderer {
     bool recs_worst_case = false;   // record table at 7 per source triangle (after an overflow of the 2-per-triangle table)
     uint32_t item_cap_floor = 1u << 22;   // its smallest size (ARCTIC_OPT_ITEM_TABLE_FLOOR; tests shrink it to reach the overflow path)
     uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t light_stats[2] = {0, 0};   // stats[8], [9]: (tile, light) pairs with n.wi <= 0 in every lit lane; tiles with a lit pixel
     int keep_float = 0, count_evals = 0, culling = 1, debug = 0, hdr16 = 0;
-    ShadeLaunch launch{};           // streams, events, band count and k_light's persistent grid
     uint32_t raster_blocks = 2048;  // persistent grid of k_raster
-    DevBuf d_tickets;               // fused shading kernel: tile tickets (zeroed once; the kernel resets them itself)
-    size_t fused_lds = ~(size_t)0; int fused_per_cu = 0;   // cached occupancy query
     // render_frame re-renders the shadow map only when its inputs changed (sun, objects, meshes): the reference redraws it
     // every frame (renderer.cpp:300-337), but a depth map of unchanged geometry from an unchanged light is the same map
     std::vector<uint8_t> shadow_key; bool shadow_cache = true;
-    int lit_parity = 0;             // which of the two stream-counter sets the next pass uses
     uint32_t cu_count = 256;
     uint32_t *h_counts = nullptr;   // pinned: [0] records, [1] work items (forward), [2], [3] the same for the shadow pass, [4], [5] item-table overflow flags
     std::string err;
@@ -141,12 +139,6 @@ struct ArcticRenderer {
         return code;
     }
     uint32_t rows() const { return band_rows ? owned_rows : row_end - row_begin; }
-    // records per shard of the lit-pixel stream: workgroup (ty, col) goes to shard (ty * bpr + col) % LIT_SHARDS
-    uint32_t lit_shard_cap() const {
-        uint32_t bpr = (tiles_x + 3) / 4, row_groups = (tiles_y + 7) / 8, nb = std::max(1u, std::min(launch.n_bands, row_groups));
-        uint32_t band_blocks = ((row_groups + nb - 1) / nb) * 8 * bpr;
-        return ((band_blocks + LIT_SHARDS - 1) / LIT_SHARDS) * 256;
-    }
     size_t n_tiles() const { return (size_t)tiles_x * tiles_y; }
     GBuffer gbuffer() const { return GBuffer{d_p0.as<float4>(), d_p4.as<float>(), d_p1.as<float4>(), d_p2.as<float4>(), d_p3.as<float4>()}; }
 };
@@ -185,22 +177,8 @@ int alloc_targets(ArcticRenderer *r) {
     HIPCHECK(r, r->d_p3.ensure(px * 16));
     HIPCHECK(r, r->d_p4.ensure(px * 12));
     HIPCHECK(r, r->d_rgba8.ensure(out_px * 4));
-    HIPCHECK(r, r->d_counter.ensure(64));
+    HIPCHECK(r, r->d_counter.ensure(8 * N_SHADE_STATS));
     HIPCHECK(r, r->d_geo_counters.ensure(32));
-    if (!r->d_tickets.p) {
-        HIPCHECK(r, r->d_tickets.ensure(9 * 128));
-        HIPCHECK(r, hipMemsetAsync(r->d_tickets.p, 0, 9 * 128, r->stream));
-    }
-    {
-        size_t cap = (size_t)r->lit_shard_cap() * LIT_SHARDS * std::max(1u, r->launch.n_bands);   // re-checked per frame: the band count is an option
-        HIPCHECK(r, r->d_lit0.ensure(cap * 16));
-        HIPCHECK(r, r->d_lit1.ensure(cap * 16));
-        HIPCHECK(r, r->d_lit2.ensure(cap * 16));
-        HIPCHECK(r, r->d_litpx.ensure(cap * 4));
-        HIPCHECK(r, r->d_litcount.ensure((size_t)2 * MAX_BANDS * LIT_SHARDS * LIT_COUNTER_STRIDE * 4));
-        HIPCHECK(r, hipMemsetAsync(r->d_litcount.p, 0, (size_t)2 * MAX_BANDS * LIT_SHARDS * LIT_COUNTER_STRIDE * 4, r->stream));
-        r->lit_parity = 0;
-    }
     r->have_gbuffer = r->have_output = r->have_vis = false;
     return ARCTIC_OK;
 }
@@ -337,6 +315,7 @@ int pass_shadow_map(ArcticRenderer *r, const ArcticScene *sc) {
     Range zone("Shadow Map Pass");
     size_t n = (size_t)r->shadow_size * r->shadow_size;
     HIPCHECK(r, launch_fill_u32(r->d_shadow.as<uint32_t>(), 0x3F800000u, n, r->stream));   // clear to 1.0 (shadow_map_pass.cpp:124-131)
+    r->bounds_valid = false;
     return run_geometry(r, sc, true);
 }
 
@@ -382,7 +361,7 @@ int fill_shade_params(ArcticRenderer *r, const ArcticScene *sc, const ArcticSett
     sp.srgb_lut = r->d_lut.as<float>();
     sp.shadow_map = r->shadow_size ? r->d_shadow.as<float>() : nullptr;
     sp.shadow_size = r->shadow_size;
-    sp.lights = r->d_lights.as<float4>();
+    sp.lights = r->d_lights.as<float4>(); sp.light_pairs = r->d_light_pairs.as<float4>();
     sp.n_lights = r->n_lights;
     std::memcpy(sp.eye, sc->camera.eye, 12);
     dir_from_rot(sc->sun.rotation, sp.sun_dir);     // DirectionalLight::direction(), scene.cpp:56-59
@@ -400,7 +379,7 @@ int fill_shade_params(ArcticRenderer *r, const ArcticScene *sc, const ArcticSett
         HIPCHECK(r, r->d_hdr.ensure(out_px * 12));
         sp.out_ldr = r->d_ldr.as<float>(); sp.out_hdr = r->d_hdr.as<float>();
     }
-    sp.light_evals = r->count_evals == 1 ? r->d_counter.as<unsigned long long>() : nullptr;   // 2: lit pixels only, no atomics in the loop
+    sp.stats = nullptr;
     sp.culling = r->culling;
     sp.debug = r->debug;
     sp.hdr16 = r->hdr16;
@@ -409,43 +388,27 @@ int fill_shade_params(ArcticRenderer *r, const ArcticScene *sc, const ArcticSett
     sp.ndc_sx = 2.0f / (float)r->width; sp.ndc_sy = 2.0f / (float)r->height;
     sp.band_tiles = (int32_t)(r->band_rows / TILE); sp.shard_index = (int32_t)r->shard_index; sp.shard_count = (int32_t)r->shard_count;
     sp.tile_y0 = (int32_t)r->tile_y0;
-    sp.lit_r0 = r->d_lit0.as<float4>(); sp.lit_r1 = r->d_lit1.as<float4>(); sp.lit_r2 = r->d_lit2.as<float4>();
-    sp.lit_px = r->d_litpx.as<uint32_t>(); sp.lit_count = sp.lit_count_next = nullptr;   // set per pass by shade_once
-    sp.lit_shard_cap = r->lit_shard_cap();
-    sp.tickets = r->d_tickets.as<uint32_t>();
-    {
-        size_t cap = (size_t)sp.lit_shard_cap * LIT_SHARDS * r->launch.n_bands;
-        HIPCHECK(r, r->d_lit0.ensure(cap * 16)); HIPCHECK(r, r->d_lit1.ensure(cap * 16)); HIPCHECK(r, r->d_lit2.ensure(cap * 16)); HIPCHECK(r, r->d_litpx.ensure(cap * 4));
-        sp.lit_r0 = r->d_lit0.as<float4>(); sp.lit_r1 = r->d_lit1.as<float4>(); sp.lit_r2 = r->d_lit2.as<float4>(); sp.lit_px = r->d_litpx.as<uint32_t>();
+    const uint32_t nb = shadow_bounds_pitch(r->shadow_size);
+    if (nb && !(r->debug & 8)) {   // the min/max table of the shadow map: rebuilt (two small launches) whenever the map was written
+        if (!r->bounds_valid) {
+            HIPCHECK(r, r->d_shadow_blocks.ensure((size_t)nb * nb * 8));
+            HIPCHECK(r, r->d_shadow_bounds.ensure((size_t)nb * nb * 8));
+            HIPCHECK(r, launch_shadow_bounds(r->d_shadow.as<float>(), r->shadow_size, r->d_shadow_blocks.as<float2>(), r->d_shadow_bounds.as<float2>(), r->stream));
+            r->bounds_valid = true;
+        }
+        sp.shadow_bounds = r->d_shadow_bounds.as<float2>(); sp.bounds_pitch = nb;
     }
     return ARCTIC_OK;
 }
 
-// one shading pass; alternates the two stream-counter sets (k_light clears the set the NEXT pass will fill)
-hipError_t shade_once(ArcticRenderer *r, ShadeParams &sp, const ShadeLaunch &L) {
-    // which way the lit pixels take (shade.hip, emit_live): automatic = inline, scalar loop up to 16 lights, packed above
-    uint32_t mode = r->light_path == 0 ? (sp.n_lights <= 16 ? 1u : 2u) : (uint32_t)r->light_path - 1u;
-    if (r->count_evals || L.n_bands != 1 || L.fused) mode = 0;   // statistics, bands and the fused kernel live on the stream path
-    // the packed inline kernel keeps descriptors AND light pairs in LDS; past the 64 KiB a workgroup gets by default (hundreds of
-    // materials with thousands of lights) the two tables go back to separate kernels
-    if (mode == 2 && (256 + (size_t)sp.n_materials * 12) * 4 + (size_t)((sp.n_lights + 3) / 4) * 96 > 64 * 1024) mode = 0;
-    if (mode) {
-        ShadeLaunch S = L;   // one kernel; the stream and its counters are not touched (both counter sets stay as they are)
-        S.inline_mode = mode; S.fused = 0;
-        return launch_shade(sp, S);
-    }
-    if (L.fused) {   // one persistent kernel, no stream: the counter sets are left alone (the cleared one stays cleared)
-        const size_t lds = fused_lds_bytes(sp.n_materials, sp.n_lights);
-        if (lds != r->fused_lds) { r->fused_lds = lds; r->fused_per_cu = fused_blocks_per_cu(lds, L.lights_per_trip); }
-        if (r->fused_per_cu < 1) return hipErrorLaunchOutOfResources;
-        ShadeLaunch F = L;
-        F.fused_blocks = r->cu_count * (uint32_t)r->fused_per_cu;
-        return launch_shade(sp, F);
-    }
-    const size_t set = (size_t)MAX_BANDS * LIT_SHARDS * LIT_COUNTER_STRIDE;
-    sp.lit_count = r->d_litcount.as<uint32_t>() + (r->lit_parity ? set : 0);
-    sp.lit_count_next = r->d_litcount.as<uint32_t>() + (r->lit_parity ? 0 : set);
-    r->lit_parity ^= 1;
+// one shading pass = one launch.  The light loop: scalar (lights through the scalar cache, small register footprint) up to
+// 16 point lights -- the reference's MAX_NUM_POINT_LIGHTS -- packed pairs from LDS above (ARCTIC_OPT_LIGHT_PATH overrides).
+hipError_t shade_once(ArcticRenderer *r, const ShadeParams &sp, bool from_vis, bool stats) {
+    ShadeLaunch L;
+    L.stream = r->stream;
+    L.loop = r->light_path == 0 ? (sp.n_lights <= 16 ? 1u : 2u) : (uint32_t)r->light_path;
+    L.from_vis = from_vis ? 1u : 0u;
+    L.stats = stats ? 1u : 0u;
     return launch_shade(sp, L);
 }
 
@@ -454,21 +417,17 @@ int pass_shade(ArcticRenderer *r, const ArcticScene *sc, const ArcticSettings *s
     ShadeParams sp;
     int rc = fill_shade_params(r, sc, st, d_out, sp, from_vis);
     if (rc != ARCTIC_OK) return rc;
-    const bool fused_count = r->launch.fused && r->count_evals;   // the fused kernel has no stream counters: it counts lit pixels itself
-    if (fused_count) sp.light_evals = r->d_counter.as<unsigned long long>();
-    if (sp.light_evals) HIPCHECK(r, hipMemsetAsync(r->d_counter.p, 0, 16, r->stream));
-    ShadeLaunch L = r->launch;
-    L.from_vis = from_vis ? 1u : 0u;
-    HIPCHECK(r, shade_once(r, sp, L));
     if (r->count_evals) {
-        unsigned long long n[2] = {0, 0};
-        std::vector<uint32_t> counts((size_t)r->launch.n_bands * LIT_SHARDS * LIT_COUNTER_STRIDE);
-        if (sp.light_evals) HIPCHECK(r, hipMemcpyAsync(n, r->d_counter.p, 16, hipMemcpyDeviceToHost, r->stream));
-        if (!r->launch.fused) HIPCHECK(r, hipMemcpyAsync(counts.data(), sp.lit_count, counts.size() * 4, hipMemcpyDeviceToHost, r->stream));
+        sp.stats = r->d_counter.as<unsigned long long>();
+        HIPCHECK(r, hipMemsetAsync(r->d_counter.p, 0, 8 * N_SHADE_STATS, r->stream));
+    }
+    HIPCHECK(r, shade_once(r, sp, from_vis, r->count_evals != 0));
+    if (r->count_evals) {
+        unsigned long long n[N_SHADE_STATS] = {};
+        HIPCHECK(r, hipMemcpyAsync(n, r->d_counter.p, 8 * N_SHADE_STATS, hipMemcpyDeviceToHost, r->stream));
         HIPCHECK(r, hipStreamSynchronize(r->stream));
-        r->stats[5] = r->count_evals == 1 ? n[0] : 0;
-        r->stats[6] = n[1];   // fused kernel counts the lit pixels itself; the two-kernel pass leaves them in the stream counters
-        if (!r->launch.fused) for (uint32_t k = 0; k < r->launch.n_bands * LIT_SHARDS; ++k) r->stats[6] += counts[(size_t)k * LIT_COUNTER_STRIDE];
+        r->stats[5] = n[0]; r->stats[6] = n[1]; r->stats[7] = n[2];
+        r->light_stats[0] = n[3]; r->light_stats[1] = n[4];
     }
     r->have_output = (d_out == nullptr);
     return ARCTIC_OK;
@@ -544,28 +503,17 @@ ArcticRenderer *arctic_create(const ArcticCreateInfo *info, char *err, uint64_t 
     {
         hipDeviceProp_t prop;
         if ((e = hipGetDeviceProperties(&prop, r->device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
-        // k_light: 24 workgroups per CU although 4 are resident: ~1 pixel group per wave, so the hardware dispatcher balances
-        // the load (measured 0.181 ms at 4 per CU, 0.164 ms at 24, flat beyond)
-        r->launch.light_blocks = (uint32_t)std::max(1, prop.multiProcessorCount) * 24;
-        r->launch.n_bands = 1;
-        r->launch.lights_per_trip = 4;
-        r->launch.fused = 0; r->launch.fused_blocks = 0; r->launch.inline_mode = 0; r->launch.from_vis = 0;
-        if (const char *f = std::getenv("ARCTIC_SHADE_FUSED")) r->launch.fused = std::atoi(f) ? 1u : 0u;   // default of ARCTIC_OPT_FUSED
         r->cu_count = (uint32_t)std::max(1, prop.multiProcessorCount);
         r->raster_blocks = (uint32_t)std::max(1, prop.multiProcessorCount) * 8;
         if ((e = hipHostMalloc((void **)&r->h_counts, 64)) != hipSuccess) return bail("hipHostMalloc", e);
         std::memset(r->h_counts, 0, 64);
-        r->launch.main = r->stream;
-        if ((e = hipStreamCreateWithFlags(&r->launch.aux, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate aux", e);
-        for (uint32_t k = 0; k < MAX_BANDS; ++k)
-            if ((e = hipEventCreateWithFlags(&r->launch.band_done[k], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
-        if ((e = hipEventCreateWithFlags(&r->launch.aux_done, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     }
     float lut[256];
     for (int i = 0; i < 256; ++i) lut[i] = srgb8_to_linear(i);
     if ((e = r->d_lut.ensure(sizeof lut)) != hipSuccess) return bail("hipMalloc lut", e);
     if ((e = hipMemcpy(r->d_lut.p, lut, sizeof lut, hipMemcpyHostToDevice)) != hipSuccess) return bail("upload lut", e);
     if ((e = r->d_lights.ensure(std::max<size_t>(32, (size_t)r->max_lights * 32))) != hipSuccess) return bail("hipMalloc lights", e);
+    if ((e = r->d_light_pairs.ensure(std::max<size_t>(48, (size_t)((r->max_lights + 1) / 2) * 48))) != hipSuccess) return bail("hipMalloc light pairs", e);
     if ((e = r->d_tex.ensure(48)) != hipSuccess) return bail("hipMalloc tex table", e);
     if (r->shadow_size) {
         size_t n = (size_t)r->shadow_size * r->shadow_size;
@@ -581,15 +529,12 @@ void arctic_destroy(ArcticRenderer *r) {
     if (!r) return;
     (void)hipSetDevice(r->device);
     if (r->h_counts) (void)hipHostFree(r->h_counts);
-    if (r->launch.aux) { (void)hipStreamSynchronize(r->launch.aux); (void)hipStreamDestroy(r->launch.aux); }
-    for (uint32_t k = 0; k < MAX_BANDS; ++k) if (r->launch.band_done[k]) (void)hipEventDestroy(r->launch.band_done[k]);
-    if (r->launch.aux_done) (void)hipEventDestroy(r->launch.aux_done);
     (void)hipStreamSynchronize(r->stream);
     if (r->own_stream) { (void)hipStreamSynchronize(r->own_stream); (void)hipStreamDestroy(r->own_stream); }
     for (Mesh &m : r->meshes) { if (m.d_vertices) (void)hipFree(m.d_vertices); if (m.d_indices) (void)hipFree(m.d_indices); }
     for (void *p : r->tex_allocs) (void)hipFree(p);
-    DevBuf *bufs[] = {&r->d_tex, &r->d_lut, &r->d_lights, &r->d_shadow, &r->d_env, &r->d_vis, &r->d_p0, &r->d_p1, &r->d_p2, &r->d_p3, &r->d_p4,
-                      &r->d_rgba8, &r->d_ldr, &r->d_hdr, &r->d_counter, &r->d_tickets, &r->d_lit0, &r->d_lit1, &r->d_lit2, &r->d_litpx, &r->d_litcount, &r->d_xverts,
+    DevBuf *bufs[] = {&r->d_tex, &r->d_lut, &r->d_lights, &r->d_light_pairs, &r->d_shadow, &r->d_env, &r->d_vis, &r->d_p0, &r->d_p1, &r->d_p2, &r->d_p3, &r->d_p4,
+                      &r->d_rgba8, &r->d_ldr, &r->d_hdr, &r->d_counter, &r->d_shadow_blocks, &r->d_shadow_bounds, &r->d_xverts,
                       &r->d_recs, &r->d_rec_of, &r->d_items, &r->d_geo_counters, &r->d_stage, &r->tables[0].d, &r->tables[1].d};
     for (PassTables &T : r->tables) { if (T.h) (void)hipHostFree(T.h); if (T.copied) (void)hipEventDestroy(T.copied); }
     for (DevBuf *b : bufs) b->release();
@@ -625,7 +570,6 @@ int arctic_set_stream(ArcticRenderer *r, void *hip_stream) {
     if (rc) return rc;
     HIPCHECK(r, hipStreamSynchronize(r->stream));
     r->stream = static_cast<hipStream_t>(hip_stream);   // NULL = the default stream
-    r->launch.main = r->stream;
     return ARCTIC_OK;
 }
 
@@ -635,7 +579,6 @@ int arctic_use_own_stream(ArcticRenderer *r) {
     if (rc) return rc;
     HIPCHECK(r, hipStreamSynchronize(r->stream));
     r->stream = r->own_stream;
-    r->launch.main = r->stream;
     return ARCTIC_OK;
 }
 
@@ -644,7 +587,6 @@ int arctic_create_material(ArcticRenderer *r, const void *diffuse, uint32_t dw, 
     if (!r) return ARCTIC_E_INVALID;
     if (!diffuse || !normal || !mr || !dw || !dh || !nw || !nh || !mw || !mh) return r->fail(ARCTIC_E_INVALID, "create_material: null image or zero size");
     if ((dw | dh | nw | nh | mw | mh) & 0xFFFF0000u) return r->fail(ARCTIC_E_CAPACITY, "create_material: image side above 65535");
-    if (r->tex.size() / 3 >= MAX_LDS_MATERIALS) return r->fail(ARCTIC_E_CAPACITY, "create_material: more than %u materials (their descriptors live in LDS)", MAX_LDS_MATERIALS);
     int rc = select_device(r);
     if (rc) return rc;
     const void *src[3] = {diffuse, normal, mr};
@@ -706,9 +648,20 @@ int arctic_update_lights(ArcticRenderer *r, const ArcticPointLight *lights, uint
     int rc = select_device(r);
     if (rc) return rc;
     uint32_t k = (uint32_t)std::min<uint64_t>(n, r->max_lights);   // renderer.cpp:587-588
-    if (k > MAX_SHADE_LIGHTS) return r->fail(ARCTIC_E_CAPACITY, "update_lights: %u lights exceed the %u the shading kernel stages in LDS", k, MAX_SHADE_LIGHTS);
     HIPCHECK(r, hipStreamSynchronize(r->stream));
     if (k) HIPCHECK(r, hipMemcpy(r->d_lights.p, lights, (size_t)k * sizeof(ArcticPointLight), hipMemcpyHostToDevice));
+    {   // the same lights as pairs for the packed loop (common.h: ShadeParams::light_pairs); an odd count gets a black partner
+        const uint32_t n_pairs = (k + 1) / 2;
+        std::vector<float> pairs((size_t)std::max(1u, n_pairs) * 12, 0.0f);
+        for (uint32_t i = 0; i < 2 * n_pairs; ++i) {
+            float *dst = pairs.data() + (size_t)(i / 2) * 12 + (i & 1);
+            if (i < k) { dst[0] = lights[i].position[0]; dst[2] = lights[i].position[1]; dst[4] = lights[i].position[2];
+                         dst[6] = lights[i].color[0]; dst[8] = lights[i].color[1]; dst[10] = lights[i].color[2]; }
+            else { dst[0] = 0.0f; dst[2] = 1.0e6f; dst[4] = 0.0f; dst[6] = dst[8] = dst[10] = 0.0f; }
+        }
+        HIPCHECK(r, r->d_light_pairs.ensure(pairs.size() * 4));
+        HIPCHECK(r, hipMemcpy(r->d_light_pairs.p, pairs.data(), pairs.size() * 4, hipMemcpyHostToDevice));
+    }
     r->n_lights = k;
     return ARCTIC_OK;
 }
@@ -762,7 +715,7 @@ int arctic_render_frame_device(ArcticRenderer *r, const ArcticScene *scene, cons
     }
     // whole frames skip the G-buffer: the shading pass interpolates from the visibility plane (k_material_vis), bit-identical
     // to visibility -> G-buffer -> shading; arctic_read_gbuffer / arctic_pass_shade materialise the G-buffer afterwards if asked
-    const bool vis_path = r->visbuffer && r->launch.n_bands == 1;
+    const bool vis_path = r->visbuffer;
     if ((rc = vis_path ? pass_visibility(r, scene) : pass_gbuffer(r, scene)) != ARCTIC_OK) return rc;
     return pass_shade(r, scene, settings, d_out, vis_path);
 }
@@ -798,36 +751,22 @@ int arctic_post_process(ArcticRenderer *r, const float *hdr, uint32_t w, uint32_
 
 int arctic_time_shade(ArcticRenderer *r, const ArcticScene *scene, const ArcticSettings *settings, uint32_t warmup, uint32_t iters,
                       float *ms_each) {
-    return arctic_time_shade_split(r, scene, settings, warmup, iters, ms_each, nullptr, nullptr);
-}
-
-int arctic_time_shade_split(ArcticRenderer *r, const ArcticScene *scene, const ArcticSettings *settings, uint32_t warmup,
-                            uint32_t iters, float *ms_each, float *ms_material, float *ms_light) {
     if (!r) return ARCTIC_E_INVALID;
     if (!scene || !settings || !ms_each || iters == 0) return r->fail(ARCTIC_E_INVALID, "time_shade: bad arguments");
-    const bool split = ms_material || ms_light;
-    if (split && r->launch.n_bands != 1) return r->fail(ARCTIC_E_STATE, "time_shade_split: per-kernel times need ARCTIC_OPT_BANDS = 1");
     int rc = select_device(r);
     if (rc) return rc;
     ShadeParams sp;
     if ((rc = fill_shade_params(r, scene, settings, nullptr, sp)) != ARCTIC_OK) return rc;
-    sp.light_evals = nullptr;
-    for (uint32_t i = 0; i < warmup; ++i) HIPCHECK(r, shade_once(r, sp, r->launch));
-    std::vector<hipEvent_t> ev(3 * (size_t)iters);
+    for (uint32_t i = 0; i < warmup; ++i) HIPCHECK(r, shade_once(r, sp, false, false));
+    std::vector<hipEvent_t> ev(2 * (size_t)iters);
     for (auto &e : ev) HIPCHECK(r, hipEventCreate(&e));
     for (uint32_t i = 0; i < iters; ++i) {
-        ShadeLaunch L = r->launch;
-        L.mid = split ? ev[3 * i + 1] : nullptr;
-        HIPCHECK(r, hipEventRecord(ev[3 * i], r->stream));
-        HIPCHECK(r, shade_once(r, sp, L));
-        HIPCHECK(r, hipEventRecord(ev[3 * i + 2], r->stream));
+        HIPCHECK(r, hipEventRecord(ev[2 * i], r->stream));
+        HIPCHECK(r, shade_once(r, sp, false, false));
+        HIPCHECK(r, hipEventRecord(ev[2 * i + 1], r->stream));
     }
     HIPCHECK(r, hipStreamSynchronize(r->stream));
-    for (uint32_t i = 0; i < iters; ++i) {
-        HIPCHECK(r, hipEventElapsedTime(&ms_each[i], ev[3 * i], ev[3 * i + 2]));
-        if (ms_material) HIPCHECK(r, hipEventElapsedTime(&ms_material[i], ev[3 * i], ev[3 * i + 1]));
-        if (ms_light) HIPCHECK(r, hipEventElapsedTime(&ms_light[i], ev[3 * i + 1], ev[3 * i + 2]));
-    }
+    for (uint32_t i = 0; i < iters; ++i) HIPCHECK(r, hipEventElapsedTime(&ms_each[i], ev[2 * i], ev[2 * i + 1]));
     for (auto &e : ev) (void)hipEventDestroy(e);
     r->have_output = true;
     return ARCTIC_OK;
@@ -912,7 +851,7 @@ int arctic_write_shadow_map(ArcticRenderer *r, const float *depth) {
     if (rc) return rc;
     HIPCHECK(r, hipStreamSynchronize(r->stream));
     HIPCHECK(r, hipMemcpy(r->d_shadow.p, depth, (size_t)r->shadow_size * r->shadow_size * 4, hipMemcpyHostToDevice));
-    r->shadow_key.clear();
+    r->shadow_key.clear(); r->bounds_valid = false;
     return ARCTIC_OK;
 }
 
@@ -944,7 +883,7 @@ int arctic_stats(ArcticRenderer *r, uint64_t *out, uint32_t n) {
     if (!r || !out) return ARCTIC_E_INVALID;
     if (select_device(r) == ARCTIC_OK) (void)hipStreamSynchronize(r->stream);
     if (r->h_counts) for (int i = 0; i < 4; ++i) r->stats[i] = r->h_counts[i];
-    for (uint32_t i = 0; i < n && i < 8; ++i) out[i] = r->stats[i];
+    for (uint32_t i = 0; i < n && i < 10; ++i) out[i] = i < 8 ? r->stats[i] : r->light_stats[i - 8];
     return ARCTIC_OK;
 }
 
@@ -952,16 +891,9 @@ int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value) {
     if (!r) return ARCTIC_E_INVALID;
     switch (option) {
     case ARCTIC_OPT_KEEP_FLOAT_OUTPUT: r->keep_float = value != 0; break;
-    case ARCTIC_OPT_COUNT_LIGHT_EVALS: r->count_evals = value == 2 ? 2 : (value != 0); break;
+    case ARCTIC_OPT_COUNT_LIGHT_EVALS: r->count_evals = value != 0; break;
     case ARCTIC_OPT_CULLING: r->culling = value != 0; break;
     case ARCTIC_OPT_DEBUG: r->debug = (int)value; break;
-    case ARCTIC_OPT_FUSED: r->launch.fused = value ? 1u : 0u; r->fused_lds = ~(size_t)0; break;
-    case ARCTIC_OPT_LIGHT_KERNEL:   // tuning: value = lights per loop trip (2 or 4) + 16 * workgroups per CU
-        if ((value & 15) != 2 && (value & 15) != 4) return r->fail(ARCTIC_E_INVALID, "set_option: light kernel variant must be 2 or 4");
-        r->launch.lights_per_trip = (uint32_t)(value & 15);
-        r->fused_lds = ~(size_t)0;
-        if (value >> 4) r->launch.light_blocks = r->cu_count * (uint32_t)(value >> 4);
-        break;
     case ARCTIC_OPT_HDR16: r->hdr16 = value != 0; break;
     case ARCTIC_OPT_VISBUFFER: r->visbuffer = value != 0; break;
     case ARCTIC_OPT_MARKERS:
@@ -969,7 +901,7 @@ int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value) {
         if (value && !g_markers.available()) return r->fail(ARCTIC_E_STATE, "set_option: libroctx64.so could not be loaded");
         break;
     case ARCTIC_OPT_LIGHT_PATH:
-        if (value < 0 || value > 3) return r->fail(ARCTIC_E_INVALID, "set_option: light path must be 0..3");
+        if (value < 0 || value > 2) return r->fail(ARCTIC_E_INVALID, "set_option: light path must be 0..2");
         r->light_path = (int)value;
         break;
     case ARCTIC_OPT_ITEM_TABLE_FLOOR:
@@ -977,10 +909,6 @@ int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value) {
         r->item_cap_floor = (uint32_t)value; r->item_cap = 0;
         break;
     case ARCTIC_OPT_SHADOW_CACHE: r->shadow_cache = value != 0; r->shadow_key.clear(); break;
-    case ARCTIC_OPT_BANDS:
-        if (value < 1 || value > (int64_t)MAX_BANDS) return r->fail(ARCTIC_E_INVALID, "set_option: bands must be 1..%u", MAX_BANDS);
-        r->launch.n_bands = (uint32_t)value;
-        break;
     default: return r->fail(ARCTIC_E_INVALID, "set_option: unknown option %u", option);
     }
     return ARCTIC_OK;

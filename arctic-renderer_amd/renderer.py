@@ -162,13 +162,6 @@ class Renderer:
         self._check(self.L.arctic_time_shade(self.h, C.byref(s), C.byref(st), warmup, iters, _ptr(ms)))
         return ms
 
-    def time_shade_split(self, desc, settings, warmup=5, iters=20):
-        """(total, k_material, k_light) milliseconds per pass, HIP events on the launch stream."""
-        s, st = self._scene(desc), self._settings(settings)
-        ms, a, b = (np.empty(iters, np.float32) for _ in range(3))
-        self._check(self.L.arctic_time_shade_split(self.h, C.byref(s), C.byref(st), warmup, iters, _ptr(ms), _ptr(a), _ptr(b)))
-        return ms, a, b
-
     def read_gbuffer(self, want=("attrs", "material", "depth", "tri")):
         n = (self.rows, self.width)
         attrs = np.empty(n + (18,), np.float32) if "attrs" in want else None
@@ -205,8 +198,8 @@ class Renderer:
         return ldr, hdr, rgba
 
     def stats(self):
-        s = np.zeros(8, np.uint64)
-        self._check(self.L.arctic_stats(self.h, _ptr(s), 8))
+        s = np.zeros(10, np.uint64)
+        self._check(self.L.arctic_stats(self.h, _ptr(s), 10))
         return s
 
     def set_option(self, name, value):

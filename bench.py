@@ -17,9 +17,15 @@ RCCL gather of the finished RGBA8 shards to rank 0 (the path's one real exchange
 overlaps the next step's shading through double buffering; total work is fixed -> "scaling": "strong".
 
 The JSON line also carries
-  roofline     achieved = 80 B x shaded pixels / mean time of the pass's two kernels (HIP events on
-               the launch stream) against the 8 TB/s HBM peak; per-kernel times and rates next to it
-               (k_light, 65 light evaluations per lit pixel, is FP32-VALU bound: SURVEY.md 7.3-1)
+  roofline     the dominant kernel = the pass itself (ONE launch: k_material<loop>): achieved = 80 B x shaded pixels /
+               kernel_ms, kernel_ms = HIP events on the launch stream around the K timed steps / K (the same launches
+               ms_per_step is the wall clock of).  Which roof binds is DERIVED, not assumed: valu_issue_frac = the kernel's
+               vector-issue cycles (SQ_INSTS_VALU and the transcendental count priced with the issue costs measured by
+               tools/experiments/valu_rates.hip) / (1024 SIMDs x clock x kernel_ms), hbm_frac = real HBM bytes / kernel_ms /
+               8 TB/s; both counter inputs are STATIC, read from profiles/pmc_latest.json (collected with rocprofv3 --pmc
+               in separate passes by tools/profile_round.sh) and labelled so.  Also in the line: the same pass with exact
+               culling off (every pixel lit) and with 16 / 4 / 0 point lights (run after the timed loop; --no-extras
+               leaves them out, which is what a rocprofv3 --stats run of this command wants).
   cpu_baseline the CPU oracle (scalar C++ port of the same HLSL math) shading a bounded stripe of
                the SAME G-buffer on this host's cores -- a baseline, not the target.
 """
@@ -37,12 +43,12 @@ import __graft_entry__ as entry  # noqa: E402
 
 BYTES_PER_PIXEL = 80          # 72 B attributes + 4 B material id + 4 B RGBA8
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
-VALU_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: FP32 vector peak = every issue slot a v_pk_fma_f32 (4 flop per lane per 4-cycle slot)
-# the packed light loop, from its ISA (make -C arctic-renderer_amd/csrc asm): per pair of lights 49 v_pk_* + ~4.5 plain VALU
-# (4-cycle issue slots) + 6 transcendentals (v_rsq/v_rcp, 8 cycles = 2 slots each) = 65.5 slots -> 32.75 slots per light
-# evaluation per lane, priced at the peak's 4 flop per slot
-VALU_FLOPS_PER_LIGHT_EVAL = 32.75 * 4
-FP32_PEAK_TFLOPS = 157.3      # vector FP32 (needs packed FMA)
+N_SIMDS = 1024                # 256 CUs x 4
+CLOCK_NOMINAL_GHZ = 2.4       # MI355X_MICROARCH.md: max clock
+# vector-issue cost in cycles per wave64 instruction (profiles/r2_valu_rates.txt, W >= 4 waves per SIMD): the kernel's
+# SQ_INSTS_VALU is priced at the packed/"slow" class cost -- most of its instructions are v_pk_* (4.4) or cvt/min/max/cmp (4.2),
+# plain v_fma/v_mul/v_add (2.6-2.9) are the minority -- and transcendentals (8) at their own
+CYCLES_PER_VALU, CYCLES_PER_TRANS = 4.0, 8.0
 
 
 def log(*a):
@@ -58,8 +64,8 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="<1 shrinks the workload (debug only; makes the number invalid)")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline shades (0 = auto)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--extras", action="store_true", help="also time the pass with culling off and count the executed light evaluations "
-                    "(extra, slower launches of the same kernels: keep them out of a rocprofv3 --stats run of this command)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra passes (culling off, 16 / 4 / 0 lights, light statistics): "
+                    "for a rocprofv3 --stats run of this command, whose kernel average should be the timed launches'")
     args = ap.parse_args()
 
     import torch
@@ -116,8 +122,7 @@ def main():
     frame = frame_ext[:sc.height] if frame_ext is not None else None
     perm = torch.as_tensor(dest, device="cuda") if staging is not None else None
     out_ptrs = [o.data_ptr() for o in outs]
-    if world > 1:
-        r.set_stream(torch.cuda.current_stream().cuda_stream)
+    r.set_stream(torch.cuda.current_stream().cuda_stream)   # the library launches on torch's stream: torch events see its kernels
     state = {"k": 0}
     shade = r.prepared_pass_shade(sc.desc, sc.settings)
 
@@ -141,11 +146,11 @@ def main():
             if pending[b] is not None:
                 finish(b)
 
-    # roofline: the shading pass is ONE kernel by default (k_material<2>: material fetch + shadow test + the light loop for the
-    # lit pixels + tonemap + store; ARCTIC_OPT_LIGHT_PATH), each launch timed with HIP events on the library's stream
-    # (measured first: it also brings clocks and caches to their steady state before the W warm-up steps)
+    # isolated launches, each between its own pair of HIP events (p10/p50/p90 in the line; also brings clocks and caches to
+    # their steady state before the W warm-up steps)
     iters = max(10, min(args.steps, 50))
     ms = r.time_shade(sc.desc, sc.settings, warmup=20, iters=iters)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     for _ in range(args.warmup):
         step()
@@ -155,14 +160,17 @@ def main():
     if world > 1:
         dist.barrier()
     t_start = time.perf_counter()
+    ev0.record()
     for _ in range(args.steps):
         step()
+    ev1.record()
     drain()
     r.flush()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t_start
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps   # HIP events on the launch stream around the K timed launches
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -180,7 +188,7 @@ def main():
             gather_ms = (time.perf_counter() - t0) / 10 * 1e3
         except Exception as exc:   # a measurement extra must never cost the bench line
             log(f"[bench] gather timing skipped: {exc}")
-        r.set_stream(None)
+    r.set_stream(None)
     if world > 1 and rank == 0 and os.environ.get("ARCTIC_BENCH_VERIFY") == "1":
         # the multi-rank invariant, end to end: the gathered, de-interleaved frame == a single-device frame, byte for byte
         full = sc.upload(pkg.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights, device=local))
@@ -200,49 +208,78 @@ def main():
     else:
         shaded = shaded_local
 
-    pass_ms = float(np.mean(ms))
-    achieved = shaded_local * BYTES_PER_PIXEL / (pass_ms * 1e-3) / 1e9
-    # lit pixels of this pass (read back from the stream counters; the kernels run exactly as in the timed loop)
-    r.set_option("count_light_evals", 2)
-    r.pass_shade(sc.desc, sc.settings)
-    r.flush()
-    lit_px = int(r.stats()[6])
-    r.set_option("count_light_evals", 0)
-    light_evals, ms_nocull, split = lit_px * len(sc.lights), None, None   # every lit pixel evaluates every point light (+ the sun)
-    if args.extras:
-        # not in the default run, so that a rocprofv3 --stats average over this command's launches is the timed kernel's:
-        # the same pass with the exact culling disabled (every covered pixel evaluates the sun and all n_lights) ...
-        r.set_option("culling", 0)
-        ms_nocull = float(np.mean(r.time_shade(sc.desc, sc.settings, warmup=2, iters=10)))
-        r.set_option("culling", 1)
-        # ... the light evaluations actually executed, counted with atomics in the loop (wave-level skips included) ...
+    achieved = shaded_local * BYTES_PER_PIXEL / (kernel_ms * 1e-3) / 1e9
+    n_lights = len(sc.lights)
+    extras = {}
+    lit_px = None
+    if not args.no_extras and world == 1:
+        # untimed, after the timed loop.  Light statistics from the counting variant of the kernel:
         r.set_option("count_light_evals", 1)
         r.pass_shade(sc.desc, sc.settings)
         r.flush()
-        light_evals = int(r.stats()[5])
+        st = [int(x) for x in r.stats()]
         r.set_option("count_light_evals", 0)
-        # ... and the alternative path, k_material -> lit-pixel stream -> k_light, timed per kernel
-        r.set_option("light_path", 1)
-        a, b, c = r.time_shade_split(sc.desc, sc.settings, warmup=5, iters=20)
-        split = [round(float(np.mean(x)), 4) for x in (a, b, c)]
-        r.set_option("light_path", 0)
+        lit_px = st[6]
+        extras["light_stats"] = {"lit_pixels": st[6], "point_light_evals": st[5], "evals_with_n_dot_wi_gt_0": st[7],
+                                 "zero_contribution_fraction": round(1.0 - st[7] / max(st[5], 1), 4),
+                                 "lit_tiles": st[9], "tile_light_pairs_all_zero": st[8],
+                                 "tile_cullable_fraction": round(st[8] / max(st[9] * n_lights, 1), 4),
+                                 "note": "exact culling = n.wi <= 0 (forward.hlsl:191-192); tile_cullable = what a per-tile light list could skip"}
+        # the same pass with every pixel lit (exact culling of fully shadowed pixels off) ...
+        r.set_option("culling", 0)
+        ms_all = float(np.mean(r.time_shade(sc.desc, sc.settings, warmup=3, iters=10)))
+        r.set_option("culling", 1)
+        extras["all_pixels_lit"] = {"kernel_ms": round(ms_all, 4), "frac": round(shaded_local * BYTES_PER_PIXEL / (ms_all * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+        # ... and the same G-buffer with the reference's own light counts (MAX_NUM_POINT_LIGHTS = 16) and fewer: the memory-bound regime
+        for n in (16, 4, 0):
+            if n < n_lights:
+                r.update_lights(sc.lights[:n])
+                m = float(np.mean(r.time_shade(sc.desc, sc.settings, warmup=3, iters=20)))
+                extras[f"{n}_point_lights"] = {"kernel_ms": round(m, 4), "frac": round(shaded_local * BYTES_PER_PIXEL / (m * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+        r.update_lights(sc.lights)
     result = None
     if rank == 0:
-        traffic = None
+        pmc, pmc_src = None, None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc_path) and world == 1 and args.scale == 1.0 and args.config == 3:
             try:
-                pmc = json.load(open(pmc_path))
-                traffic = pmc.get("hbm_bytes_per_launch")
+                pmc, pmc_src = json.load(open(pmc_path)), "profiles/pmc_latest.json"
             except Exception:
-                traffic = None
+                pmc = None
+        traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
+        roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                "traffic_source": f"static: {pmc_src}, round {pmc.get('round')} (rocprofv3 --pmc, separate passes; not measured in this run)" if pmc else None,
+                "kernel": f"k_material<{2 if n_lights > 16 else 1}> (the whole pass in one launch: material fetch, shadow test, "
+                          f"{'packed' if n_lights > 16 else 'scalar'} light loop, tonemap, store)",
+                "kernel_ms": round(kernel_ms, 4),
+                "kernel_ms_source": "HIP events on the launch stream around the K timed steps / K",
+                "isolated_launch_ms_p10_p50_p90": [round(float(np.percentile(ms, q)), 4) for q in (10, 50, 90)],
+                "bytes_per_pixel": BYTES_PER_PIXEL}
+        if lit_px is not None:
+            roof["lit_pixel_fraction"] = round(lit_px / max(shaded_local, 1), 4)
+            roof["Gevals_per_s"] = round(lit_px * n_lights / (kernel_ms * 1e-3) / 1e9, 1)
+        if pmc and pmc.get("SQ_INSTS_VALU"):
+            # which roof binds, from the counters: vector-issue cycles against the cycles the launch had, real HBM bytes against 8 TB/s
+            cyc = (pmc["SQ_INSTS_VALU"] - pmc.get("trans_insts", 0)) * CYCLES_PER_VALU + pmc.get("trans_insts", 0) * CYCLES_PER_TRANS
+            clk = pmc.get("measured_clock_GHz") or CLOCK_NOMINAL_GHZ
+            roof["valu_issue_frac"] = {"nominal_2.4GHz": round(cyc / (N_SIMDS * CLOCK_NOMINAL_GHZ * 1e9 * kernel_ms * 1e-3), 4),
+                                       "measured_clock": round(cyc / (N_SIMDS * clk * 1e9 * kernel_ms * 1e-3), 4), "clock_GHz": clk,
+                                       "SQ_INSTS_VALU": pmc["SQ_INSTS_VALU"], "transcendental_insts": pmc.get("trans_insts"),
+                                       "cycles_per_inst": [CYCLES_PER_VALU, CYCLES_PER_TRANS], "source": f"static: {pmc_src}"}
+            if pmc.get("valu_busy_frac") is not None:
+                roof["valu_issue_frac"]["SQ_ACTIVE_INST_VALU_busy"] = pmc["valu_busy_frac"]
+            roof["hbm_frac"] = round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if traffic else None
+            roof["bound"] = "valu-issue" if roof["valu_issue_frac"]["measured_clock"] > (roof["hbm_frac"] or 0) else "hbm"
+            roof["bound_note"] = "derived: the larger of valu_issue_frac and hbm_frac; achieved/frac stay the algorithmic HBM figure the target is stated in"
+        roof.update(extras)
         value = args.steps * shaded / dt / 1e6
         result = {
             "metric": "Mshaded-pixels/sec at 4K Sponza, 1 dir + 64 point lights; HBM GB/s vs roofline",
             "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[{args.config - 1}]: {sc.name}, {sc.width}x{sc.height}, 1 dir + {len(sc.lights)} point lights, "
+            "config": {"workload": f"BASELINE configs[{args.config - 1}]: {sc.name}, {sc.width}x{sc.height}, 1 dir + {n_lights} point lights, "
                                    f"shadow {sc.shadow_size}^2 PCF 5x5, tonemap {sc.settings[0]}, {len(sc.materials)} materials; shading pass over a resident G-buffer",
                        "triangles": sc.n_triangles, "shaded_pixels": shaded, "sharding": f"{BAND}-row bands round-robin over {world} ranks, RCCL gather to rank 0" if world > 1 else "none",
                        "scale": args.scale,
@@ -250,23 +287,7 @@ def main():
                            "gather_ms": round(gather_ms, 4), "bytes_per_sender": int(pad) * sc.width * 4,
                            "GBps_per_link": round(int(pad) * sc.width * 4 / (gather_ms * 1e-3) / 1e9, 2),
                            "note": "one padded shard per rank into rank 0, timed alone (synchronous), outside the timed steps"}},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "kernel": "k_material<2> (material fetch + shadow test + packed light loop + tonemap: the whole pass)" if len(sc.lights) > 16 else "k_material<1> (the whole pass, scalar light loop)", "kernel_ms": round(pass_ms, 4),
-                         "kernel_ms_p10_p50_p90": [round(float(np.percentile(ms, q)), 4) for q in (10, 50, 90)],
-                         "bytes_per_pixel": BYTES_PER_PIXEL,
-                         "lit_pixel_fraction": round(lit_px / max(shaded_local, 1), 4),
-                         "point_light_evals_per_lit_pixel": round(light_evals / max(lit_px, 1), 2),
-                         "point_light_evals_per_pixel": round(light_evals / max(shaded_local, 1), 2),
-                         "Gevals_per_s": round(light_evals / (pass_ms * 1e-3) / 1e9, 1),
-                         # the other roof: the FP32 vector peak.  The kernel has a memory-bound part (every pixel) and
-                         # a VALU-bound part (the light loop of the lit quarter); this is the loop's share of ALL issue slots of the launch
-                         "valu": {"achieved": round(light_evals * VALU_FLOPS_PER_LIGHT_EVAL / (pass_ms * 1e-3) / 1e12, 1),
-                                  "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s (FMA = 2, issue-slot equivalents of the light loop)",
-                                  "frac": round(light_evals * VALU_FLOPS_PER_LIGHT_EVAL / (pass_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4)},
-                         "kernel_ms_no_culling": round(ms_nocull, 4) if ms_nocull else None,
-                         "achieved_no_culling": round(shaded_local * BYTES_PER_PIXEL / (ms_nocull * 1e-3) / 1e9, 1) if ms_nocull else None,
-                         "stream_path_ms_pass_material_light": split},
+            "roofline": roof,
         }
         if world == 1 and not args.no_cpu:
             result["cpu_baseline"] = cpu_baseline(pkg, sc, r, args.cpu_rows)

@@ -219,12 +219,6 @@ int arctic_post_process(ArcticRenderer *r, const float *hdr_rgba32f, uint32_t w,
 int arctic_time_shade(ArcticRenderer *r, const ArcticScene *scene, const ArcticSettings *settings,
                       uint32_t warmup, uint32_t iters, float *ms_each);
 
-/* same, additionally splitting each pass at the boundary between its two kernels: ms_material = material fetch +
- * shadow + classification (k_material), ms_light = sun + point lights + tonemap over the lit pixels (k_light).
- * Either may be NULL. */
-int arctic_time_shade_split(ArcticRenderer *r, const ArcticScene *scene, const ArcticSettings *settings,
-                            uint32_t warmup, uint32_t iters, float *ms_each, float *ms_material, float *ms_light);
-
 /* ---- read-back / injection for tests ------------------------------------- */
 
 /* G-buffer of this shard, de-tiled to row-major: attrs = rows*width*18 floats
@@ -251,32 +245,33 @@ int arctic_frame_constants(const ArcticScene *scene, float *proj_view, float *li
 
 /* counters of the last frame: [0] setup triangles (forward), [1] raster work
  * items (forward), [2] setup triangles (shadow), [3] raster work items
- * (shadow), [4] reserved, [5] point-light evaluations summed over pixels and
- * [6] lit pixels handed to the light kernel (both only with
- * ARCTIC_OPT_COUNT_LIGHT_EVALS), [7] reserved.  n <= 8. */
+ * (shadow), [4] reserved; with ARCTIC_OPT_COUNT_LIGHT_EVALS: [5] point-light
+ * evaluations summed over lit pixels, [6] lit pixels (1 - shadow != 0),
+ * [7] evaluations with n.wi > 0 (the others contribute exactly 0,
+ * forward.hlsl:191-192), [8] (tile, light) pairs whose n.wi <= 0 in every lit
+ * pixel of the 8x8 tile (what a per-tile light list could skip), [9] tiles
+ * with a lit pixel.  n <= 10. */
 int arctic_stats(ArcticRenderer *r, uint64_t *out, uint32_t n);
 
 /* tuning / debug switches. */
 #define ARCTIC_OPT_KEEP_FLOAT_OUTPUT 1 /* 1 = shade also stores float LDR+HDR planes (tests); 0 = RGBA8 only (bench) */
-#define ARCTIC_OPT_COUNT_LIGHT_EVALS 2 /* 1 = shade counts evaluated lights (stats[5], atomics in the light loop: slower) and lit pixels (stats[6]);
-                                          2 = lit pixels only (read back from the stream counters, the kernels run at full speed) */
-#define ARCTIC_OPT_CULLING           3 /* 0 = evaluate every light for every pixel; 1 = exact wave-level culling (default) */
-#define ARCTIC_OPT_DEBUG             4 /* timing experiments only (wrong images): bit 0 skip material textures, bit 1 skip shadow test, bit 2 skip tonemap */
+#define ARCTIC_OPT_COUNT_LIGHT_EVALS 2 /* 1 = the shading pass runs its counting variant: stats[5..9] (a few atomics per lit tile; slower) */
+#define ARCTIC_OPT_CULLING           3 /* 0 = run the light loop for every covered pixel; 1 (default) = exact culling: fully shadowed pixels skip it
+                                          (every term of ps_main carries 1 - shadow, forward.hlsl:222,230) */
+#define ARCTIC_OPT_DEBUG             4 /* timing experiments only: bit 0 skip material textures, bit 1 skip shadow test, bit 2 skip tonemap (wrong images);
+                                          bit 3 shadow test without the min/max table (same image) */
 #define ARCTIC_OPT_HDR16             6 /* 1 = round ps_main's colour through binary16 before post_process, like the reference's
                                         R16G16B16A16_FLOAT colour target (forward_pass.cpp:149, renderer.cpp:128-144); default 0 = fp32 */
-#define ARCTIC_OPT_LIGHT_KERNEL      7 /* tuning: lights per loop trip of k_light (2 or 4) + 16 * persistent workgroups per CU */
-#define ARCTIC_OPT_FUSED             8 /* 1 = the shading pass as ONE persistent kernel (material and light halves decoupled through LDS queues); 0 = k_material + k_light */
 #define ARCTIC_OPT_SHADOW_CACHE      9 /* 1 (default) = arctic_render_frame redraws the shadow map only when the sun, the objects or the mesh list changed
                                           (byte-compared); 0 = every frame like the reference (renderer.cpp:300-337).  Same image either way. */
 #define ARCTIC_OPT_VISBUFFER        10 /* 1 (default) = arctic_render_frame shades straight from the visibility plane, no 76 B/px G-buffer round trip
                                           (bit-identical image; the G-buffer is materialised later if arctic_read_gbuffer / arctic_pass_shade ask); 0 = via the G-buffer */
 #define ARCTIC_OPT_ITEM_TABLE_FLOOR 11 /* smallest size (entries) of the rasteriser's work-item table, default 4 Mi; the table grows to 4x the largest
                                           count seen.  A frame that overflows it returns ARCTIC_E_CAPACITY from the next synchronising call. */
-#define ARCTIC_OPT_LIGHT_PATH       12 /* how the lit pixels reach the light loop: 0 = automatic (default: inline, scalar loop up to 16 point lights, packed
-                                          pairs above), 1 = k_material -> lit-pixel stream -> k_light, 2 = inline scalar, 3 = inline packed.
-                                          Same formulas (images agree to fp32 rounding, ~1e-7). */
+#define ARCTIC_OPT_LIGHT_PATH       12 /* the light loop of the shading kernel: 0 = automatic (default: scalar up to 16 point lights -- the reference's
+                                          MAX_NUM_POINT_LIGHTS -- packed pairs above), 1 = scalar fp32, lights through the scalar cache, 2 = two lights at a
+                                          time in packed fp32 from LDS.  Same formulas (images agree to fp32 rounding, ~1e-7). */
 #define ARCTIC_OPT_MARKERS          13 /* 1 = roctx ranges around each pass, named like the reference's Tracy zones (process-wide; libroctx64 is loaded on demand) */
-#define ARCTIC_OPT_BANDS             5 /* 1..16 interleaved screen bands the two shading kernels are pipelined over (default 1: no gain measured) */
 int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value);
 
 /* library/ABI version: major*10000 + minor*100 + patch */

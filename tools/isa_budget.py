@@ -1,0 +1,77 @@
+"""Per-basic-block instruction census of one kernel from hipcc's -save-temps ISA (make -C arctic-renderer_amd/csrc asm).
+usage: python tools/isa_budget.py /tmp/shade-hip-amdgcn-amd-amdhsa-gfx950.s k_materialILi2E [--dump]
+Classes: valu (v_* except the next three), pk (v_pk_*), trans (v_rcp/rsq/sqrt/exp/log/sin/cos: 8-cycle issue),
+sel (v_cndmask), salu (s_*), vmem (global_/buffer_/flat_), lds (ds_*).  Cycles = issue cost from
+tools/experiments/valu_rates.hip (4 per VALU, 8 per transcendental)."""
+import re, sys, collections
+
+def kernel_text(path, key):
+    lines = open(path).read().split("\n")
+    start = None
+    for i, l in enumerate(lines):
+        if start is None and re.match(r"^_Z\w*%s\w*:" % re.escape(key), l):
+            start = i
+        elif start is not None and (l.startswith("\t.end_amdhsa_kernel") or l.startswith(".Lfunc_end")):
+            return lines[start:i]
+    raise SystemExit("kernel not found")
+
+def classify(op):
+    if op.startswith("v_pk_"): return "pk"
+    if re.match(r"v_(rcp|rsq|sqrt|exp|log|sin|cos)_", op): return "trans"
+    if op.startswith("v_cndmask"): return "sel"
+    if op.startswith("v_"): return "valu"
+    if op.startswith("s_"): return "salu"
+    if op.startswith(("global_", "buffer_", "flat_", "scratch_")): return "vmem"
+    if op.startswith("ds_"): return "lds"
+    return "other"
+
+def max_vgpr_per_block(path, key):
+    """highest VGPR index touched per basic block: where the kernel's register count comes from"""
+    txt = kernel_text(path, key)
+    cur, out = "entry", []
+    mx = -1
+    for l in txt[1:]:
+        m = re.match(r"^(\.LBB\d+_\d+):", l)
+        if m:
+            out.append((cur, mx)); cur = m.group(1); mx = -1; continue
+        s = l.strip()
+        if not s or s.startswith((";", ".")): continue
+        for a, b in re.findall(r"v\[(\d+):(\d+)\]", s): mx = max(mx, int(b))
+        for a in re.findall(r"\bv(\d+)\b", s): mx = max(mx, int(a))
+    out.append((cur, mx))
+    return out
+
+def main():
+    path, key = sys.argv[1], sys.argv[2]
+    if "--vgpr" in sys.argv:
+        for name, mx in max_vgpr_per_block(path, key):
+            if mx >= 0: print(f"{name:12s} max v{mx}")
+        return
+    dump = "--dump" in sys.argv
+    txt = kernel_text(path, key)
+    blocks, cur = [], ["entry", collections.Counter(), []]
+    for l in txt[1:]:
+        m = re.match(r"^(\.LBB\d+_\d+):", l)
+        if m:
+            blocks.append(cur); cur = [m.group(1), collections.Counter(), []]; continue
+        s = l.strip()
+        if not s or s.startswith((";", ".", "//")): continue
+        op = s.split()[0]
+        c = classify(op)
+        cur[1][c] += 1
+        cur[2].append(s)
+    blocks.append(cur)
+    tot = collections.Counter()
+    print(f"{'block':12s} {'valu':>5s} {'pk':>5s} {'trans':>5s} {'sel':>5s} {'salu':>5s} {'vmem':>5s} {'lds':>5s}  vector-issue cycles")
+    for name, c, ins in blocks:
+        if not sum(c.values()): continue
+        cyc = 4 * (c['valu'] + c['pk'] + c['sel']) + 8 * c['trans']
+        print(f"{name:12s} {c['valu']:5d} {c['pk']:5d} {c['trans']:5d} {c['sel']:5d} {c['salu']:5d} {c['vmem']:5d} {c['lds']:5d}  {cyc}")
+        tot.update(c)
+        if dump:
+            for s in ins: print("      " + s)
+    print(f"{'total':12s} {tot['valu']:5d} {tot['pk']:5d} {tot['trans']:5d} {tot['sel']:5d} {tot['salu']:5d} {tot['vmem']:5d} {tot['lds']:5d}")
+
+if __name__ == "__main__":
+    main()
+
