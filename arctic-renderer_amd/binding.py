@@ -11,7 +11,7 @@ import re
 from .scene import CCreateInfo, CScene, CSettings
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libarctic_hip.so")
+LIB_PATH = os.environ.get("ARCTIC_HIP_LIBRARY") or os.path.join(HERE, "csrc", "libarctic_hip.so")   # the override is for A/B timing of two builds (tools/experiments)
 HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "arctic_hip.h")
 
 OPTIONS = {"keep_float_output": 1, "count_light_evals": 2, "culling": 3, "debug": 4, "hdr16": 6, "shadow_cache": 9, "visbuffer": 10, "item_table_floor": 11, "light_path": 12, "markers": 13}

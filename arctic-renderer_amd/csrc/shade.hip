@@ -75,14 +75,29 @@ __device__ __forceinline__ void wrap_axis(float u, uint32_t n, int &i0, int &i1,
 //   word 0 = diffuse.r | diffuse.g << 8 | diffuse.b << 16 | normal.r << 24
 //   word 1 = normal.g | normal.b << 8 | metal_rough.g << 16 | metal_rough.b << 24
 struct TexS { const uint8_t *texels; uint32_t w, h, packed; };
+// The descriptor is fetched with an explicit s_load: written as a plain load the compiler sinks it into the `mat == m` branch
+// of the waterfall loop, replaces the uniform m by the per-lane mat it equals there, and issues a vector load per lane.
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ TexS tex_desc(const TexDesc *tex, uint32_t i /* wave-uniform */) {
-    const uint4 v = reinterpret_cast<const uint4 *>(tex)[i];   // s_load_dwordx4
+    u4v v;
+    asm("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(tex + i));   // not volatile: a side-effecting asm would stop the compiler from using scalar loads for the lights
     TexS t;
     t.texels = reinterpret_cast<const uint8_t *>(((unsigned long long)v.y << 32) | v.x);
     t.w = v.z & 0x7FFFFFFFu; t.h = v.w;
     t.packed = v.z >> 31;   // TexDesc::w bit 31
     return t;
 }
+
+// load through a WAVE-UNIFORM base pointer (SGPR pair) and a 32-bit per-lane byte offset: one global_load with the saddr
+// form, no 64-bit address arithmetic per lane.  (Pointers rebuilt from descriptor words would otherwise be generic: flat_load.)
+typedef const char __attribute__((address_space(1))) *gchar;
+typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));   // 16 bytes at a 4-byte aligned address: gfx950 runs in unaligned-access mode
+__device__ __forceinline__ uint32_t gload_u32(const void *base, uint32_t o) { return *(const uint32_t __attribute__((address_space(1))) *)((gchar)base + o); }
+__device__ __forceinline__ uint2 gload_u2(const void *base, uint32_t o) { const u2v v = *(const u2v __attribute__((address_space(1))) *)((gchar)base + o); return make_uint2(v.x, v.y); }
+__device__ __forceinline__ float2 gload_f2(const void *base, uint32_t o) { const f2v v = *(const f2v __attribute__((address_space(1))) *)((gchar)base + o); return make_float2(v.x, v.y); }
+__device__ __forceinline__ float4u gload_f4u(const void *base, uint32_t o) { return *(const float4u __attribute__((address_space(1))) *)((gchar)base + o); }
 
 // bilinear footprint of a lane: four texels (8 bytes each when packed, else 4) + weights.  Byte offsets are 32-bit (images
 // are at most 16384^2 texels of 8 bytes), so a load is one global_load with the descriptor's base in SGPRs.
@@ -97,11 +112,11 @@ __device__ __forceinline__ void fetch_taps(const TexS &d, float u, float v, Taps
     const uint32_t o00 = (r0 + (uint32_t)x0) * TEXEL_BYTES, o10 = (r0 + (uint32_t)x1) * TEXEL_BYTES;
     const uint32_t o01 = (r1 + (uint32_t)x0) * TEXEL_BYTES, o11 = (r1 + (uint32_t)x1) * TEXEL_BYTES;
     if (TEXEL_BYTES == 8) {
-        t.q00 = *reinterpret_cast<const uint2 *>(d.texels + o00); t.q10 = *reinterpret_cast<const uint2 *>(d.texels + o10);
-        t.q01 = *reinterpret_cast<const uint2 *>(d.texels + o01); t.q11 = *reinterpret_cast<const uint2 *>(d.texels + o11);
+        t.q00 = gload_u2(d.texels, o00); t.q10 = gload_u2(d.texels, o10);
+        t.q01 = gload_u2(d.texels, o01); t.q11 = gload_u2(d.texels, o11);
     } else {
-        t.q00.x = *reinterpret_cast<const uint32_t *>(d.texels + o00); t.q10.x = *reinterpret_cast<const uint32_t *>(d.texels + o10);
-        t.q01.x = *reinterpret_cast<const uint32_t *>(d.texels + o01); t.q11.x = *reinterpret_cast<const uint32_t *>(d.texels + o11);
+        t.q00.x = gload_u32(d.texels, o00); t.q10.x = gload_u32(d.texels, o10);
+        t.q01.x = gload_u32(d.texels, o01); t.q11.x = gload_u32(d.texels, o11);
         t.q00.y = t.q10.y = t.q01.y = t.q11.y = 0u;
     }
     const float gx = 1.0f - fx, gy = 1.0f - fy;
@@ -142,9 +157,6 @@ __device__ __noinline__ float shadow_generic(const float *__restrict__ map, uint
     return shadow / 25.0f;
 }
 
-// 16-byte load from a 4-byte aligned address (gfx950 runs in unaligned-access mode: one global_load_dwordx4)
-typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));
-
 // The 25 taps are 1e-4 apart in uv (0.4 texel at S = 4000), so with their bilinear neighbours they touch at most a 4x4
 // texel window whenever S <= 5000.  Every bilinear result lies in [min, max] of the texels it reads (an fmaf lerp with a
 // weight in [0,1) cannot leave the interval of its operands), so
@@ -181,11 +193,8 @@ __device__ __forceinline__ float shadow_window(const float *__restrict__ map, ui
     const bool ok = u0 >= 0.0f && u4 < 1.0f && v0 >= 0.0f && v4 < 1.0f && xa >= 0.0f && ya >= 0.0f && xb - xa <= 2.0f && yb - ya <= 2.0f &&
                     xa + 3.0f < Sf && ya + 3.0f < Sf;
     if (!ok) return shadow_generic(map, S, px, py, pz);
-    const float *base = map + ((uint32_t)(int)ya * S + (uint32_t)(int)xa);
-    const float4u w0 = *reinterpret_cast<const float4u *>(base);
-    const float4u w1 = *reinterpret_cast<const float4u *>(base + S);
-    const float4u w2 = *reinterpret_cast<const float4u *>(base + 2 * S);
-    const float4u w3 = *reinterpret_cast<const float4u *>(base + 3 * S);
+    const uint32_t o0 = ((uint32_t)(int)ya * S + (uint32_t)(int)xa) * 4u;   // byte offset: maps are at most 16384^2 floats
+    const float4u w0 = gload_f4u(map, o0), w1 = gload_f4u(map, o0 + S * 4u), w2 = gload_f4u(map, o0 + S * 8u), w3 = gload_f4u(map, o0 + S * 12u);
     const float lo = fminf(fminf(fminf(fminf(w0.x, w0.y), fminf(w0.z, w0.w)), fminf(fminf(w1.x, w1.y), fminf(w1.z, w1.w))),
                            fminf(fminf(fminf(w2.x, w2.y), fminf(w2.z, w2.w)), fminf(fminf(w3.x, w3.y), fminf(w3.z, w3.w))));
     const float hi = fmaxf(fmaxf(fmaxf(fmaxf(w0.x, w0.y), fmaxf(w0.z, w0.w)), fmaxf(fmaxf(w1.x, w1.y), fmaxf(w1.z, w1.w))),
@@ -236,7 +245,7 @@ __device__ __forceinline__ bool shadow_quick(const ShadeParams &sp, float lsx, f
     if (sp.shadow_bounds == nullptr) return false;   // S > 5000 (host), or the table is switched off
     const Window w = shadow_footprint(sp.shadow_size, p.px, p.py);
     if (!w.ok) return false;
-    const float2 mm = sp.shadow_bounds[(uint32_t)(w.by >> 2) * sp.bounds_pitch + (uint32_t)(w.bx >> 2)];
+    const float2 mm = gload_f2(sp.shadow_bounds, ((uint32_t)(w.by >> 2) * sp.bounds_pitch + (uint32_t)(w.bx >> 2)) * 8u);
     if (p.pz > mm.y) { lit = 0.0f; return true; }
     return !(p.pz > mm.x);
 }
@@ -383,10 +392,25 @@ __device__ __forceinline__ PackedPix pack_pix(const LoopPix &p) {
     k.q21 = (v2){p.q2, p.q1}; k.q0_ = (v2){p.q0, 0.0f};
     return k;
 }
-// light_scalars<true> for the two point lights of a pair (positions lx, ly, lz and colours cr, cg, cb in SGPR pairs):
-// lane-wise the same arithmetic as the scalar loop.  nd (n . d of both lights) is returned for the statistics.
-__device__ __forceinline__ v2 accumulate_pair(const PackedPix &k, v2 lx, v2 ly, v2 lz, v2 cr, v2 cg, v2 cb, Sums2 &S) {
-    const v2 dx = pk_sub_sb<0>(lx, k.w_xy), dy = pk_sub_sb<1>(ly, k.w_xy), dz = pk_sub_sb<0>(lz, k.wz_a2);
+// scalar loads of one light pair, and the wait that makes them usable (tied to the registers, so every use comes after it)
+typedef float f4v __attribute__((ext_vector_type(4)));
+// (volatile: the two statements keep their order, so the wait never covers loads issued after it in program order)
+__device__ __forceinline__ void load_light_pair(const char *p /* wave-uniform */, f4v &A, f4v &B, f4v &C) {
+    asm volatile("s_load_dwordx4 %0, %3, 0x0\n\ts_load_dwordx4 %1, %3, 0x10\n\ts_load_dwordx4 %2, %3, 0x20" : "=&s"(A), "=&s"(B), "=&s"(C) : "s"(p));
+}
+// d = l - world for the three components of a light pair, behind the s_waitcnt that makes the pair's SGPRs valid: every
+// other use of the pair depends on d, so it is ordered after the wait by data flow
+__device__ __forceinline__ void wait_and_sub(v2 lx, v2 ly, v2 lz, v2 w_xy, v2 wz, v2 &dx, v2 &dy, v2 &dz) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                 "v_pk_add_f32 %0, %3, %6 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                 "v_pk_add_f32 %1, %4, %6 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                 "v_pk_add_f32 %2, %5, %7 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]"
+                 : "=&v"(dx), "=&v"(dy), "=&v"(dz) : "s"(lx), "s"(ly), "s"(lz), "v"(w_xy), "v"(wz));
+}
+
+// light_scalars<true> for the two point lights of a pair (d = position - world from wait_and_sub, colours cr, cg, cb in SGPR
+// pairs): lane-wise the same arithmetic as the scalar loop.  nd (n . d of both lights) is returned for the statistics.
+__device__ __forceinline__ v2 accumulate_pair(const PackedPix &k, v2 dx, v2 dy, v2 dz, v2 cr, v2 cg, v2 cb, Sums2 &S) {
     const v2 d2 = pk_fma(dz, dz, pk_fma(dy, dy, dx * dx));
     v2 ndx;                                                                     // n.x d.x, in the shadow of the rsq
     const v2 inv = rsq2_and_mul_b0(d2, dx, k.n_xy, ndx);
@@ -520,8 +544,13 @@ __device__ __forceinline__ void shade_tile(const ShadeParams &sp, const float *l
     f3 base = mk(0.0f, 0.0f, 0.0f);
     bool plain = false;   // lane's material is stored as three plain RGBA8 images (unequal sizes): the cold path
     auto fetch_material = [&]() {
-        pt.q00 = pt.q10 = pt.q01 = pt.q11 = make_uint2(0x808080u, 0u); pt.w00 = pt.w10 = pt.w01 = pt.w11 = 0.25f;
-        if (sp.debug & 1) return;
+        // an empty asm "writes" every component: nothing of an earlier fetch stays live across the shadow test's slow path
+        asm("" : "=v"(pt.q00.x), "=v"(pt.q00.y), "=v"(pt.q10.x), "=v"(pt.q10.y), "=v"(pt.q01.x), "=v"(pt.q01.y), "=v"(pt.q11.x), "=v"(pt.q11.y));
+        asm("" : "=v"(pt.w00), "=v"(pt.w10), "=v"(pt.w01), "=v"(pt.w11));
+        if (sp.debug & 1) {   // timing only: no texture traffic
+            pt.q00 = pt.q10 = pt.q01 = pt.q11 = make_uint2(0x808080u, 0u); pt.w00 = pt.w10 = pt.w01 = pt.w11 = 0.25f;
+            return;
+        }
         unsigned long long todo = __ballot(covered);
         while (todo) {   // one trip per distinct material of the tile: almost always one
             const uint32_t m = __builtin_amdgcn_readlane(mat, __ffsll((long long)todo) - 1);
@@ -631,20 +660,33 @@ __device__ __forceinline__ void shade_tile(const ShadeParams &sp, const float *l
             for (int k = 0; k < 3; ++k) { S.a[k] = (v2){0.0f, 0.0f}; S.b[k] = (v2){0.0f, 0.0f}; S.c[k] = (v2){0.0f, 0.0f}; }
             const uint32_t n_pairs = (sp.n_lights + 1) >> 1;
             const PackedPix pk = pack_pix(px);
-            const float4 *lp = sp.light_pairs;   // 3 float4 per pair: {x0,x1,y0,y1} {z0,z1,r0,r1} {g0,g1,b0,b1}; wave-uniform: scalar loads
+            // The light pairs (3 x 16 bytes per pair: {x0,x1,y0,y1} {z0,z1,r0,r1} {g0,g1,b0,b1}) come through the scalar cache into two
+            // sets of SGPRs used alternately: the loads of pair p + 1 are issued before pair p is evaluated (one s_waitcnt per pair,
+            // hundreds of cycles after its loads).  Written as asm because the compiler's own version addresses every dword separately
+            // (40 scalar instructions per trip) and waits right after issuing.
+            const char *lp = reinterpret_cast<const char *>(sp.light_pairs);
+            auto finish = [&](v2 dx, v2 dy, v2 dz, const f4v &Bq, const f4v &C, uint32_t p) {
+                const v2 nd = accumulate_pair(pk, dx, dy, dz, (v2){Bq.z, Bq.w}, (v2){C.x, C.y}, (v2){C.z, C.w}, S);
+                if (STATS) {
+                    const bool second = 2 * p + 1 < sp.n_lights;
+                    const unsigned long long m0 = __ballot(nd.x > 0.0f), m1 = second ? __ballot(nd.y > 0.0f) : ~0ull;
+                    contributing += __popcll(m0) + (second ? __popcll(m1) : 0);
+                    wave_zero += (m0 == 0ull ? 1 : 0) + (m1 == 0ull ? 1 : 0);
+                }
+            };
             if (n_pairs) {
-                float4 A = lp[0], Bq = lp[1], C = lp[2];
-                for (uint32_t p = 0; p < n_pairs; ++p) {
-                    const v2 lx = {A.x, A.y}, ly = {A.z, A.w}, lz = {Bq.x, Bq.y}, cr = {Bq.z, Bq.w}, cg = {C.x, C.y}, cb = {C.z, C.w};
-                    const uint32_t pn = min(p + 1, n_pairs - 1);   // the next pair is in flight while this one is evaluated
-                    A = lp[3 * pn]; Bq = lp[3 * pn + 1]; C = lp[3 * pn + 2];
-                    const v2 nd = accumulate_pair(pk, lx, ly, lz, cr, cg, cb, S);
-                    if (STATS) {
-                        const bool second = 2 * p + 1 < sp.n_lights;
-                        const unsigned long long m0 = __ballot(nd.x > 0.0f), m1 = second ? __ballot(nd.y > 0.0f) : ~0ull;
-                        contributing += __popcll(m0) + (second ? __popcll(m1) : 0);
-                        wave_zero += (m0 == 0ull ? 1 : 0) + (m1 == 0ull ? 1 : 0);
-                    }
+                f4v A0, B0, C0, A1, B1, C1;
+                v2 dx, dy, dz;
+                load_light_pair(lp, A0, B0, C0);
+                for (uint32_t p = 0;;) {
+                    wait_and_sub((v2){A0.x, A0.y}, (v2){A0.z, A0.w}, (v2){B0.x, B0.y}, pk.w_xy, pk.wz_a2, dx, dy, dz);   // set 0 has landed
+                    if (p + 1 < n_pairs) load_light_pair(lp + 48 * (p + 1), A1, B1, C1);                                  // set 1 in flight
+                    finish(dx, dy, dz, B0, C0, p);
+                    if (++p == n_pairs) break;
+                    wait_and_sub((v2){A1.x, A1.y}, (v2){A1.z, A1.w}, (v2){B1.x, B1.y}, pk.w_xy, pk.wz_a2, dx, dy, dz);
+                    if (p + 1 < n_pairs) load_light_pair(lp + 48 * (p + 1), A0, B0, C0);
+                    finish(dx, dy, dz, B1, C1, p);
+                    if (++p == n_pairs) break;
                 }
             }
             float A[3], Bs[3], Cs[3];
@@ -691,9 +733,8 @@ __global__ __launch_bounds__(256) void k_material(const ShadeParams sp) {
     // each row left to right, so horizontal neighbours -- which share texture and shadow-map cache lines -- meet in the
     // same L2, while all eight XCDs stay within 8 tile rows of each other in the G-buffer stream.  (Placement is a speed
     // matter only; the grid is padded to whole groups of 8 rows and surplus blocks exit.)
-    const uint32_t bpr = (sp.tiles_x + 3) >> 2;                       // workgroups per tile row
-    const uint32_t xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
-    const uint32_t ty = (idx / bpr) * 8 + xcd, tx = (idx % bpr) * 4 + wave;
+    // grid = (8 x workgroups per tile row, groups of 8 tile rows): the linear block id advances along x first, so id % 8 = x % 8
+    const uint32_t ty = blockIdx.y * 8 + (blockIdx.x & 7u), tx = (blockIdx.x >> 3) * 4 + wave;
     const bool tile_ok = ty < sp.tiles_y && tx < sp.tiles_x;
     const size_t gi = ((size_t)ty * sp.tiles_x + tx) * 64 + lane;
     TileHead cur;
@@ -716,9 +757,7 @@ __global__ __launch_bounds__(256) void k_material_vis(const ShadeParams sp) {
     __shared__ float lut[256];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t bpr = (sp.tiles_x + 3) >> 2;
-    const uint32_t xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;   // XCD-aware order: see k_material
-    const uint32_t ty = (idx / bpr) * 8 + xcd, tx = (idx % bpr) * 4 + wave;
+    const uint32_t ty = blockIdx.y * 8 + (blockIdx.x & 7u), tx = (blockIdx.x >> 3) * 4 + wave;   // XCD-aware order: see k_material
     const bool tile_ok = ty < sp.tiles_y && tx < sp.tiles_x;
     const size_t gi = ((size_t)ty * sp.tiles_x + tx) * 64 + lane;
     unsigned long long key = ~0ull;
@@ -793,7 +832,7 @@ __global__ __launch_bounds__(256) void k_post_process(const float4 *__restrict__
 }
 
 template <int LOOP, bool STATS>
-hipError_t launch_variant(const ShadeParams &sp, const ShadeLaunch &L, uint32_t grid) {
+hipError_t launch_variant(const ShadeParams &sp, const ShadeLaunch &L, dim3 grid) {
     if (L.from_vis) k_material_vis<LOOP, STATS><<<grid, 256, 0, L.stream>>>(sp);
     else k_material<LOOP, STATS><<<grid, 256, 0, L.stream>>>(sp);
     return hipGetLastError();
@@ -807,7 +846,7 @@ hipError_t launch_shade(const ShadeParams &sp, const ShadeLaunch &L) {
     const uint32_t n_tiles = sp.tiles_x * sp.tiles_y;
     if (n_tiles == 0) return hipSuccess;
     const uint32_t bpr = (sp.tiles_x + 3) / 4, row_groups = (sp.tiles_y + 7) / 8;
-    const uint32_t grid = row_groups * 8 * bpr;
+    const dim3 grid(8 * bpr, row_groups);
     if (L.loop == 2) return L.stats ? launch_variant<2, true>(sp, L, grid) : launch_variant<2, false>(sp, L, grid);
     return L.stats ? launch_variant<1, true>(sp, L, grid) : launch_variant<1, false>(sp, L, grid);
 }

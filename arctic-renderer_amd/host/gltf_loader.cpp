@@ -283,7 +283,7 @@ std::vector<uint8_t> decode_jpeg(const uint8_t *data, size_t size, uint32_t &w, 
     JpegHuff dc[4], ac[4];
     struct Comp { int id = 0, hs = 1, vs = 1, tq = 0, td = 0, ta = 0, pred = 0, bw = 0, bh = 0; std::vector<uint8_t> plane; } comp[3];
     int ncomp = 0, restart = 0, hmax = 1, vmax = 1;
-    bool have_sof = false;
+    bool have_sof = false, have_dc[4] = {false, false, false, false}, have_ac[4] = {false, false, false, false};
     size_t pos = 2;
     auto be16 = [&](size_t o) { if (o + 2 > size) fail("JPEG: truncated"); return (int)((data[o] << 8) | data[o + 1]); };
     for (;;) {
@@ -300,14 +300,17 @@ std::vector<uint8_t> decode_jpeg(const uint8_t *data, size_t size, uint32_t &w, 
         if (m == 0xDB) {   // DQT
             for (int o = 0; o < n;) {
                 const int pq = seg[o] >> 4, tq = seg[o] & 15; ++o;
-                if (tq > 3) fail("JPEG: bad quantisation table id");
+                if (tq > 3 || pq > 1) fail("JPEG: bad quantisation table id");
+                if (o + (pq ? 128 : 64) > n) fail("JPEG: truncated quantisation table");
                 for (int i = 0; i < 64; ++i) { qt[tq][zz[i]] = pq ? (uint16_t)((seg[o] << 8) | seg[o + 1]) : seg[o]; o += pq ? 2 : 1; }
             }
         } else if (m == 0xC4) {   // DHT
             for (int o = 0; o < n;) {
                 const int tc = seg[o] >> 4, th = seg[o] & 15; ++o;
-                if (th > 3) fail("JPEG: bad Huffman table id");
+                if (th > 3 || tc > 1) fail("JPEG: bad Huffman table id");
+                if (o + 16 > n) fail("JPEG: truncated Huffman table");
                 JpegHuff &t = tc ? ac[th] : dc[th];
+                (tc ? have_ac : have_dc)[th] = true;
                 int total = 0;
                 for (int i = 1; i <= 16; ++i) { t.count[i] = seg[o++]; total += t.count[i]; }
                 if (total > 256 || o + total > n) fail("JPEG: bad Huffman table");
@@ -315,9 +318,11 @@ std::vector<uint8_t> decode_jpeg(const uint8_t *data, size_t size, uint32_t &w, 
                 t.build();
             }
         } else if (m == 0xC0 || m == 0xC1) {   // SOF0 / SOF1 (sequential Huffman)
+            if (n < 6) fail("JPEG: truncated frame header");
             if (seg[0] != 8) fail("JPEG: only 8-bit precision is supported");
             h = (uint32_t)((seg[1] << 8) | seg[2]); w = (uint32_t)((seg[3] << 8) | seg[4]); ncomp = seg[5];
             if ((ncomp != 1 && ncomp != 3) || !w || !h) fail("JPEG: unsupported component count or size");
+            if (n < 6 + 3 * ncomp) fail("JPEG: truncated frame header");
             for (int c = 0; c < ncomp; ++c) {
                 comp[c].id = seg[6 + c * 3]; comp[c].hs = seg[7 + c * 3] >> 4; comp[c].vs = seg[7 + c * 3] & 15; comp[c].tq = seg[8 + c * 3];
                 if (comp[c].hs < 1 || comp[c].hs > 2 || comp[c].vs < 1 || comp[c].vs > 2 || comp[c].tq > 3) fail("JPEG: unsupported sampling factors");
@@ -326,16 +331,18 @@ std::vector<uint8_t> decode_jpeg(const uint8_t *data, size_t size, uint32_t &w, 
             have_sof = true;
         } else if (m == 0xC2) fail("JPEG: progressive files are not supported (re-save as baseline or PNG)");
         else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) fail("JPEG: unsupported coding process");
-        else if (m == 0xDD) restart = (seg[0] << 8) | seg[1];
+        else if (m == 0xDD) { if (n < 2) fail("JPEG: truncated restart interval"); restart = (seg[0] << 8) | seg[1]; }
         else if (m == 0xDA) {   // SOS: the one interleaved scan of a baseline file
             if (!have_sof) fail("JPEG: scan before frame header");
-            if (seg[0] != ncomp) fail("JPEG: non-interleaved scans are not supported");
+            if (n < 1 || seg[0] != ncomp) fail("JPEG: non-interleaved scans are not supported");
+            if (n < 1 + 2 * ncomp + 3) fail("JPEG: truncated scan header");
             for (int i = 0; i < ncomp; ++i) {
                 const int id = seg[1 + i * 2];
                 int c = 0;
                 while (c < ncomp && comp[c].id != id) ++c;
                 if (c == ncomp) fail("JPEG: scan refers to an unknown component");
                 comp[c].td = seg[2 + i * 2] >> 4; comp[c].ta = seg[2 + i * 2] & 15;
+                if (comp[c].td > 3 || comp[c].ta > 3 || !have_dc[comp[c].td] || !have_ac[comp[c].ta]) fail("JPEG: scan selects a Huffman table that was never defined");
             }
             pos += (size_t)len;
             break;
@@ -367,11 +374,13 @@ std::vector<uint8_t> decode_jpeg(const uint8_t *data, size_t size, uint32_t &w, 
                     for (int bx = 0; bx < comp[c].hs; ++bx) {
                         float blk[64] = {0};
                         const int t = dc[comp[c].td].decode(br);
+                        if (t > 11) fail("JPEG: bad DC category");
                         comp[c].pred += jpeg_extend(br.bits(t), t);
                         blk[0] = (float)(comp[c].pred * qt[comp[c].tq][0]);
                         for (int k = 1; k < 64;) {
                             const int rs = ac[comp[c].ta].decode(br), r = rs >> 4, sz = rs & 15;
                             if (sz == 0) { if (r == 15) { k += 16; continue; } break; }
+                            if (sz > 10) fail("JPEG: bad AC coefficient size");
                             k += r;
                             if (k > 63) fail("JPEG: coefficient index out of range");
                             blk[zz[k]] = (float)(jpeg_extend(br.bits(sz), sz) * qt[comp[c].tq][zz[k]]);
@@ -497,15 +506,24 @@ struct Loader {
 
     Loader(const Json &d, std::string b) : doc(d), base(std::move(b)) {}
 
+    // every index and offset of the file is untrusted: non-negative and in range before use, ranges checked without overflow
+    static size_t index_of(const Json &j, const char *what) {
+        const double v = j.as_num();
+        if (!(v >= 0.0) || v > 4.0e15 || v != std::floor(v)) fail(std::string("glTF: bad ") + what);
+        return (size_t)v;
+    }
+    static void check_range(size_t off, size_t need, size_t size, const char *what) {
+        if (off > size || need > size - off) fail(std::string("glTF: ") + what + " out of bounds");
+    }
     const std::vector<uint8_t> &buffer(size_t i) {
         const Json &bufs = doc.at("buffers");
+        const Json &b = bufs[i];   // range-checked
         if (buffers.size() < bufs.size()) buffers.resize(bufs.size());
         if (buffers[i].empty()) {
-            const Json &b = bufs[i];
             if (b.has("uri")) buffers[i] = load_uri(b.at("uri").as_str(), base);
             else if (i == 0 && !glb_bin.empty()) buffers[i] = glb_bin;
             else fail("glTF: buffer without uri");
-            if (buffers[i].size() < (size_t)b.at("byteLength").as_int()) fail("glTF: buffer shorter than byteLength");
+            if (buffers[i].size() < index_of(b.at("byteLength"), "byteLength")) fail("glTF: buffer shorter than byteLength");
         }
         return buffers[i];
     }
@@ -518,16 +536,21 @@ struct Loader {
         const auto it = comps.find(a.at("type").as_str());
         if (it == comps.end() || it->second < n_comp) fail("glTF: accessor type mismatch");
         const int file_comp = it->second;
-        const int64_t ct = a.at("componentType").as_int(), count = a.at("count").as_int();
+        const int64_t ct = a.at("componentType").as_int();
+        const size_t count = index_of(a.at("count"), "accessor count");
         const bool norm = a.has("normalized") && a.at("normalized").b;
         const size_t csize = ct == 5126 || ct == 5125 ? 4 : (ct == 5123 || ct == 5122 ? 2 : 1);
-        const Json &bv = doc.at("bufferViews")[(size_t)a.at("bufferView").as_int()];
-        const std::vector<uint8_t> &buf = buffer((size_t)bv.at("buffer").as_int());
-        const size_t off = (size_t)(bv.has("byteOffset") ? bv.at("byteOffset").as_int() : 0) + (size_t)(a.has("byteOffset") ? a.at("byteOffset").as_int() : 0);
-        const size_t stride = bv.has("byteStride") ? (size_t)bv.at("byteStride").as_int() : csize * file_comp;
-        if (count < 0 || off + (count ? (size_t)(count - 1) * stride + csize * file_comp : 0) > buf.size()) fail("glTF: accessor out of bounds");
-        std::vector<float> out((size_t)count * n_comp);
-        for (int64_t i = 0; i < count; ++i)
+        const Json &bv = doc.at("bufferViews")[index_of(a.at("bufferView"), "bufferView index")];
+        const std::vector<uint8_t> &buf = buffer(index_of(bv.at("buffer"), "buffer index"));
+        const size_t off_v = bv.has("byteOffset") ? index_of(bv.at("byteOffset"), "byteOffset") : 0, off_a = a.has("byteOffset") ? index_of(a.at("byteOffset"), "byteOffset") : 0;
+        const size_t stride = bv.has("byteStride") ? index_of(bv.at("byteStride"), "byteStride") : csize * file_comp;
+        const size_t elem = csize * file_comp;
+        if (stride < elem || stride > 65536) fail("glTF: bad byteStride");
+        check_range(off_v, off_a, buf.size(), "accessor");
+        const size_t off = off_v + off_a;
+        if (count) { if (count - 1 > (buf.size() - off) / stride) fail("glTF: accessor out of bounds"); check_range(off, (count - 1) * stride + elem, buf.size(), "accessor"); }
+        std::vector<float> out(count * (size_t)n_comp);
+        for (size_t i = 0; i < count; ++i)
             for (int c = 0; c < n_comp; ++c) {
                 const uint8_t *p = &buf[off + (size_t)i * stride + (size_t)c * csize];
                 float v;
@@ -546,15 +569,18 @@ struct Loader {
 
     std::vector<uint32_t> indices(size_t accessor) {
         const Json &a = doc.at("accessors")[accessor];
-        const int64_t ct = a.at("componentType").as_int(), count = a.at("count").as_int();
+        const int64_t ct = a.at("componentType").as_int();
+        const size_t count = index_of(a.at("count"), "accessor count");
         const size_t csize = ct == 5125 ? 4 : ct == 5123 ? 2 : ct == 5121 ? 1 : 0;
         if (!csize || a.at("type").as_str() != "SCALAR") fail("glTF: bad index accessor");
-        const Json &bv = doc.at("bufferViews")[(size_t)a.at("bufferView").as_int()];
-        const std::vector<uint8_t> &buf = buffer((size_t)bv.at("buffer").as_int());
-        const size_t off = (size_t)(bv.has("byteOffset") ? bv.at("byteOffset").as_int() : 0) + (size_t)(a.has("byteOffset") ? a.at("byteOffset").as_int() : 0);
-        if (count < 0 || off + (size_t)count * csize > buf.size()) fail("glTF: index accessor out of bounds");
-        std::vector<uint32_t> out((size_t)count);
-        for (int64_t i = 0; i < count; ++i) {
+        const Json &bv = doc.at("bufferViews")[index_of(a.at("bufferView"), "bufferView index")];
+        const std::vector<uint8_t> &buf = buffer(index_of(bv.at("buffer"), "buffer index"));
+        const size_t off_v = bv.has("byteOffset") ? index_of(bv.at("byteOffset"), "byteOffset") : 0, off_a = a.has("byteOffset") ? index_of(a.at("byteOffset"), "byteOffset") : 0;
+        check_range(off_v, off_a, buf.size(), "index accessor");
+        const size_t off = off_v + off_a;
+        if (count > (buf.size() - off) / csize) fail("glTF: index accessor out of bounds");
+        std::vector<uint32_t> out(count);
+        for (size_t i = 0; i < count; ++i) {
             const uint8_t *p = &buf[off + (size_t)i * csize];
             if (csize == 4) std::memcpy(&out[(size_t)i], p, 4);
             else if (csize == 2) { uint16_t u; std::memcpy(&u, p, 2); out[(size_t)i] = u; }
@@ -565,17 +591,17 @@ struct Loader {
 
     const Image &image_of_texture(size_t texture) {
         const Json &t = doc.at("textures")[texture];
-        const size_t src = (size_t)t.at("source").as_int();
+        const size_t src = index_of(t.at("source"), "image index");
         auto it = image_cache.find(src);
         if (it != image_cache.end()) return it->second;
         const Json &im = doc.at("images")[src];
         std::vector<uint8_t> file;
         if (im.has("uri")) file = load_uri(im.at("uri").as_str(), base);
         else if (im.has("bufferView")) {
-            const Json &bv = doc.at("bufferViews")[(size_t)im.at("bufferView").as_int()];
-            const std::vector<uint8_t> &buf = buffer((size_t)bv.at("buffer").as_int());
-            const size_t off = bv.has("byteOffset") ? (size_t)bv.at("byteOffset").as_int() : 0, len = (size_t)bv.at("byteLength").as_int();
-            if (off + len > buf.size()) fail("glTF: image bufferView out of bounds");
+            const Json &bv = doc.at("bufferViews")[index_of(im.at("bufferView"), "bufferView index")];
+            const std::vector<uint8_t> &buf = buffer(index_of(bv.at("buffer"), "buffer index"));
+            const size_t off = bv.has("byteOffset") ? index_of(bv.at("byteOffset"), "byteOffset") : 0, len = index_of(bv.at("byteLength"), "byteLength");
+            check_range(off, len, buf.size(), "image bufferView");
             file.assign(buf.begin() + (long)off, buf.begin() + (long)(off + len));
         } else fail("glTF: image without uri or bufferView");
         Image out;
@@ -734,12 +760,13 @@ std::unique_ptr<ArcticGltf> load(const std::string &path) {
     const size_t n_nodes = doc.has("nodes") ? doc.at("nodes").size() : 0;
     std::vector<size_t> roots;
     if (doc.has("scenes") && doc.at("scenes").size()) {
-        const size_t sc = doc.has("scene") ? (size_t)doc.at("scene").as_int() : 0;
+        const size_t sc = doc.has("scene") ? Loader::index_of(doc.at("scene"), "scene index") : 0;
         const Json &s = doc.at("scenes")[sc];
-        if (s.has("nodes")) for (size_t i = 0; i < s.at("nodes").size(); ++i) roots.push_back((size_t)s.at("nodes")[i].as_int());
+        if (s.has("nodes")) for (size_t i = 0; i < s.at("nodes").size(); ++i) roots.push_back(Loader::index_of(s.at("nodes")[i], "node index"));
     }
     struct Item { long node; M4 parent; };   // node -1: the synthetic root assimp creates when the scene has several roots
     std::vector<Item> stack;
+    std::vector<bool> visited(n_nodes, false);   // the spec makes the node graph a forest: a node reached twice is a cycle or a DAG, both refused
     if (roots.size() == 1) stack.push_back({(long)roots[0], identity()});
     else if (!roots.empty()) stack.push_back({-1, identity()});
     while (!stack.empty()) {
@@ -751,10 +778,12 @@ std::unique_ptr<ArcticGltf> load(const std::string &path) {
         if (it.node < 0) { trs = mul(it.parent, identity()); children = roots; }
         else {
             if ((size_t)it.node >= n_nodes) fail("glTF: node index out of range");
+            if (visited[(size_t)it.node]) fail("glTF: node graph is not a tree (a node is reachable twice)");
+            visited[(size_t)it.node] = true;
             const Json &n = doc.at("nodes")[(size_t)it.node];
             trs = mul(it.parent, transpose(node_matrix(n)));
-            if (n.has("children")) for (size_t i = 0; i < n.at("children").size(); ++i) children.push_back((size_t)n.at("children")[i].as_int());
-            if (n.has("mesh")) mesh = (long)n.at("mesh").as_int();
+            if (n.has("children")) for (size_t i = 0; i < n.at("children").size(); ++i) children.push_back(Loader::index_of(n.at("children")[i], "node index"));
+            if (n.has("mesh")) mesh = (long)Loader::index_of(n.at("mesh"), "mesh index");
         }
         for (size_t c : children) stack.push_back({(long)c, trs});
         if (mesh >= 0) {
@@ -767,7 +796,6 @@ std::unique_ptr<ArcticGltf> load(const std::string &path) {
                 g->objects.push_back(o);
             }
         }
-        if (g->objects.size() > 10000000) fail("glTF: node graph too large (cycle?)");
     }
     return g;
 }

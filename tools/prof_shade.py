@@ -1,6 +1,6 @@
 # minimal program for rocprofv3: build config-3 G-buffer once, then launch k_shade a few times
 import sys, numpy as np
-sys.path.insert(0,'/root/repo')
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import __graft_entry__ as e
 pkg=e.load_package()
 mode=sys.argv[1] if len(sys.argv)>1 else "full"
