@@ -148,8 +148,9 @@ struct ShadeLaunch {
     uint32_t stats;      // 1: the counting variant (ShadeParams::stats)
 };
 constexpr uint32_t N_SHADE_STATS = 5;
-// the shadow-bounds table: one entry per 4x4 texel block; only for maps the 4x4 window argument covers (S <= 5000)
-inline uint32_t shadow_bounds_pitch(uint32_t S) { return S >= 4 && S <= 5000 ? (S + 3) / 4 : 0; }
+// the shadow-bounds table: one entry per 4x4 texel block; only for maps whose 25 PCF taps (4e-4 S apart end to end, in fp32)
+// span less than 2 texels, so that a footprint never leaves the 4x4 window behind its first texel
+inline uint32_t shadow_bounds_pitch(uint32_t S) { return S >= 4 && S <= 4900 ? (S + 3) / 4 : 0; }
 
 // ---- kernel launchers (geometry.hip, shade.hip) ---------------------------------------------
 // every launcher enqueues on `s` and returns the launch error, never synchronises.

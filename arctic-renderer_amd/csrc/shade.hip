@@ -164,25 +164,13 @@ __device__ __noinline__ float shadow_generic(const float *__restrict__ map, uint
 // decided without filtering, exactly.  Two levels of that test:
 //   shadow_quick   bounds from the precomputed table (k_shadow_bounds): entry (i, j) = min/max over texels [4i, 4i+8) x
 //                  [4j, 4j+8), which contains the 4x4 window of every footprint whose first texel is in [4i, 4i+4)^2:
-//                  ONE 8-byte load per pixel, taps 0 and 4 are the only coordinates needed;
+//                  ONE 8-byte load per pixel, tap 0 is the only coordinate needed;
 //   shadow_window  (tiles on a shadow edge) loads the window itself (4 x 16 B), tests its own min/max, and otherwise
 //                  evaluates the 25 bilinear compares from registers in the oracle's operation order (horizontal lerps are
 //                  shared between taps, which does not change any tap's value).
 // Lanes near the map border (WRAP would engage) or with a wider footprint use shadow_generic.
-struct Window { int bx, by; bool ok; };
-__device__ __forceinline__ Window shadow_footprint(uint32_t S, float px, float py) {
-#pragma clang fp contract(off)
-    // taps i = 0 and i = 4 bound the footprint: u_i = px + (i - 2) * 1e-4 is monotone in i, and so is floor(u_i * S - 0.5)
-    const float Sf = (float)S;
-    const float xa = floorf((px + -0.0002f) * Sf - 0.5f), xb = floorf((px + 0.0002f) * Sf - 0.5f);
-    const float ya = floorf((py + -0.0002f) * Sf - 0.5f), yb = floorf((py + 0.0002f) * Sf - 0.5f);
-    Window w;
-    w.bx = (int)xa; w.by = (int)ya;
-    // first texel inside the map with three more to its right / below (no WRAP: implies 0 <= u_0 and u_4 < 1), at most
-    // 3 texel columns / rows between the first and the last tap
-    w.ok = xa >= 0.0f && ya >= 0.0f && xb - xa <= 2.0f && yb - ya <= 2.0f && xa + 3.0f < Sf && ya + 3.0f < Sf;
-    return w;
-}
+// floor and convert in one instruction (exact for |x| < 2^31)
+__device__ __forceinline__ int floor_to_int(float x) { int i; asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(i) : "v"(x)); return i; }
 
 __device__ __forceinline__ float shadow_window(const float *__restrict__ map, uint32_t S, float px, float py, float pz) {
 #pragma clang fp contract(off)
@@ -241,13 +229,20 @@ __device__ __forceinline__ bool shadow_quick(const ShadeParams &sp, float lsx, f
     p.px = p.px * 0.5f + 0.5f;
     p.py = p.py * 0.5f + 0.5f;
     p.py = 1.0f - p.py;
-    if (p.pz > 1.0f || p.px < 0.0f || p.py < 0.0f || p.px > 1.0f || p.py > 1.0f) return true;
-    if (sp.shadow_bounds == nullptr) return false;   // S > 5000 (host), or the table is switched off
-    const Window w = shadow_footprint(sp.shadow_size, p.px, p.py);
-    if (!w.ok) return false;
-    const float2 mm = gload_f2(sp.shadow_bounds, ((uint32_t)(w.by >> 2) * sp.bounds_pitch + (uint32_t)(w.bx >> 2)) * 8u);
-    if (p.pz > mm.y) { lit = 0.0f; return true; }
-    return !(p.pz > mm.x);
+    if (sp.shadow_bounds != nullptr) {   // only for S <= 4900 (shadow_bounds_pitch)
+        // first texel of tap 0 (u_0 = px - 2e-4) per axis.  0 <= bx < S - 3 means: inside the map with three more texels after it,
+        // so 0 < px < 1, no tap wraps, and -- the taps spanning 4e-4 S < 2 texels -- every texel a tap reads lies in [bx, bx + 3]
+        const uint32_t S = sp.shadow_size;
+        const float Sf = (float)S;
+        const int bx = floor_to_int((p.px + -0.0002f) * Sf - 0.5f), by = floor_to_int((p.py + -0.0002f) * Sf - 0.5f);
+        if ((uint32_t)bx < S - 3u && (uint32_t)by < S - 3u && !(p.pz > 1.0f)) {
+            const float2 mm = gload_f2(sp.shadow_bounds, (((uint32_t)by >> 2) * sp.bounds_pitch + ((uint32_t)bx >> 2)) * 8u);
+            if (p.pz > mm.y) { lit = 0.0f; return true; }
+            return !(p.pz > mm.x);
+        }
+    }
+    // outside the map: no shadow (forward.hlsl:75-77); everything else takes the slow path
+    return p.pz > 1.0f || p.px < 0.0f || p.py < 0.0f || p.px > 1.0f || p.py > 1.0f;
 }
 __device__ __forceinline__ float shadow_slow(const ShadeParams &sp, const ShadowPos &p) {
     const uint32_t S = sp.shadow_size;
@@ -487,7 +482,9 @@ __device__ __forceinline__ float through_half(float x) { return (float)(_Float16
 __device__ __forceinline__ void store_pixel(const ShadeParams &sp, uint32_t o, f3 color) {
     if (sp.hdr16) color = mk(through_half(color.x), through_half(color.y), through_half(color.z));
     const f3 l = (sp.debug & 4) ? color : post_process(color, sp.tm_method, sp.inv_gamma, sp.exposure);   // bit 2: timing only
-    reinterpret_cast<uint32_t *>(sp.out_rgba8)[o] = unorm8(l.x) | (unorm8(l.y) << 8) | (unorm8(l.z) << 16) | 0xFF000000u;
+    // uniform base + 32-bit byte offset (targets are at most 16384^2 pixels): no 64-bit address arithmetic per lane
+    *(uint32_t __attribute__((address_space(1))) *)((char __attribute__((address_space(1))) *)sp.out_rgba8 + o * 4u) =
+        unorm8(l.x) | (unorm8(l.y) << 8) | (unorm8(l.z) << 16) | 0xFF000000u;
     if (sp.out_ldr) { sp.out_ldr[(size_t)o * 3] = l.x; sp.out_ldr[(size_t)o * 3 + 1] = l.y; sp.out_ldr[(size_t)o * 3 + 2] = l.z; }
     if (sp.out_hdr) { sp.out_hdr[(size_t)o * 3] = color.x; sp.out_hdr[(size_t)o * 3 + 1] = color.y; sp.out_hdr[(size_t)o * 3 + 2] = color.z; }
 }

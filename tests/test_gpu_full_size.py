@@ -27,7 +27,7 @@ def prepass_pair(pkg, oracle, hip, sc):
 def assert_prepass_bit_exact(sc, o, r):
     if sc.shadow_size:
         a, b = o.read_shadow_map(), r.read_shadow_map()
-        assert (a < 1.0).mean() > 0.01
+        assert (a < 1.0).mean() > 0.001   # config 2: the models cover half a percent of the +-16 m light window
         np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
     oa, om, od, ot = o.read_gbuffer()
     ha, hm, hd, ht = r.read_gbuffer()
