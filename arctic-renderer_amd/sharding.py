@@ -71,22 +71,25 @@ class _Works:
             q.wait()
 
 
-def gather_rows(shard, gathered, rank, world, root=0, group=None, async_op=False):
+def gather_rows(shard, gathered, rank, world, root=0, group=None, async_op=False, equal_rows=None):
     """gather the (rows_r, width, 4) uint8 shards on `root`; `gathered` is the root's list of per-rank buffers (None
     elsewhere).  Equal shards: one dist.gather (ncclGather); shards differing by a row: send/recv into the root.
-    async_op=True returns an object with .wait() (None when there is nothing to wait for)."""
+    async_op=True returns an object with .wait() (None when there is nothing to wait for).
+    equal_rows: whether every rank's shard has the same number of rows -- something all ranks must agree on, because it selects
+    the collective.  Pass it when the caller knows (bench.py pads every shard to one size: True); None decides with one small
+    all_reduce per call (never cached: a cached answer keyed on the local shape can differ between ranks after a resize)."""
     if world == 1:
         return None if async_op else shard
     if shard.is_cuda and dist.get_backend(group) == "gloo":
         # rehearsal of the multi-rank path on a box with one GPU (gloo has no device gather): stage through the host
         torch.cuda.current_stream().synchronize()
         host = [torch.empty(g.shape, dtype=g.dtype) for g in gathered] if rank == root else None
-        gather_rows(shard.cpu(), host, rank, world, root, group)
+        gather_rows(shard.cpu(), host, rank, world, root, group, equal_rows=equal_rows)
         if rank == root:
             for g, h in zip(gathered, host):
                 g.copy_(h)
         return _Works([]) if async_op else gathered
-    if _all_equal_rows(shard, world, group):   # decided collectively: every rank must take the same branch
+    if _all_equal_rows(shard, world, group) if equal_rows is None else equal_rows:   # every rank must take the same branch
         w = dist.gather(shard, gather_list=gathered if rank == root else None, dst=root, group=group, async_op=async_op)
         return w if async_op else gathered
     if rank == root:
@@ -101,16 +104,10 @@ def gather_rows(shard, gathered, rank, world, root=0, group=None, async_op=False
     return gathered
 
 
-_equal_cache = {}
-
-
 def _all_equal_rows(shard, world, group):
-    key = (tuple(shard.shape), world, id(group))
-    if key not in _equal_cache:
-        t = torch.tensor([shard.shape[0], -shard.shape[0]], dtype=torch.int64, device=shard.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
-        _equal_cache[key] = bool(t[0].item() == -t[1].item())
-    return _equal_cache[key]
+    t = torch.tensor([shard.shape[0], -shard.shape[0]], dtype=torch.int64, device=shard.device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return bool(t[0].item() == -t[1].item())
 
 
 def assemble(gathered):

@@ -133,7 +133,7 @@ def main():
             finish(b)
         shade(out_ptrs[b])
         if world > 1:
-            pending[b] = sharding.gather_rows(outs[b], gathered[b], rank, world, async_op=True)
+            pending[b] = sharding.gather_rows(outs[b], gathered[b], rank, world, async_op=True, equal_rows=True)
 
     def finish(b):
         pending[b].wait()
@@ -183,7 +183,7 @@ def main():
             torch.cuda.synchronize(); dist.barrier()
             t0 = time.perf_counter()
             for _ in range(10):
-                sharding.gather_rows(outs[0], gathered[0], rank, world)
+                sharding.gather_rows(outs[0], gathered[0], rank, world, equal_rows=True)
             torch.cuda.synchronize(); dist.barrier()
             gather_ms = (time.perf_counter() - t0) / 10 * 1e3
         except Exception as exc:   # a measurement extra must never cost the bench line
