@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ARCTIC_HIP_LIBRARY") or os.path.join(HERE, "csrc", "libarctic_hip.so")   # the override is for A/B timing of two builds (tools/experiments)
 HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "arctic_hip.h")
 
-OPTIONS = {"keep_float_output": 1, "count_light_evals": 2, "culling": 3, "debug": 4, "hdr16": 6, "shadow_cache": 9, "visbuffer": 10, "item_table_floor": 11, "light_path": 12, "markers": 13}
+OPTIONS = {"keep_float_output": 1, "count_light_evals": 2, "culling": 3, "debug": 4, "hdr16": 6, "shadow_cache": 9, "visbuffer": 10, "item_table_floor": 11, "light_path": 12, "markers": 13, "shadow_sharded": 14}
 ERRORS = {-1: "ARCTIC_E_INVALID", -2: "ARCTIC_E_DEVICE", -3: "ARCTIC_E_NO_DEVICE", -4: "ARCTIC_E_STATE", -5: "ARCTIC_E_CAPACITY"}
 
 _vp, _u32, _u64, _i32, _i64 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32, C.c_int64
@@ -49,12 +49,18 @@ SIGNATURES = {
     "arctic_stats": (_i32, [_vp, _vp, _u32]),
     "arctic_set_option": (_i32, [_vp, _u32, _i64]),
     "arctic_version": (_i32, []),
+    # include/arctic_dist.h: the multi-GPU exchange steps
+    "arctic_comm_unique_id": (_i32, [_vp, _vp, _u64]),
+    "arctic_comm_init": (_i32, [_vp, _vp, _i32, _i32]),
+    "arctic_comm_destroy": (_i32, [_vp]),
+    "arctic_gather_frame": (_i32, [_vp, _vp, _vp, _i32]),
+    "arctic_assemble_frame": (_i32, [_vp, _vp, _vp, _u32, _vp]),
 }
 
 
 def header_symbols():
-    """names of every function include/arctic_hip.h declares."""
-    text = open(HEADER_PATH).read()
+    """names of every function include/arctic_hip.h and include/arctic_dist.h declare."""
+    text = open(HEADER_PATH).read() + open(os.path.join(os.path.dirname(HEADER_PATH), "arctic_dist.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(arctic_[a-z0-9_]+)\s*\(", text)))
 

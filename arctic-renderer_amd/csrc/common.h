@@ -169,6 +169,8 @@ hipError_t launch_fill_u64(unsigned long long *p, unsigned long long v, size_t n
 hipError_t launch_fill_u32(uint32_t *p, uint32_t v, size_t n, hipStream_t s);
 hipError_t launch_shade(const ShadeParams &sp, const ShadeLaunch &L);
 hipError_t launch_shadow_bounds(const float *map, uint32_t S, float2 *blocks, float2 *bounds, hipStream_t s);
+hipError_t launch_place_rows(const uint8_t *staging, uint8_t *frame, uint32_t width, uint32_t height, uint32_t band_rows, uint32_t world,
+                             const uint32_t *d_ranges, const unsigned long long *d_shard_offset, hipStream_t s);
 hipError_t launch_post_process(const float4 *hdr, uint32_t w, uint32_t h, int32_t tm, float inv_gamma, float exposure,
                                uint8_t *rgba8, float *ldr, hipStream_t s);
 hipError_t launch_gbuffer_tile(GBuffer g, float *attrs, uint32_t *mat, uint32_t width, uint32_t rows,

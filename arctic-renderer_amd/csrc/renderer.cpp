@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../include/arctic_hip.h"
+#include "../../include/arctic_dist.h"
 #include "common.h"
 
 using namespace arctic;
@@ -51,6 +52,46 @@ struct Range {
     ~Range() { if (live) g_markers.pop(); }
 };
 
+
+// RCCL, loaded at run time like roctx (arctic_dist.h): the few entry points the exchange steps use.  Types are declared here
+// the way rccl.h declares them (opaque communicator, 128-byte id by value, int enums) so the library needs no RCCL headers.
+struct Rccl {
+    struct UniqueId { char internal[ARCTIC_COMM_ID_BYTES]; };
+    typedef void *Comm;
+    static constexpr int Uint8 = 1, Uint32 = 3, Float32 = 7;   // ncclDataType_t (rccl.h:459-466)
+    int (*GetUniqueId)(UniqueId *) = nullptr;
+    int (*CommInitRank)(Comm *, int, UniqueId, int) = nullptr;
+    int (*CommDestroy)(Comm) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, Comm, hipStream_t) = nullptr;
+    int (*Send)(const void *, size_t, int, int, Comm, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, Comm, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool tried = false;
+    bool load() {
+        if (!tried) {
+            tried = true;
+            void *h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+            if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+            if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
+            if (h) {
+                GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+                CommInitRank = reinterpret_cast<decltype(CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+                CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+                AllGather = reinterpret_cast<decltype(AllGather)>(dlsym(h, "ncclAllGather"));
+                Send = reinterpret_cast<decltype(Send)>(dlsym(h, "ncclSend"));
+                Recv = reinterpret_cast<decltype(Recv)>(dlsym(h, "ncclRecv"));
+                GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(h, "ncclGroupStart"));
+                GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(h, "ncclGroupEnd"));
+                GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+            }
+        }
+        return GetUniqueId && CommInitRank && CommDestroy && AllGather && Send && Recv && GroupStart && GroupEnd;
+    }
+    const char *why(int rc) const { return GetErrorString ? GetErrorString(rc) : "RCCL error"; }
+};
+Rccl g_rccl;
 
 struct DevBuf {
     void *p = nullptr;
@@ -126,6 +167,18 @@ struct ArcticRenderer {
     // every frame (renderer.cpp:300-337), but a depth map of unchanged geometry from an unchanged light is the same map
     std::vector<uint8_t> shadow_key; bool shadow_cache = true;
     uint32_t cu_count = 256;
+    // multi-GPU exchange (arctic_dist.h): an RCCL communicator owned by the handle, a communication stream ordered against the
+    // main stream with events, the shard layout of every rank (all-gathered once at arctic_comm_init)
+    Rccl::Comm comm = nullptr;
+    int comm_rank = 0, comm_world = 1;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_main = nullptr;
+    struct InFlight { const void *ptr = nullptr; hipEvent_t done = nullptr; } inflight[4];   // gathers that still read a shard buffer
+    std::vector<uint32_t> peer_rows, peer_ranges;    // rows of every rank's shard; [begin, end) of every rank (row-range shards)
+    DevBuf d_staging, d_layout;                       // root: all shards back to back; ranges (2 u32 per rank) + byte offsets (u64 per rank)
+    uint32_t layout_world = 0; bool layout_from_comm = false;
+    bool shadow_sharded = false;                      // ARCTIC_OPT_SHADOW_SHARDED
+    uint32_t shadow_rows_alloc = 0;                   // rows the shadow buffer holds (>= shadow_size: padded to world * ceil(S / world))
     uint32_t *h_counts = nullptr;   // pinned: [0] records, [1] work items (forward), [2], [3] the same for the shadow pass, [4], [5] item-table overflow flags
     std::string err;
 
@@ -255,6 +308,11 @@ int run_geometry(ArcticRenderer *r, const ArcticScene *sc, bool shadow_pass) {
         std::memcpy(gp.clip_from_world, gp.light_from_world, sizeof gp.clip_from_world);
         gp.vp_w = gp.vp_h = (float)r->shadow_size;
         gp.sc_x0 = gp.sc_y0 = 0; gp.sc_x1 = gp.sc_y1 = (int32_t)r->shadow_size;
+        if (r->shadow_sharded && r->comm && r->comm_world > 1) {   // this rank's slice of the light-space rows; the all-gather follows the raster
+            const uint32_t per = (r->shadow_size + (uint32_t)r->comm_world - 1) / (uint32_t)r->comm_world;
+            gp.sc_y0 = (int32_t)std::min(r->shadow_size, per * (uint32_t)r->comm_rank);
+            gp.sc_y1 = (int32_t)std::min(r->shadow_size, per * ((uint32_t)r->comm_rank + 1));
+        }
         gp.cull_front = 1;                                       // shadow_map_pass.cpp:96-97
         gp.tiles_x = (int32_t)((r->shadow_size + 7) / 8); gp.tile_y0 = 0; gp.pitch = (int32_t)r->shadow_size;
     } else {
@@ -316,7 +374,17 @@ int pass_shadow_map(ArcticRenderer *r, const ArcticScene *sc) {
     size_t n = (size_t)r->shadow_size * r->shadow_size;
     HIPCHECK(r, launch_fill_u32(r->d_shadow.as<uint32_t>(), 0x3F800000u, n, r->stream));   // clear to 1.0 (shadow_map_pass.cpp:124-131)
     r->bounds_valid = false;
-    return run_geometry(r, sc, true);
+    int rc = run_geometry(r, sc, true);
+    if (rc != ARCTIC_OK) return rc;
+    if (r->shadow_sharded && r->comm && r->comm_world > 1) {
+        // every rank has drawn ceil(S / world) rows of the map: one in-place all-gather (the send buffer is this rank's slice of the
+        // receive buffer) completes it everywhere, on the main stream -- the shading pass needs it next
+        const size_t per = (size_t)((r->shadow_size + (uint32_t)r->comm_world - 1) / (uint32_t)r->comm_world) * r->shadow_size;
+        float *base = r->d_shadow.as<float>();
+        const int nrc = g_rccl.AllGather(base + per * (size_t)r->comm_rank, base, per, Rccl::Float32, r->comm, r->stream);
+        if (nrc != 0) return r->fail(ARCTIC_E_DEVICE, "ncclAllGather(shadow map): %s", g_rccl.why(nrc));
+    }
+    return ARCTIC_OK;
 }
 
 // visibility only: vertex -> setup -> raster of the camera view
@@ -417,6 +485,8 @@ int pass_shade(ArcticRenderer *r, const ArcticScene *sc, const ArcticSettings *s
     ShadeParams sp;
     int rc = fill_shade_params(r, sc, st, d_out, sp, from_vis);
     if (rc != ARCTIC_OK) return rc;
+    for (auto &f : r->inflight)   // a gather of an earlier frame may still be reading this output buffer
+        if (f.ptr && f.ptr == static_cast<const void *>(sp.out_rgba8)) { HIPCHECK(r, hipStreamWaitEvent(r->stream, f.done, 0)); f.ptr = nullptr; }
     if (r->count_evals) {
         sp.stats = r->d_counter.as<unsigned long long>();
         HIPCHECK(r, hipMemsetAsync(r->d_counter.p, 0, 8 * N_SHADE_STATS, r->stream));
@@ -530,11 +600,12 @@ void arctic_destroy(ArcticRenderer *r) {
     (void)hipSetDevice(r->device);
     if (r->h_counts) (void)hipHostFree(r->h_counts);
     (void)hipStreamSynchronize(r->stream);
+    (void)arctic_comm_destroy(r);
     if (r->own_stream) { (void)hipStreamSynchronize(r->own_stream); (void)hipStreamDestroy(r->own_stream); }
     for (Mesh &m : r->meshes) { if (m.d_vertices) (void)hipFree(m.d_vertices); if (m.d_indices) (void)hipFree(m.d_indices); }
     for (void *p : r->tex_allocs) (void)hipFree(p);
     DevBuf *bufs[] = {&r->d_tex, &r->d_lut, &r->d_lights, &r->d_light_pairs, &r->d_shadow, &r->d_env, &r->d_vis, &r->d_p0, &r->d_p1, &r->d_p2, &r->d_p3, &r->d_p4,
-                      &r->d_rgba8, &r->d_ldr, &r->d_hdr, &r->d_counter, &r->d_shadow_blocks, &r->d_shadow_bounds, &r->d_xverts,
+                      &r->d_rgba8, &r->d_ldr, &r->d_hdr, &r->d_counter, &r->d_shadow_blocks, &r->d_shadow_bounds, &r->d_staging, &r->d_layout, &r->d_xverts,
                       &r->d_recs, &r->d_rec_of, &r->d_items, &r->d_geo_counters, &r->d_stage, &r->tables[0].d, &r->tables[1].d};
     for (PassTables &T : r->tables) { if (T.h) (void)hipHostFree(T.h); if (T.copied) (void)hipEventDestroy(T.copied); }
     for (DevBuf *b : bufs) b->release();
@@ -560,6 +631,7 @@ int arctic_flush(ArcticRenderer *r) {
     int rc = select_device(r);
     if (rc) return rc;
     HIPCHECK(r, hipStreamSynchronize(r->stream));
+    if (r->comm_stream) HIPCHECK(r, hipStreamSynchronize(r->comm_stream));
     if (int ov = check_item_overflow(r)) return ov;
     return ARCTIC_OK;
 }
@@ -909,8 +981,178 @@ int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value) {
         r->item_cap_floor = (uint32_t)value; r->item_cap = 0;
         break;
     case ARCTIC_OPT_SHADOW_CACHE: r->shadow_cache = value != 0; r->shadow_key.clear(); break;
+    case ARCTIC_OPT_SHADOW_SHARDED: r->shadow_sharded = value != 0; r->shadow_key.clear(); break;
     default: return r->fail(ARCTIC_E_INVALID, "set_option: unknown option %u", option);
     }
+    return ARCTIC_OK;
+}
+
+// ---- multi-GPU exchange steps (include/arctic_dist.h) ------------------------------------------------------------------------
+namespace {
+
+// rows of every rank's shard and where each shard starts in a staging buffer that holds them back to back; uploaded to d_layout
+int upload_layout(ArcticRenderer *r, uint32_t world, const uint32_t *ranges /* 2 * world, or null: interleaved bands */, bool from_comm) {
+    std::vector<uint32_t> rows(world, 0), rg(2 * (size_t)world, 0);
+    if (ranges) {
+        for (uint32_t k = 0; k < world; ++k) {
+            if (ranges[2 * k] > ranges[2 * k + 1] || ranges[2 * k + 1] > r->height) return r->fail(ARCTIC_E_INVALID, "frame layout: bad row range of rank %u", k);
+            rg[2 * k] = ranges[2 * k]; rg[2 * k + 1] = ranges[2 * k + 1]; rows[k] = ranges[2 * k + 1] - ranges[2 * k];
+        }
+    } else {
+        if (!r->band_rows || r->shard_count != world) return r->fail(ARCTIC_E_INVALID, "frame layout: interleaved bands need band_rows > 0 and shard_count == world");
+        for (uint32_t y = 0; y < r->height; ++y) rows[(y / r->band_rows) % world]++;
+    }
+    std::vector<unsigned long long> off(world, 0);
+    for (uint32_t k = 1; k < world; ++k) off[k] = off[k - 1] + (unsigned long long)rows[k - 1] * r->width * 4;
+    const size_t ranges_bytes = (((size_t)world * 8) + 15) / 16 * 16;
+    HIPCHECK(r, r->d_layout.ensure(ranges_bytes + (size_t)world * 8));
+    HIPCHECK(r, hipMemcpyAsync(r->d_layout.p, rg.data(), (size_t)world * 8, hipMemcpyHostToDevice, r->stream));
+    HIPCHECK(r, hipMemcpyAsync(r->d_layout.as<char>() + ranges_bytes, off.data(), (size_t)world * 8, hipMemcpyHostToDevice, r->stream));
+    HIPCHECK(r, hipStreamSynchronize(r->stream));   // the host vectors go out of scope
+    r->peer_rows = rows; r->peer_ranges = ranges ? rg : std::vector<uint32_t>();
+    r->layout_world = world; r->layout_from_comm = from_comm;
+    return ARCTIC_OK;
+}
+const uint32_t *layout_ranges(const ArcticRenderer *r) { return r->d_layout.as<uint32_t>(); }
+const unsigned long long *layout_offsets(const ArcticRenderer *r) {
+    return reinterpret_cast<const unsigned long long *>(r->d_layout.as<char>() + (((size_t)r->layout_world * 8) + 15) / 16 * 16);
+}
+
+}  // namespace
+
+int arctic_comm_unique_id(void *id_out, char *err, uint64_t err_len) {
+    auto say = [&](const char *m) { if (err && err_len) std::snprintf(err, (size_t)err_len, "%s", m); return ARCTIC_E_DEVICE; };
+    if (!id_out) return ARCTIC_E_INVALID;
+    if (!g_rccl.load()) return say("arctic_comm_unique_id: librccl.so could not be loaded");
+    Rccl::UniqueId id;
+    const int rc = g_rccl.GetUniqueId(&id);
+    if (rc != 0) return say(g_rccl.why(rc));
+    std::memcpy(id_out, id.internal, ARCTIC_COMM_ID_BYTES);
+    return ARCTIC_OK;
+}
+
+int arctic_comm_init(ArcticRenderer *r, const void *id_bytes, int rank, int world) {
+    if (!r) return ARCTIC_E_INVALID;
+    if (!id_bytes || world < 1 || rank < 0 || rank >= world) return r->fail(ARCTIC_E_INVALID, "comm_init: bad id / rank / world");
+    if (r->comm) return r->fail(ARCTIC_E_STATE, "comm_init: the handle already has a communicator");
+    if (r->band_rows && ((uint32_t)world != r->shard_count || (uint32_t)rank != r->shard_index))
+        return r->fail(ARCTIC_E_INVALID, "comm_init: rank %d of %d does not match the handle's shard %u of %u", rank, world, r->shard_index, r->shard_count);
+    int rc = select_device(r);
+    if (rc) return rc;
+    if (!g_rccl.load()) return r->fail(ARCTIC_E_DEVICE, "comm_init: librccl.so could not be loaded");
+    Rccl::UniqueId id;
+    std::memcpy(id.internal, id_bytes, ARCTIC_COMM_ID_BYTES);
+    int nrc = g_rccl.CommInitRank(&r->comm, world, id, rank);
+    if (nrc != 0) { r->comm = nullptr; return r->fail(ARCTIC_E_DEVICE, "ncclCommInitRank: %s", g_rccl.why(nrc)); }
+    r->comm_rank = rank; r->comm_world = world;
+    if (!r->comm_stream) HIPCHECK(r, hipStreamCreateWithFlags(&r->comm_stream, hipStreamNonBlocking));
+    if (!r->ev_main) HIPCHECK(r, hipEventCreateWithFlags(&r->ev_main, hipEventDisableTiming));
+    for (auto &f : r->inflight) if (!f.done) HIPCHECK(r, hipEventCreateWithFlags(&f.done, hipEventDisableTiming));
+    // every rank's shard layout: {row_begin, row_end, rows, band_rows} all-gathered once (the root places shards of unequal size)
+    DevBuf tmp;
+    HIPCHECK(r, tmp.ensure((size_t)world * 16));
+    const uint32_t mine[4] = {r->band_rows ? 0u : r->row_begin, r->band_rows ? 0u : r->row_end, r->rows(), r->band_rows};
+    HIPCHECK(r, hipMemcpyAsync(tmp.as<char>() + (size_t)rank * 16, mine, 16, hipMemcpyHostToDevice, r->comm_stream));
+    nrc = g_rccl.AllGather(tmp.as<char>() + (size_t)rank * 16, tmp.p, 4, Rccl::Uint32, r->comm, r->comm_stream);
+    if (nrc != 0) { tmp.release(); return r->fail(ARCTIC_E_DEVICE, "ncclAllGather(layout): %s", g_rccl.why(nrc)); }
+    std::vector<uint32_t> all((size_t)world * 4);
+    HIPCHECK(r, hipMemcpyAsync(all.data(), tmp.p, (size_t)world * 16, hipMemcpyDeviceToHost, r->comm_stream));
+    HIPCHECK(r, hipStreamSynchronize(r->comm_stream));
+    tmp.release();
+    std::vector<uint32_t> ranges(2 * (size_t)world);
+    for (int k = 0; k < world; ++k) {
+        if (all[4 * k + 3] != r->band_rows) return r->fail(ARCTIC_E_INVALID, "comm_init: rank %d shards the frame differently (band_rows %u vs %u)", k, all[4 * k + 3], r->band_rows);
+        ranges[2 * k] = all[4 * k]; ranges[2 * k + 1] = all[4 * k + 1];
+    }
+    if ((rc = upload_layout(r, (uint32_t)world, r->band_rows ? nullptr : ranges.data(), true)) != ARCTIC_OK) return rc;
+    for (int k = 0; k < world; ++k)
+        if (r->peer_rows[k] != all[4 * k + 2]) return r->fail(ARCTIC_E_INVALID, "comm_init: rank %d reports %u rows, the layout gives it %u", k, all[4 * k + 2], r->peer_rows[k]);
+    if (r->shadow_size) {   // room for the in-place all-gather of a sharded shadow map: world * ceil(S / world) rows
+        const uint32_t per = (r->shadow_size + (uint32_t)world - 1) / (uint32_t)world;
+        if ((size_t)per * world > r->shadow_size) {
+            const size_t n = (size_t)per * world * r->shadow_size;
+            if (r->d_shadow.cap < n * 4) {
+                HIPCHECK(r, r->d_shadow.ensure(n * 4));
+                HIPCHECK(r, launch_fill_u32(r->d_shadow.as<uint32_t>(), 0x3F800000u, n, r->stream));
+                r->shadow_key.clear(); r->bounds_valid = false;
+            }
+        }
+    }
+    return ARCTIC_OK;
+}
+
+int arctic_comm_destroy(ArcticRenderer *r) {
+    if (!r) return ARCTIC_E_INVALID;
+    if (r->comm_stream) (void)hipStreamSynchronize(r->comm_stream);
+    if (r->comm) { (void)g_rccl.CommDestroy(r->comm); r->comm = nullptr; }
+    r->comm_rank = 0; r->comm_world = 1;
+    if (r->layout_from_comm) { r->layout_world = 0; r->layout_from_comm = false; }
+    for (auto &f : r->inflight) { if (f.done) (void)hipEventDestroy(f.done); f.done = nullptr; f.ptr = nullptr; }
+    if (r->ev_main) { (void)hipEventDestroy(r->ev_main); r->ev_main = nullptr; }
+    if (r->comm_stream) { (void)hipStreamDestroy(r->comm_stream); r->comm_stream = nullptr; }
+    return ARCTIC_OK;
+}
+
+int arctic_gather_frame(ArcticRenderer *r, const void *d_shard, void *d_frame, int root) {
+    if (!r) return ARCTIC_E_INVALID;
+    if (!r->comm || !r->layout_from_comm) return r->fail(ARCTIC_E_STATE, "gather_frame: no communicator (arctic_comm_init)");
+    if (root < 0 || root >= r->comm_world) return r->fail(ARCTIC_E_INVALID, "gather_frame: bad root");
+    const bool is_root = r->comm_rank == root;
+    if (is_root && !d_frame) return r->fail(ARCTIC_E_INVALID, "gather_frame: the root needs a frame buffer");
+    if (!d_shard) {
+        if (!r->have_output) return r->fail(ARCTIC_E_STATE, "gather_frame: no shaded output to gather");
+        d_shard = r->d_rgba8.p;
+    }
+    int rc = select_device(r);
+    if (rc) return rc;
+    const size_t row_bytes = (size_t)r->width * 4;
+    HIPCHECK(r, hipEventRecord(r->ev_main, r->stream));               // after the shading that produced the shard ...
+    HIPCHECK(r, hipStreamWaitEvent(r->comm_stream, r->ev_main, 0));   // ... on the communication stream, beside the next frame
+    const uint8_t *src = static_cast<const uint8_t *>(d_shard);
+    if (r->comm_world > 1) {
+        size_t total = 0;
+        for (uint32_t k = 0; k < (uint32_t)r->comm_world; ++k) total += (size_t)r->peer_rows[k] * row_bytes;
+        if (is_root) HIPCHECK(r, r->d_staging.ensure(total));
+        int nrc = g_rccl.GroupStart();
+        if (nrc != 0) return r->fail(ARCTIC_E_DEVICE, "ncclGroupStart: %s", g_rccl.why(nrc));
+        size_t off = 0;
+        for (int k = 0; k < r->comm_world && nrc == 0; ++k) {
+            const size_t bytes = (size_t)r->peer_rows[k] * row_bytes;
+            if (is_root && k != root && bytes) nrc = g_rccl.Recv(r->d_staging.as<char>() + off, bytes, Rccl::Uint8, k, r->comm, r->comm_stream);
+            off += bytes;
+        }
+        if (!is_root && nrc == 0 && r->rows()) nrc = g_rccl.Send(src, (size_t)r->rows() * row_bytes, Rccl::Uint8, root, r->comm, r->comm_stream);
+        const int erc = g_rccl.GroupEnd();
+        if (nrc != 0 || erc != 0) return r->fail(ARCTIC_E_DEVICE, "ncclSend/ncclRecv(frame shards): %s", g_rccl.why(nrc ? nrc : erc));
+        if (is_root) {
+            size_t mine = 0;
+            for (int k = 0; k < root; ++k) mine += (size_t)r->peer_rows[k] * row_bytes;
+            HIPCHECK(r, hipMemcpyAsync(r->d_staging.as<char>() + mine, src, (size_t)r->rows() * row_bytes, hipMemcpyDeviceToDevice, r->comm_stream));
+            src = r->d_staging.as<uint8_t>();
+        }
+    }
+    if (is_root)
+        HIPCHECK(r, launch_place_rows(src, static_cast<uint8_t *>(d_frame), r->width, r->height, r->band_rows, (uint32_t)r->comm_world,
+                                      layout_ranges(r), layout_offsets(r), r->comm_stream));
+    // whoever writes this shard buffer next waits for the transfers that still read it
+    ArcticRenderer::InFlight *slot = nullptr;
+    for (auto &f : r->inflight) if (f.ptr == d_shard) slot = &f;
+    if (!slot) for (auto &f : r->inflight) if (!f.ptr) { slot = &f; break; }
+    if (!slot) { HIPCHECK(r, hipStreamSynchronize(r->comm_stream)); for (auto &f : r->inflight) f.ptr = nullptr; slot = &r->inflight[0]; }
+    slot->ptr = d_shard;
+    HIPCHECK(r, hipEventRecord(slot->done, r->comm_stream));
+    return ARCTIC_OK;
+}
+
+int arctic_assemble_frame(ArcticRenderer *r, const void *d_staging, void *d_frame, uint32_t world, const uint32_t *row_ranges) {
+    if (!r) return ARCTIC_E_INVALID;
+    if (!d_staging || !d_frame || world == 0) return r->fail(ARCTIC_E_INVALID, "assemble_frame: null buffer or world == 0");
+    int rc = select_device(r);
+    if (rc) return rc;
+    if (r->layout_from_comm && (uint32_t)r->comm_world != world) return r->fail(ARCTIC_E_STATE, "assemble_frame: the handle's communicator has another world size");
+    if (!r->layout_from_comm && (rc = upload_layout(r, world, row_ranges, false)) != ARCTIC_OK) return rc;
+    HIPCHECK(r, launch_place_rows(static_cast<const uint8_t *>(d_staging), static_cast<uint8_t *>(d_frame), r->width, r->height,
+                                  row_ranges ? 0u : r->band_rows, world, layout_ranges(r), layout_offsets(r), r->stream));
     return ARCTIC_OK;
 }
 

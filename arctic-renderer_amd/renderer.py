@@ -89,6 +89,37 @@ class Renderer:
         else:
             self._check(self.L.arctic_set_stream(self.h, C.c_void_p(hip_stream)))
 
+    # ---- multi-GPU exchange steps (include/arctic_dist.h) -----------------------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        """128 bytes from ncclGetUniqueId: one process calls it, every rank of the communicator gets the bytes."""
+        L = binding.lib()
+        buf, err = C.create_string_buffer(128), C.create_string_buffer(512)
+        rc = L.arctic_comm_unique_id(buf, err, 512)
+        if rc != 0:
+            raise ArcticError(rc, err.value.decode())
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, world):
+        """collective: an RCCL communicator of `world` ranks owned by this handle (ncclCommInitRank) + the shard layouts."""
+        assert len(unique_id) == 128
+        self._check(self.L.arctic_comm_init(self.h, C.c_char_p(unique_id), rank, world))
+
+    def comm_destroy(self):
+        self._check(self.L.arctic_comm_destroy(self.h))
+
+    def gather_frame(self, d_shard_ptr, d_frame_ptr, root=0):
+        """collective, asynchronous: this rank's RGBA8 shard (device pointer; None = the handle's own output) to the root's
+        row-major frame (device pointer; ignored on the other ranks)."""
+        self._check(self.L.arctic_gather_frame(self.h, C.c_void_p(d_shard_ptr) if d_shard_ptr else None,
+                                               C.c_void_p(d_frame_ptr) if d_frame_ptr else None, root))
+
+    def assemble_frame(self, d_staging_ptr, d_frame_ptr, world, row_ranges=None):
+        """the root's placement step alone: shards back to back in rank order -> the full frame."""
+        rr = None if row_ranges is None else np.ascontiguousarray(row_ranges, dtype=np.uint32).reshape(-1)
+        assert rr is None or rr.size == 2 * world
+        self._check(self.L.arctic_assemble_frame(self.h, C.c_void_p(d_staging_ptr), C.c_void_p(d_frame_ptr), world, _ptr(rr)))
+
     def create_material(self, diffuse, normal, metal_rough):
         """three (h, w, 4) uint8 images; returns the material index."""
         d, n, m = (np.ascontiguousarray(t, dtype=np.uint8) for t in (diffuse, normal, metal_rough))

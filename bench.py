@@ -13,8 +13,11 @@ and G-buffer prepass.
 
 N > 1: the frame is sharded by rows, in interleaved bands of 16 rows dealt round-robin to the ranks
 (lit regions are spatially clustered; contiguous ranges would be unbalanced); every step issues the
-RCCL gather of the finished RGBA8 shards to rank 0 (the path's one real exchange step), which
-overlaps the next step's shading through double buffering; total work is fixed -> "scaling": "strong".
+gather of the finished RGBA8 shards to rank 0 (the path's one real exchange step) through the C-ABI
+(arctic_gather_frame, include/arctic_dist.h: RCCL send/recv on the handle's communication stream + one
+placement kernel on the root), which overlaps the next step's shading through two shard buffers; total
+work is fixed -> "scaling": "strong".  torch.distributed only carries the 128-byte communicator id and
+the timing barriers (ARCTIC_BENCH_EXCHANGE=torch keeps the round-1 path: dist.gather + index_copy_).
 
 The JSON line also carries
   roofline     the dominant kernel = the pass itself (ONE launch: k_material<loop>): achieved = 80 B x shaded pixels /
@@ -98,6 +101,19 @@ def main():
         r = sc.upload(pkg.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights, device=local, band_rows=BAND, shard=(rank, world)))
     else:
         r = sc.upload(pkg.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights, device=local))
+    cabi = False
+    if world > 1 and backend == "nccl" and os.environ.get("ARCTIC_BENCH_EXCHANGE", "cabi") == "cabi":
+        try:   # the exchange below Python: an RCCL communicator owned by the handle; the id travels over torch.distributed
+            box = [pkg.Renderer.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            r.comm_init(box[0], rank, world)
+            r.set_option("shadow_sharded", 1)
+            cabi = True
+        except Exception as exc:
+            log(f"[bench] rank {rank}: C-ABI exchange unavailable ({exc}); falling back to torch.distributed")
+        flag = torch.tensor([1 if cabi else 0], device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        cabi = bool(flag.item())
     r.pass_shadow_map(sc.desc)      # untimed: the producers of the hot path's inputs
     r.pass_gbuffer(sc.desc)
     r.flush()
@@ -113,13 +129,16 @@ def main():
     # N > 1: every rank sends the same number of rows (its own, padded to the largest shard), so the exchange is ONE
     # ncclGather per frame; on the root the shards land back to back in a staging buffer and ONE indexed copy
     # de-interleaves them into the frame (the padding rows go to dummy rows past the frame's end: world * pad rows in all)
-    pad, dest = sharding.padded_gather_plan(sc.height, world, BAND) if world > 1 else (rows, None)
+    pad, dest = sharding.padded_gather_plan(sc.height, world, BAND) if (world > 1 and not cabi) else (rows, None)
     outs = [torch.empty((pad, sc.width, 4), dtype=torch.uint8, device="cuda") for _ in range(n_buf)]
-    staging = [torch.empty((world * pad, sc.width, 4), dtype=torch.uint8, device="cuda") for _ in range(n_buf)] if (world > 1 and rank == 0) else None
+    staging = [torch.empty((world * pad, sc.width, 4), dtype=torch.uint8, device="cuda") for _ in range(n_buf)] if (world > 1 and rank == 0 and not cabi) else None
     gathered = [[staging[b][k * pad:(k + 1) * pad] for k in range(world)] for b in range(n_buf)] if staging is not None else [None] * n_buf
     pending = [None] * n_buf
     frame_ext = torch.empty((world * pad, sc.width, 4), dtype=torch.uint8, device="cuda") if staging is not None else None
     frame = frame_ext[:sc.height] if frame_ext is not None else None
+    if cabi and rank == 0:
+        frame = torch.empty((sc.height, sc.width, 4), dtype=torch.uint8, device="cuda")
+    frame_ptr = frame.data_ptr() if (cabi and rank == 0) else None
     perm = torch.as_tensor(dest, device="cuda") if staging is not None else None
     out_ptrs = [o.data_ptr() for o in outs]
     r.set_stream(torch.cuda.current_stream().cuda_stream)   # the library launches on torch's stream: torch events see its kernels
@@ -131,8 +150,10 @@ def main():
         state["k"] += 1
         if pending[b] is not None:
             finish(b)
-        shade(out_ptrs[b])
-        if world > 1:
+        shade(out_ptrs[b])      # (waits by itself for the gather that last read this buffer)
+        if cabi:
+            r.gather_frame(out_ptrs[b], frame_ptr, 0)
+        elif world > 1:
             pending[b] = sharding.gather_rows(outs[b], gathered[b], rank, world, async_op=True, equal_rows=True)
 
     def finish(b):
@@ -183,11 +204,39 @@ def main():
             torch.cuda.synchronize(); dist.barrier()
             t0 = time.perf_counter()
             for _ in range(10):
-                sharding.gather_rows(outs[0], gathered[0], rank, world, equal_rows=True)
-            torch.cuda.synchronize(); dist.barrier()
+                if cabi:
+                    r.gather_frame(out_ptrs[0], frame_ptr, 0)
+                else:
+                    sharding.gather_rows(outs[0], gathered[0], rank, world, equal_rows=True)
+            r.flush(); torch.cuda.synchronize(); dist.barrier()
             gather_ms = (time.perf_counter() - t0) / 10 * 1e3
         except Exception as exc:   # a measurement extra must never cost the bench line
             log(f"[bench] gather timing skipped: {exc}")
+    # whole frames, outside the timed region (shadow raster [only when the sun moves] + visibility prepass of this rank's rows +
+    # shading from the visibility plane [+ gather]): what an application sees, next to the pass the metric is defined on
+    whole = {}
+    try:
+        for name, cache in (("static_sun", 1), ("moving_sun", 0)):
+            r.set_option("shadow_cache", cache)
+            for k in range(3 + 20):
+                if k == 3:
+                    r.flush(); torch.cuda.synchronize()
+                    if world > 1:
+                        dist.barrier()
+                    t0 = time.perf_counter()
+                r.render_frame_device(sc.desc, sc.settings, out_ptrs[k % n_buf])
+                if cabi:
+                    r.gather_frame(out_ptrs[k % n_buf], frame_ptr, 0)
+            r.flush(); torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            whole[name + "_ms"] = round((time.perf_counter() - t0) / 20 * 1e3, 4)
+        r.set_option("shadow_cache", 1)
+        whole["note"] = ("arctic_render_frame_device per rank" + (" + arctic_gather_frame; the shadow map is drawn in light-space row shards "
+                         "and all-gathered when the sun moves" if cabi else "") + "; vertex transform and triangle setup of the whole scene are "
+                         "redundant per rank (DESIGN.md section 5)")
+    except Exception as exc:
+        log(f"[bench] whole-frame timing skipped: {exc}")
     r.set_stream(None)
     if world > 1 and rank == 0 and os.environ.get("ARCTIC_BENCH_VERIFY") == "1":
         # the multi-rank invariant, end to end: the gathered, de-interleaved frame == a single-device frame, byte for byte
@@ -282,7 +331,8 @@ def main():
             "config": {"workload": f"BASELINE configs[{args.config - 1}]: {sc.name}, {sc.width}x{sc.height}, 1 dir + {n_lights} point lights, "
                                    f"shadow {sc.shadow_size}^2 PCF 5x5, tonemap {sc.settings[0]}, {len(sc.materials)} materials; shading pass over a resident G-buffer",
                        "triangles": sc.n_triangles, "shaded_pixels": shaded, "sharding": f"{BAND}-row bands round-robin over {world} ranks, RCCL gather to rank 0" if world > 1 else "none",
-                       "scale": args.scale,
+                       "scale": args.scale, "whole_frame": whole or None,
+                       "exchange_path": ("C-ABI arctic_gather_frame (RCCL send/recv + placement kernel)" if cabi else "torch.distributed gather + index_copy_") if world > 1 else None,
                        "exchange": None if gather_ms is None else {
                            "gather_ms": round(gather_ms, 4), "bytes_per_sender": int(pad) * sc.width * 4,
                            "GBps_per_link": round(int(pad) * sc.width * 4 / (gather_ms * 1e-3) / 1e9, 2),
