@@ -217,6 +217,58 @@ __device__ __forceinline__ float shadow_window(const float *__restrict__ map, ui
     return shadow / 25.0f;
 }
 
+// ---- the LDS variant of the 25-tap path (north_star: "stages ... shadow-map tiles in LDS"; ARCTIC_OPT_DEBUG bit 4 selects the
+// kernels instantiated with it) ----------------------------------------------------------------------------------------------
+// For a tile on a shadow edge: the bounding box of the undecided lanes' footprints (4x4 windows) is staged ONCE per wave in LDS
+// (<= 32 x 32 texels; the lanes of an 8x8 screen tile land within a few texels of each other) and every tap reads its four texels
+// from there with computed addresses -- no selects: per tap 2 ds_read2_b32 + 3 exact lerps + compare, in the oracle's order.
+// Against the register window (4 x 16-byte loads per lane, ~185 v_cndmask to pick texels): measured in DESIGN.md section 4.2.
+constexpr int SHADOW_TILE = 32;   // texels per side of a wave's LDS tile
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d));
+    return v;
+}
+// returns true when the wave's undecided lanes were handled here (lit updated); false: the caller takes the register path
+__device__ __forceinline__ bool shadow_lds_tile(const ShadeParams &sp, float *tile /* this wave's SHADOW_TILE^2 floats */, uint32_t lane, bool undecided,
+                                                const float px, const float py, const float pz, float &lit) {
+#pragma clang fp contract(off)
+    const uint32_t S = sp.shadow_size;
+    const float Sf = (float)S;
+    const int bx = floor_to_int((px + -0.0002f) * Sf - 0.5f), by = floor_to_int((py + -0.0002f) * Sf - 0.5f);
+    const int ex = floor_to_int((px + 0.0002f) * Sf - 0.5f) + 1, ey = floor_to_int((py + 0.0002f) * Sf - 0.5f) + 1;   // last texel a tap reads
+    const bool ok = bx >= 0 && by >= 0 && ex < (int)S && ey < (int)S;   // no tap wraps (the window test of shadow_window, without its width limit)
+    if (__ballot(undecided && !ok) != 0ull) return false;
+    const int BIG = 1 << 30;
+    const int x0 = wave_min_i32(undecided ? bx : BIG), y0 = wave_min_i32(undecided ? by : BIG);
+    const int x1 = -wave_min_i32(undecided ? -ex : BIG), y1 = -wave_min_i32(undecided ? -ey : BIG);
+    const int W = x1 - x0 + 1, H = y1 - y0 + 1;
+    if (W > SHADOW_TILE || H > SHADOW_TILE) return false;
+    // stage rows y0 .. y1, texels x0 .. x1: two rows per step (lanes 0-31 / 32-63), coalesced along x
+    for (int r = (int)(lane >> 5); r < H; r += 2) {
+        const int c = (int)(lane & 31);
+        if (c < W) tile[r * SHADOW_TILE + c] = sp.shadow_map[(size_t)(y0 + r) * S + (size_t)(x0 + c)];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // same wave: LDS operations complete in order
+    if (undecided) {
+        float shadow = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const float x = (px + (float)(i - 2) * 0.0001f) * Sf - 0.5f, xf = floorf(x), fx = x - xf;
+            const int cx = (int)xf - x0;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const float y = (py + (float)(j - 2) * 0.0001f) * Sf - 0.5f, yf = floorf(y), fy = y - yf;
+                const float *t0 = tile + ((int)yf - y0) * SHADOW_TILE + cx;
+                const float top = lerp_exact(t0[0], t0[1], fx), bot = lerp_exact(t0[SHADOW_TILE], t0[SHADOW_TILE + 1], fx);
+                shadow += pz > lerp_exact(top, bot, fy) ? 1.0f : 0.0f;
+            }
+        }
+        lit = 1.0f - shadow / 25.0f;
+    }
+    return true;
+}
+
 // 1 - shadow in two steps.  shadow_quick decides from the bounds table where it can (and for every pixel outside the map);
 // returns false for the lanes that need shadow_slow: tiles on a shadow edge, the map's border, maps above 5000^2.
 struct ShadowPos { float px, py, pz; };
@@ -525,8 +577,8 @@ __device__ __noinline__ f3 sample_environment(const float4 *__restrict__ env, ui
 // G-buffer planes c, d, e): loaded from the G-buffer, or interpolated on the spot by the visibility-buffer kernel.
 // LOOP 1: scalar loop.  LOOP 2: two lights at a time in packed fp32.  Both read the lights through the scalar cache.
 // STATS: count lit pixels, evaluated lights, contributing (n.wi > 0) evaluations and wave-wide zero evaluations into sp.stats.
-template <int LOOP, bool STATS, class Second>
-__device__ __forceinline__ void shade_tile(const ShadeParams &sp, const float *lut, uint32_t ty, uint32_t tx,
+template <int LOOP, bool STATS, bool LDS_SHADOW, class Second>
+__device__ __forceinline__ void shade_tile(const ShadeParams &sp, const float *lut, float *shadow_tile, uint32_t ty, uint32_t tx,
                                            uint32_t lane, const TileHead &cur, Second second) {
     const uint32_t x = tx * 8 + (lane & 7);
     const int32_t y = (int32_t)(ty * 8 + (lane >> 3)) - (int32_t)sp.row0_in_tile;
@@ -573,7 +625,8 @@ __device__ __forceinline__ void shade_tile(const ShadeParams &sp, const float *l
         ShadowPos spos;
         const bool decided = !covered || shadow_quick(sp, cur.a.z, cur.a.w, cur.b0, cur.b1, spos, lit);
         if (__ballot(!decided) != 0ull) {   // a tile on a shadow edge (or at the map's border)
-            if (!decided) lit = shadow_slow(sp, spos);
+            const bool staged = LDS_SHADOW && sp.shadow_size <= 5000u && shadow_lds_tile(sp, shadow_tile, lane, !decided, spos.px, spos.py, spos.pz, lit);
+            if (!staged && !decided) lit = shadow_slow(sp, spos);
             // the 25-tap path is what sets the kernel's register count: the texels fetched above are dropped across it and
             // fetched again (cache hits; such tiles are few) instead of being kept alive through it
             fetch_material();
@@ -720,9 +773,10 @@ __device__ __forceinline__ void shade_tile(const ShadeParams &sp, const float *l
 __device__ __forceinline__ void stage_lds(const ShadeParams &sp, float *lut) { lut[threadIdx.x] = sp.srgb_lut[threadIdx.x]; }
 
 // ---- the shading pass over a resident G-buffer ------------------------------------------------------------------------
-template <int LOOP, bool STATS>
+template <int LOOP, bool STATS, bool LDS_SHADOW>
 __global__ __launch_bounds__(256) void k_material(const ShadeParams sp) {
     __shared__ float lut[256];
+    __shared__ float shadow_tiles[LDS_SHADOW ? 4 : 1][LDS_SHADOW ? SHADOW_TILE * SHADOW_TILE : 1];   // one per wave (the LDS variant of the PCF slow path)
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (each with its own 4 MiB L2), so physical block b
@@ -739,7 +793,7 @@ __global__ __launch_bounds__(256) void k_material(const ShadeParams sp) {
     stage_lds(sp, lut);
     __syncthreads();
     if (!tile_ok) return;
-    shade_tile<LOOP, STATS>(sp, lut, ty, tx, lane, cur,
+    shade_tile<LOOP, STATS, LDS_SHADOW>(sp, lut, shadow_tiles[LDS_SHADOW ? wave : 0], ty, tx, lane, cur,
                             [&](float4 &gc, float4 &gd, float4 &ge) { gc = sp.g.c[gi]; gd = sp.g.d[gi]; ge = sp.g.e[gi]; });
 }
 
@@ -749,9 +803,10 @@ __global__ __launch_bounds__(256) void k_material(const ShadeParams sp) {
 // triangle, and interpolates uv + light-space position for every covered pixel and world position + tangent frame only
 // for the lit ones -- with the very operations of k_resolve (edges.h, fp contraction off), so the pixels are bit-identical
 // to the G-buffer path.  Everything after the attributes is shade_tile, shared.
-template <int LOOP, bool STATS>
+template <int LOOP, bool STATS, bool LDS_SHADOW>
 __global__ __launch_bounds__(256) void k_material_vis(const ShadeParams sp) {
     __shared__ float lut[256];
+    __shared__ float shadow_tiles[LDS_SHADOW ? 4 : 1][LDS_SHADOW ? SHADOW_TILE * SHADOW_TILE : 1];   // one per wave (the LDS variant of the PCF slow path)
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t ty = blockIdx.y * 8 + (blockIdx.x & 7u), tx = (blockIdx.x >> 3) * 4 + wave;   // XCD-aware order: see k_material
@@ -781,7 +836,7 @@ __global__ __launch_bounds__(256) void k_material_vis(const ShadeParams sp) {
         cur.b0 = interpolate_attr(B, A0, A1, A2, 16); cur.b1 = interpolate_attr(B, A0, A1, A2, 17);
         cur.b2 = __uint_as_float(ob.material);
     }
-    shade_tile<LOOP, STATS>(sp, lut, ty, tx, lane, cur, [&](float4 &gc, float4 &gd, float4 &ge) {
+    shade_tile<LOOP, STATS, LDS_SHADOW>(sp, lut, shadow_tiles[LDS_SHADOW ? wave : 0], ty, tx, lane, cur, [&](float4 &gc, float4 &gd, float4 &ge) {
         // attribute order (XVert::attr): uv 0-1, t 2-4, b 5-7, n 8-10, world 11-13, light space 14-17; planes as gbuffer_pack
         gc = make_float4(interpolate_attr(B, A0, A1, A2, 11), interpolate_attr(B, A0, A1, A2, 12), interpolate_attr(B, A0, A1, A2, 13), interpolate_attr(B, A0, A1, A2, 2));
         gd = make_float4(interpolate_attr(B, A0, A1, A2, 3), interpolate_attr(B, A0, A1, A2, 4), interpolate_attr(B, A0, A1, A2, 5), interpolate_attr(B, A0, A1, A2, 6));
@@ -828,10 +883,10 @@ __global__ __launch_bounds__(256) void k_post_process(const float4 *__restrict__
     if (ldr) { ldr[i * 3] = l.x; ldr[i * 3 + 1] = l.y; ldr[i * 3 + 2] = l.z; }
 }
 
-template <int LOOP, bool STATS>
+template <int LOOP, bool STATS, bool LDS_SHADOW>
 hipError_t launch_variant(const ShadeParams &sp, const ShadeLaunch &L, dim3 grid) {
-    if (L.from_vis) k_material_vis<LOOP, STATS><<<grid, 256, 0, L.stream>>>(sp);
-    else k_material<LOOP, STATS><<<grid, 256, 0, L.stream>>>(sp);
+    if (L.from_vis) k_material_vis<LOOP, STATS, LDS_SHADOW><<<grid, 256, 0, L.stream>>>(sp);
+    else k_material<LOOP, STATS, LDS_SHADOW><<<grid, 256, 0, L.stream>>>(sp);
     return hipGetLastError();
 }
 
@@ -844,8 +899,10 @@ hipError_t launch_shade(const ShadeParams &sp, const ShadeLaunch &L) {
     if (n_tiles == 0) return hipSuccess;
     const uint32_t bpr = (sp.tiles_x + 3) / 4, row_groups = (sp.tiles_y + 7) / 8;
     const dim3 grid(8 * bpr, row_groups);
-    if (L.loop == 2) return L.stats ? launch_variant<2, true>(sp, L, grid) : launch_variant<2, false>(sp, L, grid);
-    return L.stats ? launch_variant<1, true>(sp, L, grid) : launch_variant<1, false>(sp, L, grid);
+    if (sp.debug & 16)   // A/B only: the 25-tap path staged through LDS (a separate instantiation: it costs the default kernels nothing)
+        return L.loop == 2 ? launch_variant<2, false, true>(sp, L, grid) : launch_variant<1, false, true>(sp, L, grid);
+    if (L.loop == 2) return L.stats ? launch_variant<2, true, false>(sp, L, grid) : launch_variant<2, false, false>(sp, L, grid);
+    return L.stats ? launch_variant<1, true, false>(sp, L, grid) : launch_variant<1, false, false>(sp, L, grid);
 }
 
 hipError_t launch_shadow_bounds(const float *map, uint32_t S, float2 *blocks, float2 *bounds, hipStream_t s) {

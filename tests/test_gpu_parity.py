@@ -158,16 +158,21 @@ def test_light_paths_agree(pair, pkg):
 
 def test_shadow_bounds_table_changes_nothing(pair):
     """the min/max table of the shadow map (k_shadow_bounds) only decides pixels whose 25 PCF compares all agree; debug
-    bit 3 runs the shadow test without it: byte-identical float images.  Also after the map was replaced from the host."""
+    bit 3 runs the shadow test without it, bit 4 runs the 25-tap path of edge tiles from a per-wave LDS tile instead of the
+    per-lane register window: byte-identical float images in every combination.  Also after the map was replaced from the host."""
     sc, o, r = pair
     r.pass_shade(sc.desc, sc.settings)
     a = [x.copy() for x in r.read_output()]
     try:
-        r.set_option("debug", 8)
-        r.pass_shade(sc.desc, sc.settings)
-        b = r.read_output()
-        for x, y in zip(a, b):
-            np.testing.assert_array_equal(x.view(np.uint32) if x.dtype == np.float32 else x, y.view(np.uint32) if y.dtype == np.float32 else y)
+        for bits in (8, 16, 24):
+            r.set_option("debug", bits)
+            r.pass_shade(sc.desc, sc.settings)
+            b = r.read_output()
+            for x, y in zip(a, b):
+                np.testing.assert_array_equal(x.view(np.uint32) if x.dtype == np.float32 else x, y.view(np.uint32) if y.dtype == np.float32 else y)
+            frame = r.render_frame(sc.desc, sc.settings)          # the visibility-plane kernels have the same variants
+            np.testing.assert_array_equal(frame, a[2])
+            r.pass_gbuffer(sc.desc)
         r.set_option("debug", 0)
         if sc.shadow_size:
             m = r.read_shadow_map()

@@ -1,7 +1,7 @@
 """whole-frame and shading-pass times of the BASELINE configurations at full size (secondary figures of SURVEY 8d).
 usage: python tools/frame_time.py [config ...]   (default 3 2 1; 4 and 5 are the 256- and 1024-light cases)"""
 import sys, time, numpy as np
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import __graft_entry__ as e
 import torch
 pkg = e.load_package()
@@ -22,10 +22,9 @@ for cfg in [int(a) for a in sys.argv[1:]] or (3, 2, 1):
             print(f"config {cfg}{' + environment map' if env is not None else ''}: {sc.width}x{sc.height} {sc.n_triangles} tris, {len(sc.lights)} lights, "
                   f"whole frame ({'static sun: visibility prepass + shading' if cache else 'shadow raster + visibility prepass + shading'}) "
                   f"{dt*1e3:.3f} ms = {1/dt:.0f} fps, {sc.width*sc.height/dt/1e6:.0f} Mpx/s", flush=True)
-        ms, ms_mat, ms_light = r.time_shade_split(sc.desc, sc.settings, warmup=3, iters=N)
+        ms = r.time_shade(sc.desc, sc.settings, warmup=3, iters=N)
         r.set_option("count_light_evals", 1); r.pass_shade(sc.desc, sc.settings); r.flush(); st = r.stats(); r.set_option("count_light_evals", 0)
         _, mat, _, _ = r.read_gbuffer(want=("material",)); cov = int((mat != 0xFFFFFFFF).sum())
-        print(f"    shading pass {np.mean(ms):.4f} ms (k_material {np.mean(ms_mat):.4f} + k_light {np.mean(ms_light):.4f}); covered {cov/mat.size:.3f}, "
-              f"lit {int(st[6])/max(cov,1):.3f} of covered, {int(st[5])/1e6:.1f} M light evaluations = {int(st[5])/max(np.mean(ms_light),1e-9)/1e6:.0f} G/s; "
-              f"{cov*80/np.mean(ms)/1e6:.0f} GB/s algorithmic", flush=True)
+        print(f"    shading pass {np.mean(ms):.4f} ms; covered {cov/mat.size:.3f}, lit {int(st[6])/max(cov,1):.3f} of covered, "
+              f"{int(st[5])/1e6:.1f} M light evaluations; {cov*80/np.mean(ms)/1e6:.0f} GB/s algorithmic", flush=True)
         r.close()
