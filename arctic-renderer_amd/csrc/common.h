@@ -67,7 +67,7 @@ struct SetupRec {
     int32_t px0, py0, px1, py1;  // inclusive pixel bounds (scissored)
     uint32_t src_tri, object;
     uint32_t order_id;    // 8 * src_tri + index of this sub-triangle: the tie-break of equal depths (first drawn wins)
-    uint32_t exact_f64;   // 1: every |X|, |Y| < 2^25, so the integer edge functions are exact in double arithmetic (geometry.hip, edges.h)
+    uint32_t pad;
 };
 static_assert(sizeof(SetupRec) == 128, "SetupRec layout");
 

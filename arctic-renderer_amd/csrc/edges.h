@@ -36,27 +36,11 @@ __device__ __forceinline__ int64_t edge_eval(const Edges &e, int i, int32_t px, 
 // Every operation rounds once, in this order, wherever it is compiled (the callers disable fp contraction).
 __device__ __forceinline__ void source_barycentrics(const SetupRec &t, int32_t px, int32_t py, float B[3]) {
 #pragma clang fp contract(off)
-    // the exact integer edge functions.  Records whose coordinates are all below 2^25 in magnitude (SetupRec::exact_f64 = 1: every record
-    // up to 4K targets) evaluate them in double: factors below 2^26, results below 2^53, so the products, their difference and the
-    // conversion to float (round to nearest even) are bit for bit what int64 arithmetic gives, at a fraction of the instructions
-    // (a 64-bit multiply-add and an int64 -> float conversion are long sequences); the others take the integer path.
+    Edges e;
+    make_edges(t, e);
     const float inv_area = 1.0f / (float)t.area2;
-    float l1, l2;
-    if (t.exact_f64) {
-        const double Px = (double)(px * 256 + 128), Py = (double)(py * 256 + 128);
-        auto edge = [&](int i) {
-            const int j = (i + 1) % 3;
-            const double dx = (double)(t.X[j] - t.X[i]), dy = (double)(t.Y[j] - t.Y[i]);
-            return __builtin_fma(-dy, Px - (double)t.X[i], dx * (Py - (double)t.Y[i]));
-        };
-        l1 = (float)edge(2) * inv_area;
-        l2 = (float)edge(0) * inv_area;
-    } else {
-        Edges e;
-        make_edges(t, e);
-        l1 = (float)edge_eval(e, 2, px, py) * inv_area;
-        l2 = (float)edge_eval(e, 0, px, py) * inv_area;
-    }
+    const float l1 = (float)edge_eval(e, 2, px, py) * inv_area;
+    const float l2 = (float)edge_eval(e, 0, px, py) * inv_area;
     const float l0 = (1.0f - l1) - l2;
     const float pw0 = l0 * t.iw[0], pw1 = l1 * t.iw[1], pw2 = l2 * t.iw[2];
     const float rr = 1.0f / ((pw0 + pw1) + pw2);

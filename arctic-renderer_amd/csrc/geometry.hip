@@ -263,11 +263,7 @@ __global__ __launch_bounds__(256) void k_setup(const ObjectRec *__restrict__ obj
         ibase += iincl - nb;
         const uint32_t r = rbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
         if (has) {
-            t.src_tri = src; t.object = oi; t.order_id = src * 8u + produced;
-            // every coordinate below 2^25 in magnitude: edge functions of this record are exact in double arithmetic (raster_item, edges.h)
-            int32_t big = 0;
-            for (int k = 0; k < 3; ++k) big = max(big, max(abs(t.X[k]), abs(t.Y[k])));
-            t.exact_f64 = big < (1 << 25) ? 1u : 0u;
+            t.src_tri = src; t.object = oi; t.order_id = src * 8u + produced; t.pad = 0;
             if (r < rec_cap) { recs[r] = t; rec_of[src * 8u + produced] = r; }
             else nb = 0;   // record table full (flagged above; k_raster then does nothing)
             ++produced;
@@ -293,89 +289,8 @@ __global__ __launch_bounds__(256) void k_setup(const ObjectRec *__restrict__ obj
 // differences and the offsets inside a block all fit 32 bits), then +-dx*256 / dy*256 per pixel of the quad: the same exact
 // integers as edge_eval at every pixel.  The four early depth reads are issued together (one memory round trip per item,
 // not four), then the atomics of the pixels that still win.
-// The exact integers of edge_eval travel as DOUBLES when the record allows it (SetupRec::exact_f64 = 1, set by k_setup: every coordinate
-// below 2^25 in magnitude -- always true up to 4K targets, and for everything but triangles reaching far into the guard band
-// above).  Then every quantity here is an integer below 2^53 (factors below 2^26, |edge function| < 2^53), so double products, sums
-// and differences are exact, a sign test on the double is the sign test on the integer, and (float)double rounds to nearest even
-// exactly like (float)int64 -- the same bits as the oracle's integer arithmetic at two thirds of the instructions (a 64-bit
-// integer add is two instructions, a compare more, an int64 -> float conversion about ten; v_add_f64 / v_cmp_f64 / v_cvt_f32_f64
-// are one each).  Records with larger coordinates take raster_item_i64, the same arithmetic on 64-bit integers.
 template <bool DEPTH_ONLY>
-__device__ __forceinline__ void raster_item_f64(const SetupRec &t, uint32_t local, uint32_t lane, const GeomParams *__restrict__ gpp,
-                                            unsigned long long *__restrict__ vis, uint32_t *__restrict__ depth_bits) {
-    const int32_t bx0 = t.px0 >> 4, by0 = t.py0 >> 4;
-    const uint32_t nbx = (uint32_t)((t.px1 >> 4) - bx0 + 1);
-    const int32_t ox = (bx0 + (int32_t)(local % nbx)) * 16, oy = (by0 + (int32_t)(local / nbx)) * 16;   // the block's first pixel
-    const int32_t lx = (int32_t)(lane & 7) * 2, ly = (int32_t)(lane >> 3) * 2;                          // this lane's 2x2 quad in it
-    const int32_t qx = ox + lx, qy = oy + ly;
-    if (qx > t.px1 || qx + 1 < t.px0 || qy > t.py1 || qy + 1 < t.py0) return;
-    Edges e;
-    make_edges(t, e);
-    const float inv_area = 1.0f / (float)t.area2;
-    // edge functions at the quad's first pixel: the block's (wave-uniform, integer) + this lane's offset
-    double eq[3], sx[3], sy[3], bias[3];
-    const double dlx = (double)(lx * 256), dly = (double)(ly * 256);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const double ddx = (double)(int32_t)e.dx[i], ddy = (double)(int32_t)e.dy[i];
-        eq[i] = __builtin_fma(-ddy, dlx, __builtin_fma(ddx, dly, (double)edge_eval(e, i, ox, oy)));
-        sx[i] = -ddy * 256.0;   // one pixel to the right
-        sy[i] = ddx * 256.0;    // one pixel down
-        bias[i] = (double)e.bias[i];
-    }
-    // target row: both rows of the quad lie in the same 8-pixel tile row (qy is even)
-    uint32_t row_base = 0;
-    bool owned = true;
-    if (!DEPTH_ONLY) {
-        const int ty_rel = (qy >> 3) - gpp->tile_y0;
-        int lrow = ty_rel;
-        if (gpp->band_tiles != 0) {   // interleaved shard: rows of other shards are skipped, the own ones are packed
-            owned = row_owned(ty_rel, gpp->band_tiles, gpp->shard_count, gpp->shard_index);
-            lrow = row_local(ty_rel, gpp->band_tiles, gpp->shard_count);
-        }
-        row_base = (uint32_t)lrow * (uint32_t)gpp->tiles_x;
-    }
-    bool ok[4];
-    uint32_t at[4];
-    unsigned long long key[4];
-    const float dz1 = t.z[1] - t.z[0], dz2 = t.z[2] - t.z[0];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int dx = k & 1, dy = k >> 1;
-        const int32_t px = qx + dx, py = qy + dy;
-        ok[k] = owned && !(px < t.px0 || px > t.px1 || py < t.py0 || py > t.py1);
-        const double f0 = eq[0] + (dy ? sy[0] : 0.0) + (dx ? sx[0] : 0.0);
-        const double f1 = eq[1] + (dy ? sy[1] : 0.0) + (dx ? sx[1] : 0.0);
-        const double f2 = eq[2] + (dy ? sy[2] : 0.0) + (dx ? sx[2] : 0.0);
-        ok[k] = ok[k] && !((f0 + bias[0]) < 0.0 || (f1 + bias[1]) < 0.0 || (f2 + bias[2]) < 0.0);
-        const float l1 = (float)f2 * inv_area, l2 = (float)f0 * inv_area;
-        float z = fmaf(l2, dz2, fmaf(l1, dz1, t.z[0]));
-        z = fminf(fmaxf(z, 0.0f), 1.0f);
-        ok[k] = ok[k] && (z < 1.0f);   // depth LESS against the 1.0 clear
-        if (DEPTH_ONLY) {
-            at[k] = (uint32_t)py * (uint32_t)gpp->pitch + (uint32_t)px;
-            key[k] = __float_as_uint(z);
-        } else {
-            at[k] = (row_base + ((uint32_t)px >> 3)) * 64u + ((uint32_t)py & 7u) * 8u + ((uint32_t)px & 7u);
-            key[k] = ((unsigned long long)__float_as_uint(z) << 32) | t.order_id;   // ties: first drawn (smallest order id) wins
-        }
-    }
-    unsigned long long cur[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        cur[k] = 0ull;
-        if (ok[k]) cur[k] = DEPTH_ONLY ? (unsigned long long)depth_bits[at[k]] : vis[at[k]];
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (ok[k] && key[k] < cur[k]) {
-            if (DEPTH_ONLY) atomicMin(depth_bits + at[k], (uint32_t)key[k]);
-            else atomicMin(vis + at[k], key[k]);
-        }
-}
-
-template <bool DEPTH_ONLY>
-__device__ __forceinline__ void raster_item_i64(const SetupRec &t, uint32_t local, uint32_t lane, const GeomParams *__restrict__ gpp,
+__device__ __forceinline__ void raster_item(const SetupRec &t, uint32_t local, uint32_t lane, const GeomParams *__restrict__ gpp,
                                             unsigned long long *__restrict__ vis, uint32_t *__restrict__ depth_bits) {
     const int32_t bx0 = t.px0 >> 4, by0 = t.py0 >> 4;
     const uint32_t nbx = (uint32_t)((t.px1 >> 4) - bx0 + 1);
@@ -438,13 +353,6 @@ __device__ __forceinline__ void raster_item_i64(const SetupRec &t, uint32_t loca
             if (DEPTH_ONLY) atomicMin(depth_bits + at[k], (uint32_t)key[k]);
             else atomicMin(vis + at[k], key[k]);
         }
-}
-
-template <bool DEPTH_ONLY>
-__device__ __forceinline__ void raster_item(const SetupRec &t, uint32_t local, uint32_t lane, const GeomParams *__restrict__ gpp,
-                                            unsigned long long *__restrict__ vis, uint32_t *__restrict__ depth_bits) {
-    if (t.exact_f64) raster_item_f64<DEPTH_ONLY>(t, local, lane, gpp, vis, depth_bits);   // wave-uniform
-    else raster_item_i64<DEPTH_ONLY>(t, local, lane, gpp, vis, depth_bits);
 }
 
 // Persistent: the number of work items is only known on the device (counters[1]), so a fixed grid strides over the item

@@ -822,15 +822,14 @@ __global__ __launch_bounds__(256) void k_material_vis(const ShadeParams sp) {
     TileHead cur;
     cur.a = make_float4(0.0f, 0.0f, 0.0f, 0.0f); cur.b0 = 0.0f; cur.b1 = 0.0f; cur.b2 = __uint_as_float(NO_MATERIAL);
     float B[3] = {0.0f, 0.0f, 0.0f};
-    const float *A0 = nullptr, *A1 = nullptr, *A2 = nullptr;
+    uint32_t v0 = 0, v1 = 0, v2 = 0;   // the source triangle's transformed vertices (indices, not pointers: they stay live across the tile)
     if (key != ~0ull) {
         const SetupRec &t = sp.recs[sp.rec_of[(uint32_t)key]];   // low word of the key = order id (k_setup)
         source_barycentrics(t, px, py, B);
         const ObjectRec &ob = sp.objs[t.object];
         const uint32_t lt = t.src_tri - ob.first_triangle;
-        A0 = sp.xv[ob.first_xvert + ob.indices[3 * lt]].attr;
-        A1 = sp.xv[ob.first_xvert + ob.indices[3 * lt + 1]].attr;
-        A2 = sp.xv[ob.first_xvert + ob.indices[3 * lt + 2]].attr;
+        v0 = ob.first_xvert + ob.indices[3 * lt]; v1 = ob.first_xvert + ob.indices[3 * lt + 1]; v2 = ob.first_xvert + ob.indices[3 * lt + 2];
+        const float *A0 = sp.xv[v0].attr, *A1 = sp.xv[v1].attr, *A2 = sp.xv[v2].attr;
         cur.a = make_float4(interpolate_attr(B, A0, A1, A2, 0), interpolate_attr(B, A0, A1, A2, 1),
                             interpolate_attr(B, A0, A1, A2, 14), interpolate_attr(B, A0, A1, A2, 15));
         cur.b0 = interpolate_attr(B, A0, A1, A2, 16); cur.b1 = interpolate_attr(B, A0, A1, A2, 17);
@@ -838,6 +837,7 @@ __global__ __launch_bounds__(256) void k_material_vis(const ShadeParams sp) {
     }
     shade_tile<LOOP, STATS, LDS_SHADOW>(sp, lut, shadow_tiles[LDS_SHADOW ? wave : 0], ty, tx, lane, cur, [&](float4 &gc, float4 &gd, float4 &ge) {
         // attribute order (XVert::attr): uv 0-1, t 2-4, b 5-7, n 8-10, world 11-13, light space 14-17; planes as gbuffer_pack
+        const float *A0 = sp.xv[v0].attr, *A1 = sp.xv[v1].attr, *A2 = sp.xv[v2].attr;
         gc = make_float4(interpolate_attr(B, A0, A1, A2, 11), interpolate_attr(B, A0, A1, A2, 12), interpolate_attr(B, A0, A1, A2, 13), interpolate_attr(B, A0, A1, A2, 2));
         gd = make_float4(interpolate_attr(B, A0, A1, A2, 3), interpolate_attr(B, A0, A1, A2, 4), interpolate_attr(B, A0, A1, A2, 5), interpolate_attr(B, A0, A1, A2, 6));
         ge = make_float4(interpolate_attr(B, A0, A1, A2, 7), interpolate_attr(B, A0, A1, A2, 8), interpolate_attr(B, A0, A1, A2, 9), interpolate_attr(B, A0, A1, A2, 10));
