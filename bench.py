@@ -316,11 +316,13 @@ def main():
                                        "measured_clock": round(cyc / (N_SIMDS * clk * 1e9 * kernel_ms * 1e-3), 4), "clock_GHz": clk,
                                        "SQ_INSTS_VALU": pmc["SQ_INSTS_VALU"], "transcendental_insts": pmc.get("trans_insts"),
                                        "cycles_per_inst": [CYCLES_PER_VALU, CYCLES_PER_TRANS], "source": f"static: {pmc_src}"}
-            if pmc.get("valu_busy_frac") is not None:
-                roof["valu_issue_frac"]["SQ_ACTIVE_INST_VALU_busy"] = pmc["valu_busy_frac"]
+            if pmc.get("valu_busy_frac") is not None:   # the hardware's own busy counter of the profiled launches (static)
+                roof["valu_issue_frac"]["SQ_ACTIVE_INST_VALU_busy_in_profiled_run"] = pmc["valu_busy_frac"]
             roof["hbm_frac"] = round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if traffic else None
-            roof["bound"] = "valu-issue" if roof["valu_issue_frac"]["measured_clock"] > (roof["hbm_frac"] or 0) else "hbm"
-            roof["bound_note"] = "derived: the larger of valu_issue_frac and hbm_frac; achieved/frac stay the algorithmic HBM figure the target is stated in"
+            busy = max(roof["valu_issue_frac"]["measured_clock"], pmc.get("valu_busy_frac") or 0.0)
+            roof["bound"] = "valu-issue" if busy > (roof["hbm_frac"] or 0) else "hbm"
+            roof["bound_note"] = ("derived: the larger of the VALU issue fraction and hbm_frac; achieved / frac stay the algorithmic-bytes figure "
+                                  "against the HBM peak that BASELINE.json's target is stated in")
         roof.update(extras)
         value = args.steps * shaded / dt / 1e6
         result = {

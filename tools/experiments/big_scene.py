@@ -1,7 +1,7 @@
 """stress: millions of (mostly sub-pixel) triangles through the prepass and the frame paths; checks the frame path against
 the G-buffer path and prints the rasteriser's work counts."""
 import sys, time, numpy as np
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..' if os.path.basename(os.path.dirname(os.path.abspath(__file__))) == 'tools' else os.path.join('..', '..')))
 import __graft_entry__ as e
 pkg = e.load_package()
 S = pkg.scenes

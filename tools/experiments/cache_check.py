@@ -1,7 +1,7 @@
 """is the single-G-buffer timing served from the 256 MiB Infinity Cache?  Two handles with their own G-buffers on ONE
 stream (so nothing overlaps): alternating between them doubles the working set; the per-pass time should not change."""
 import sys, time, numpy as np, torch
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..' if os.path.basename(os.path.dirname(os.path.abspath(__file__))) == 'tools' else os.path.join('..', '..')))
 import __graft_entry__ as e
 pkg = e.load_package()
 sc = pkg.scenes.CONFIGS[3](scale=1.0)

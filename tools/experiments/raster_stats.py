@@ -1,5 +1,5 @@
 import sys, numpy as np
-sys.path.insert(0,'/root/repo')
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..' if os.path.basename(os.path.dirname(os.path.abspath(__file__))) == 'tools' else os.path.join('..', '..')))
 import __graft_entry__ as e
 pkg=e.load_package()
 for cfg in (3,2):

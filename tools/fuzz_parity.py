@@ -6,7 +6,7 @@ n.wo ~ 1e-6, low-roughness highlights): a pixel whose LITERAL fp32 evaluation (o
 usage: python tools/fuzz_parity.py [n_cases] [seed]"""
 import copy, sys, time
 import numpy as np
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..' if os.path.basename(os.path.dirname(os.path.abspath(__file__))) == 'tools' else os.path.join('..', '..')))
 import __graft_entry__ as e
 pkg = e.load_package()
 from oracle import oracle as O

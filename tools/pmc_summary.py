@@ -43,10 +43,14 @@ if "SQ_INSTS_VALU" in out:
     latest["SQ_INSTS_VALU"] = out["SQ_INSTS_VALU"]
     latest["trans_insts"] = out.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
     pm = next((v for k, v in stats.items() if k.startswith("pmc3")), None)
+    N_XCD, N_SIMD = 8, 1024   # GRBM_GUI_ACTIVE comes back summed over the 8 XCDs (one GRBM each): 4.0 M "cycles" for a 0.235 ms launch
     if pm and "GRBM_GUI_ACTIVE" in out:
-        latest["measured_clock_GHz"] = round(out["GRBM_GUI_ACTIVE"] / max(inst["GRBM_GUI_ACTIVE"], 1) / pm["avg_ns"], 3)
+        latest["GRBM_GUI_ACTIVE_per_XCD"] = out["GRBM_GUI_ACTIVE"] / N_XCD
+        latest["measured_clock_GHz"] = round(out["GRBM_GUI_ACTIVE"] / N_XCD / pm["avg_ns"], 3)
         latest["kernel_ns_in_that_pass"] = pm["avg_ns"]
-    if "SQ_ACTIVE_INST_VALU" in out and "SQ_BUSY_CYCLES" in out:
-        latest["SQ_ACTIVE_INST_VALU"] = out["SQ_ACTIVE_INST_VALU"]; latest["SQ_BUSY_CYCLES"] = out["SQ_BUSY_CYCLES"]
+    if "SQ_ACTIVE_INST_VALU" in out and "GRBM_GUI_ACTIVE" in out:
+        latest["SQ_ACTIVE_INST_VALU"] = out["SQ_ACTIVE_INST_VALU"]
+        # rocprof's VALUBusy: SQ_ACTIVE_INST_VALU counts in units of 4 cycles, summed over all SIMDs
+        latest["valu_busy_frac"] = round(out["SQ_ACTIVE_INST_VALU"] * 4 / N_SIMD / (out["GRBM_GUI_ACTIVE"] / N_XCD), 4)
 json.dump(latest, open(os.path.join(dst, "pmc_latest.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))

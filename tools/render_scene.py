@@ -3,7 +3,7 @@ usage: python tools/render_scene.py out.png [config 1-5 | path.gltf/.glb] [scale
 For a glTF file the camera orbits the scene's bounding box; lights: the default sun (src/app.hpp:51-55)."""
 import struct, sys, zlib
 import numpy as np
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..' if os.path.basename(os.path.dirname(os.path.abspath(__file__))) == 'tools' else os.path.join('..', '..')))
 import __graft_entry__ as e
 pkg = e.load_package()
 
