@@ -16,17 +16,19 @@
 //      texels; only tiles on a shadow edge load the 4x4 window and run the 25 compares;
 //   C  fully shadowed pixels are finished (ambient * base: every light term of ps_main carries (1 - shadow),
 //      forward.hlsl:222,230) without ever loading their position / tangent frame (48 B/pixel);
-//   D  lit pixels: normal map, sun + point lights.  Two loops: scalar fp32 with the lights through the scalar cache (few
-//      lights, small register footprint), or two lights at a time in packed fp32 from LDS (many lights);
+//   D  lit pixels: normal map, sun + point lights.  Two loops, both fed through the scalar cache: plain fp32 (few lights), or two
+//      lights at a time in packed fp32 with SGPR light pairs and op_sel-shared per-pixel register pairs (many lights);
 //   E  one tonemap + gamma + RGBA8 store for every pixel of the tile.
 // Scalar-per-pixel FP32: no MFMA, by design.  The kernel is VALU-issue bound with many lights and memory bound with few:
 // it is written against the issue costs measured by tools/experiments/valu_rates.hip (profiles/r2_valu_rates.txt):
 // v_add/mul/fma ~2.6-2.9 cycles per wave64, v_pk_* ~4.4, min/max/cvt/cmp/floor/bfe ~4.2, transcendentals 8.
 //
 // Numerics: texel coordinates/weights and the whole shadow test are computed exactly as the
-// CPU oracle does (fp contract off, IEEE divide) because they feed discontinuous decisions; the
-// BRDF and tonemap use v_rcp/v_rsq/v_exp/v_log (~1 ulp) and free contraction, inside the 1e-4
-// per-channel budget of the output.
+// CPU oracle does (IEEE divide, every operation rounding once in the oracle's order) because they feed
+// discontinuous decisions; the BRDF and tonemap use v_rcp/v_rsq/v_exp/v_log (~1 ulp), inside the 1e-4
+// per-channel budget of the output.  The file is compiled with -ffp-contract=off and every fused
+// multiply-add is written out, so k_material and k_material_vis round identically (their images are
+// compared bit for bit).
 #include "common.h"
 #include "edges.h"
 
