@@ -386,6 +386,24 @@ def cpu_baseline(pkg, sc, r, cpu_rows):
         reps1 += 1
         dt1 = time.perf_counter() - t
     one_thread = int((mat[mid:mid + n1] != 0xFFFFFFFF).sum()) * reps1 / dt1 / 1e6
+    # parity in the same run: a stripe of the frame the GPU has just shaded against the float64 oracle
+    parity = None
+    try:
+        r.set_option("keep_float_output", 1)
+        r.pass_shade(sc.desc, sc.settings)
+        g_ldr, _, g_rgba = r.read_output()
+        r.set_option("keep_float_output", 0)
+        o.set_precision(64)
+        rows_p = min(48, attrs.shape[0])
+        y0 = max(0, int(attrs.shape[0] * 0.72) - rows_p // 2)      # through the sunlit floor and its shadow edges
+        ref = o.shade_gbuffer(sc.desc, sc.settings, attrs[y0:y0 + rows_p], mat[y0:y0 + rows_p], threads=threads, want=("ldr", "rgba8"))
+        err = np.abs(ref["ldr"] - g_ldr[y0:y0 + rows_p])
+        parity = {"rows": [y0, y0 + rows_p], "max_abs_ldr_error": float(err.max()), "p9999_ldr_error": float(np.quantile(err, 0.9999)),
+                  "rgba8_mismatch_rate": float((ref["rgba8"] != g_rgba[y0:y0 + rows_p]).mean()),
+                  "rgba8_max_lsb": int(np.abs(ref["rgba8"].astype(np.int16) - g_rgba[y0:y0 + rows_p].astype(np.int16)).max()),
+                  "against": "float64 evaluation of the oracle (oracle/arctic_oracle.cpp) on the same G-buffer, shadow map and lights; gate 1e-4"}
+    except Exception as exc:
+        parity = {"error": str(exc)}
     o.close()
     model = ""
     try:
@@ -393,7 +411,7 @@ def cpu_baseline(pkg, sc, r, cpu_rows):
     except Exception:
         pass
     return {"value": round(px * reps / dt / 1e6, 3), "unit": "Mpixels/s", "cores": threads, "kind": "port",
-            "one_thread_value": round(one_thread, 4), "cpu_model": model,
+            "one_thread_value": round(one_thread, 4), "cpu_model": model, "parity_in_this_run": parity,
             "sample": f"rows {start}..{start + n} of the {sc.height}-row frame x {reps} ({px * reps} shaded pixels, {dt:.1f} s), same "
                       f"G-buffer, shadow map and {len(sc.lights)} lights; scalar fp32 C++ oracle, {threads} threads, no culling"}
 

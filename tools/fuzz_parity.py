@@ -2,7 +2,8 @@
 Bars as in tests/test_gpu_parity.py: shadow map / G-buffer bit-exact, float LDR image within 1e-4 -- except on pixels
 where the reference formula itself is ill-conditioned in fp32 (tests/test_oracle_noise_floor.py: grazing views with
 n.wo ~ 1e-6, low-roughness highlights): a pixel whose LITERAL fp32 evaluation (oracle precision 32) is itself more than
-5e-5 away from the float64 value is reported and must stay within 4x that distance instead.
+5e-5 away from the float64 value, or whose float64 value moves by more than 2.5e-5 when tangent frame and world position
+move by one fp32 ulp, is reported and must stay within 4x the larger of those two distances instead.
 usage: python tools/fuzz_parity.py [n_cases] [seed]"""
 import copy, sys, time
 import numpy as np
@@ -51,9 +52,21 @@ for case in range(n_cases):
     oldr, _, orgba = o.read_output()
     hldr, _, hrgba = r.read_output()
     e_hip, e_f32 = np.abs(oldr - hldr).max(-1), np.abs(oldr - ldr32).max(-1)
-    ill = e_f32 > 5e-5                                       # the literal fp32 evaluation itself misses the float64 value here
+    # conditioning of the formula itself: the float64 oracle on the same G-buffer with the tangent frame and the world position
+    # (attributes 2..13) moved by ONE fp32 ulp per component, in four sign patterns.  At a grazing view (n.wo ~ 1e-5 under the normal
+    # map) that alone moves the exact result by 1e-3: no fp32 evaluation -- whose normalised n carries half an ulp of rounding per
+    # component -- can promise 1e-4 there, whether or not the oracle's own fp32 path happens to land close
+    sens = np.zeros_like(e_hip)
+    prng = np.random.default_rng(case)
+    for pattern in range(4):
+        up = np.ones(og[0][..., 2:14].shape, bool) if pattern == 0 else (~np.ones(og[0][..., 2:14].shape, bool) if pattern == 1 else prng.random(og[0][..., 2:14].shape) < 0.5)
+        pert = og[0].copy()
+        pert[..., 2:14] = np.where(up, np.nextafter(pert[..., 2:14], np.float32(np.inf)), np.nextafter(pert[..., 2:14], np.float32(-np.inf)))
+        alt = o.shade_gbuffer(desc, settings, pert, og[1], threads=threads, want=("ldr",))["ldr"]
+        sens = np.maximum(sens, np.abs(alt - oldr).max(-1))
+    ill = (e_f32 > 5e-5) | (sens > 2.5e-5)                   # the literal fp32 evaluation misses the float64 value, or one input ulp moves it
     err = float(e_hip[~ill].max())
-    ill_ok = bool((e_hip[ill] <= 4 * e_f32[ill]).all())
+    ill_ok = bool((e_hip[ill] <= 4 * np.maximum(e_f32, sens)[ill]).all())
     n_ill, worst_ill = int(ill.sum()), float(e_hip[ill].max()) if ill.any() else 0.0
     mism = float((orgba != hrgba).mean())
     cov = float((og[1] != 0xFFFFFFFF).mean())
@@ -77,11 +90,12 @@ for case in range(n_cases):
     worst["ldr"], worst["rgba"] = max(worst["ldr"], err), max(worst["rgba"], mism)
     print(f"case {case:2d} config {cfg} {sc.width}x{sc.height} tm {settings[0]} sky {env is not None} coverage {cov:.2f}: shadow map {'==' if sm_ok else '!='}, "
           f"G-buffer {'==' if gb_ok else '!='}, max |ldr err| {err:.2e}, fp32-ill-conditioned pixels {n_ill} (HIP max {worst_ill:.1e}), rgba8 mismatch {mism:.1e}{shard_note} -> {'ok' if ok else 'FAIL'}", flush=True)
-    if only >= 0:
+    if only >= 0 or not ok:   # a failing case dumps its worst pixels (the random stream of a lone re-run differs: shard draws, see below)
         ys, xs = np.nonzero(e_hip > 2e-5)
         print("pixels above 2e-5:", len(ys))
         _, ohdr, _ = o.read_output(); _, hhdr, _ = r.read_output()
-        for y, x in list(zip(ys, xs))[:8]:
+        order = np.argsort(-e_hip[ys, xs])[:8]
+        for y, x in zip(ys[order], xs[order]):
             a = og[0][y, x]
             print(f"  ({x},{y}) ldr o {oldr[y, x]} h {hldr[y, x]} hdr o {ohdr[y, x]} h {hhdr[y, x]} mat {og[1][y, x]} uv {a[0:2]} n {a[8:11]} world {a[11:14]} ls {a[14:18]}")
             # the same pixel through the oracle's literal fp32 arithmetic
