@@ -65,10 +65,10 @@ __device__ __forceinline__ void wrap_axis(float u, uint32_t n, int &i0, int &i1,
     float x = uw * (float)n - 0.5f;
     float xf = floorf(x);
     f = x - xf;
-    i0 = (int)xf;
-    i1 = i0 + 1;
-    if (i0 < 0) i0 += (int)n;
-    if (i1 >= (int)n) i1 -= (int)n;
+    i0 = (int)xf;                       // in [-1, n - 1]
+    i1 = i0 + 1;                        // in [0, n]
+    i0 = i0 < 0 ? (int)n - 1 : i0;      // WRAP: one compare + select each (uw in [0, 1] keeps the indices within one period)
+    i1 = i1 == (int)n ? 0 : i1;
 }
 
 // one texture of a material, WAVE-UNIFORM (the descriptor lives in SGPRs).  packed = 0: plain RGBA8 image.  packed = 1: the
@@ -504,12 +504,21 @@ __device__ __forceinline__ f3 post_process(f3 c, int tm, float inv_gamma, float 
             return fabsf(v) < 0.015625f ? series : direct;
         };
         t = mk(one_minus_exp(x.x), one_minus_exp(x.y), one_minus_exp(x.z));
-    } else if (tm == 2) {   // tm_aces :15-25, :50-57
-        f3 i = mk(fm(0.04823f, c.z, fm(0.35458f, c.y, 0.59719f * c.x)), fm(0.01566f, c.z, fm(0.90834f, c.y, 0.07600f * c.x)),
-                  fm(0.837f, c.z, fm(0.13383f, c.y, 0.02840f * c.x)));
-        i = mk(rrt_odt(i.x), rrt_odt(i.y), rrt_odt(i.z));
-        t = mk(sat(fm(-0.07367f, i.z, fm(-0.53108f, i.y, 1.60475f * i.x))), sat(fm(-0.00605f, i.z, fm(1.10813f, i.y, -0.10208f * i.x))),
-               sat(fm(1.07f, i.z, fm(-0.07276f, i.y, -0.00327f * i.x))));
+    } else if (tm == 2) {   // tm_aces :15-25, :50-57; channels x and y as a packed pair (same operations lane for lane), z plain
+        typedef float p2 __attribute__((ext_vector_type(2)));
+        auto pfm = [](p2 a, p2 b, p2 c2) { return __builtin_elementwise_fma(a, b, c2); };
+        const p2 cx = {c.x, c.x}, cy = {c.y, c.y}, cz = {c.z, c.z};
+        p2 ixy = pfm((p2){0.04823f, 0.01566f}, cz, pfm((p2){0.35458f, 0.90834f}, cy, (p2){0.59719f, 0.07600f} * cx));
+        float iz = fm(0.837f, c.z, fm(0.13383f, c.y, 0.02840f * c.x));
+        {   // rrt_and_odt_fit
+            const p2 a = pfm(ixy, ixy + (p2){0.0245786f, 0.0245786f}, (p2){-0.000090537f, -0.000090537f});
+            const p2 b = pfm(ixy, pfm((p2){0.983729f, 0.983729f}, ixy, (p2){0.4329510f, 0.4329510f}), (p2){0.238081f, 0.238081f});
+            ixy = a * (p2){rcp(b.x), rcp(b.y)};
+            iz = rrt_odt(iz);
+        }
+        const p2 ix = {ixy.x, ixy.x}, iy = {ixy.y, ixy.y}, izz = {iz, iz};
+        const p2 oxy = pfm((p2){-0.07367f, -0.00605f}, izz, pfm((p2){-0.53108f, 1.10813f}, iy, (p2){1.60475f, -0.10208f} * ix));
+        t = mk(sat(oxy.x), sat(oxy.y), sat(fm(1.07f, iz, fm(-0.07276f, ixy.y, -0.00327f * ixy.x))));
     } else {                // tm_reinhard :39-42 (and `default:`)
         t = mk(c.x * rcp(c.x + 1.0f), c.y * rcp(c.y + 1.0f), c.z * rcp(c.z + 1.0f));
     }
@@ -522,10 +531,15 @@ __device__ __forceinline__ uint32_t unorm8(float x) { return (uint32_t)__builtin
 
 // first wave of G-buffer loads: what every pixel needs (28 B)
 struct TileHead { float4 a; float b0, b1, b2; };   // a = uv.xy, ls.xy; b = ls.z, ls.w, material id
-__device__ __forceinline__ TileHead load_head(const GBuffer &g, size_t idx) {
+// (the tile's base addresses are wave-uniform -- scalar 64-bit arithmetic -- and the lane adds a 32-bit offset: saddr loads)
+typedef float f3v __attribute__((ext_vector_type(3), aligned(4)));
+typedef float f4a __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 gload_f4(const void *base, uint32_t o) { const f4a v = *(const f4a __attribute__((address_space(1))) *)((gchar)base + o); return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ TileHead load_head(const GBuffer &g, size_t tile /* wave-uniform */, uint32_t lane) {
     TileHead t;
-    t.a = g.a[idx];
-    t.b0 = g.b[idx * 3]; t.b1 = g.b[idx * 3 + 1]; t.b2 = g.b[idx * 3 + 2];
+    t.a = gload_f4(g.a + tile * 64, lane * 16u);
+    const f3v b = *(const f3v __attribute__((address_space(1))) *)((gchar)(g.b + tile * 192) + lane * 12u);
+    t.b0 = b.x; t.b1 = b.y; t.b2 = b.z;
     return t;
 }
 
@@ -602,10 +616,7 @@ __device__ __forceinline__ void shade_tile(const ShadeParams &sp, const float *l
             pt.q00 = pt.q10 = pt.q01 = pt.q11 = make_uint2(0x808080u, 0u); pt.w00 = pt.w10 = pt.w01 = pt.w11 = 0.25f;
             return;
         }
-        unsigned long long todo = __ballot(covered);
-        while (todo) {   // one trip per distinct material of the tile: almost always one
-            const uint32_t m = __builtin_amdgcn_readlane(mat, __ffsll((long long)todo) - 1);
-            const bool mine = covered && mat == m;
+        auto fetch = [&](uint32_t m, bool mine) {   // m wave-uniform: the descriptor comes through the scalar unit
             const TexS d0 = tex_desc(sp.tex, m * 3);
             if (mine) {
                 if (d0.packed) fetch_taps<8>(d0, u, v, pt);
@@ -616,6 +627,18 @@ __device__ __forceinline__ void shade_tile(const ShadeParams &sp, const float *l
                     plain = true;
                 }
             }
+        };
+        unsigned long long todo = __ballot(covered);
+        if (todo == 0ull) return;
+        const uint32_t m0 = __builtin_amdgcn_readlane(mat, __ffsll((long long)todo) - 1);
+        if (__ballot(covered && mat != m0) == 0ull) {   // one material in the tile (almost always): straight-line code, the texel
+            fetch(m0, covered);                        // loads go straight into their registers
+            return;
+        }
+        while (todo) {   // a waterfall loop over the distinct materials of a mixed tile
+            const uint32_t m = __builtin_amdgcn_readlane(mat, __ffsll((long long)todo) - 1);
+            const bool mine = covered && mat == m;
+            fetch(m, mine);
             todo &= ~__ballot(mine);
         }
     };
@@ -789,14 +812,16 @@ __global__ __launch_bounds__(256) void k_material(const ShadeParams sp) {
     // grid = (8 x workgroups per tile row, groups of 8 tile rows): the linear block id advances along x first, so id % 8 = x % 8
     const uint32_t ty = blockIdx.y * 8 + (blockIdx.x & 7u), tx = (blockIdx.x >> 3) * 4 + wave;
     const bool tile_ok = ty < sp.tiles_y && tx < sp.tiles_x;
-    const size_t gi = ((size_t)ty * sp.tiles_x + tx) * 64 + lane;
+    const size_t tile = (size_t)ty * sp.tiles_x + tx;   // wave-uniform
     TileHead cur;
-    if (tile_ok) cur = load_head(sp.g, gi);   // in flight while LDS is staged
+    if (tile_ok) cur = load_head(sp.g, tile, lane);   // in flight while LDS is staged
     stage_lds(sp, lut);
     __syncthreads();
     if (!tile_ok) return;
     shade_tile<LOOP, STATS, LDS_SHADOW>(sp, lut, shadow_tiles[LDS_SHADOW ? wave : 0], ty, tx, lane, cur,
-                            [&](float4 &gc, float4 &gd, float4 &ge) { gc = sp.g.c[gi]; gd = sp.g.d[gi]; ge = sp.g.e[gi]; });
+                            [&](float4 &gc, float4 &gd, float4 &ge) {
+                                gc = gload_f4(sp.g.c + tile * 64, lane * 16u); gd = gload_f4(sp.g.d + tile * 64, lane * 16u); ge = gload_f4(sp.g.e + tile * 64, lane * 16u);
+                            });
 }
 
 // ---- the same without a G-buffer (whole frames): the tile walk straight from the visibility plane ----------------------
