@@ -71,6 +71,26 @@ struct SetupRec {
 };
 static_assert(sizeof(SetupRec) == 128, "SetupRec layout");
 
+// what the rasteriser reads per work item, written by k_setup next to the SetupRec, 128 B (two scalar loads).
+// Edge function i of the record at pixel (px, py), i.e. edges.h's edge_eval, as the plane C + A*px + B*py held in binary64:
+// with every snapped coordinate below 2^24 in magnitude all three terms and every partial sum are integers below 2^53, so
+// the binary64 evaluation IS the 64-bit integer one (flag RASTER_EXACT_F64; other records take the integer path).
+struct RasterRec {
+    double A[3], B[3], C[3];   // C[1] has the fill-rule threshold folded in (covered <=> value >= 0); edges 0 and 2 also feed the depth
+    double t0, t2;             // fill-rule thresholds of edges 0 and 2: covered <=> e >= t, t = 0 (top-left edge) or 1
+    float z0, dz1, dz2;        // depth plane: z = fma(l2, dz2, fma(l1, dz1, z0))
+    float inv_area;            // 1 / (float)area2
+    uint32_t order_id;
+    uint32_t flags;
+    uint32_t pad[4];
+};
+static_assert(sizeof(RasterRec) == 128, "RasterRec layout");
+constexpr uint32_t RASTER_EXACT_F64 = 1u;
+// a work item = {record, block}: block = bx | by << 12 | ITEM_SCISSOR (the 16x16 block is cut by the scissor / the target's edge);
+// record ITEM_SKIP: an entry of a large record whose block no edge function reaches (its slot was taken before that was known)
+constexpr uint32_t ITEM_SCISSOR = 1u << 24;
+constexpr uint32_t ITEM_SKIP = 0xFFFFFFFFu;
+
 // frame constants for the geometry kernels
 struct GeomParams {
     float clip_from_world[16];   // proj_view (forward) or light_proj_view (shadow)
@@ -83,6 +103,7 @@ struct GeomParams {
     int32_t pitch;               // shadow pass: row pitch of the row-major depth map (= S)
     int32_t band_tiles;          // interleaved shard: tile rows per band (0 = contiguous shard), else see row_* below
     int32_t shard_index, shard_count;
+    int32_t raster_flags;        // 1: every record takes the integer rasteriser (ARCTIC_OPT_DEBUG bit 5: A/B of the two paths)
 };
 // tile-row bookkeeping of a shard.  ty_rel = global tile row - tile_y0.  Contiguous shard: local == ty_rel.  Interleaved
 // shard: bands of band_tiles tile rows are dealt round-robin, shard r owns bands r, r + n, ...; local rows are packed.
@@ -157,11 +178,11 @@ inline uint32_t shadow_bounds_pitch(uint32_t S) { return S >= 4 && S <= 4900 ? (
 hipError_t launch_vertex(const ObjectRec *objs, const uint32_t *block_obj, const uint32_t *block_first,
                          uint32_t n_blocks, const GeomParams *gp, XVert *xv, int clip_only, hipStream_t s);
 hipError_t launch_setup(const ObjectRec *objs, const uint32_t *block_obj, const uint32_t *block_first, uint32_t n_blocks,
-                        const GeomParams *gp, const XVert *xv, SetupRec *recs, uint32_t *rec_of /*8 per source triangle*/,
+                        const GeomParams *gp, const XVert *xv, SetupRec *recs, RasterRec *rrecs, uint32_t *rec_of /*8 per source triangle*/,
                         uint2 *items, uint32_t item_cap, uint32_t rec_cap, uint32_t *counters /*records, items, overflow: zeroed before*/, hipStream_t s);
-hipError_t launch_raster_vis(const SetupRec *recs, const uint2 *items, uint32_t item_cap, const uint32_t *counters, uint32_t grid_blocks,
+hipError_t launch_raster_vis(const SetupRec *recs, const RasterRec *rrecs, const uint2 *items, uint32_t item_cap, const uint32_t *counters, uint32_t grid_blocks,
                              const GeomParams *gp, unsigned long long *vis, hipStream_t s);
-hipError_t launch_raster_depth(const SetupRec *recs, const uint2 *items, uint32_t item_cap, const uint32_t *counters, uint32_t grid_blocks,
+hipError_t launch_raster_depth(const SetupRec *recs, const RasterRec *rrecs, const uint2 *items, uint32_t item_cap, const uint32_t *counters, uint32_t grid_blocks,
                                const GeomParams *gp, uint32_t *depth_bits, hipStream_t s);
 hipError_t launch_resolve(const unsigned long long *vis, const SetupRec *recs, const uint32_t *rec_of, const ObjectRec *objs, const XVert *xv,
                           const GeomParams *gp, uint32_t n_tiles, GBuffer g, hipStream_t s);

@@ -130,10 +130,50 @@ __device__ bool setup_triangle(const CV &a, const CV &b, const CV &c, const Geom
     return t.px0 <= t.px1 && t.py0 <= t.py1;
 }
 
-// raster work items are 16x16-pixel blocks (one wave, a 2x2 pixel quad per lane): the per-item record search and record
-// fetch are latency, so fewer, fatter items
+// raster work items are 16x16-pixel blocks (one wave): the per-item record fetch is latency, so fewer, fatter items
 __device__ __forceinline__ uint32_t tiles_of(const SetupRec &t) {
     return (uint32_t)((t.px1 >> 4) - (t.px0 >> 4) + 1) * (uint32_t)((t.py1 >> 4) - (t.py0 >> 4) + 1);
+}
+
+// the record's edge functions as binary64 planes over pixel coordinates (RasterRec, common.h).  edge_eval(e, i, px, py) =
+// dx*(256 py + 128 - y0) - dy*(256 px + 128 - x0) = C + A px + B py with A = -256 dy, B = 256 dx, C = dx (128 - y0) - dy (128 - x0).
+// With M = max |X|, |Y| < 2^24: |dx|, |dy| < 2^25, |128 - y0| < 2^25, so |C| < 2^51, |A px|, |B py| < 2^47 (px, py < 2^14):
+// every product and partial sum is an integer below 2^53, i.e. exact in binary64 in any order.
+__device__ __forceinline__ void make_raster_rec(const SetupRec &t, bool force_integer, RasterRec &q) {
+    Edges e;
+    make_edges(t, e);
+    int32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        m = max(m, max(abs(t.X[i]), abs(t.Y[i])));
+        const int64_t c = e.dx[i] * (int64_t)(128 - e.y0[i]) - e.dy[i] * (int64_t)(128 - e.x0[i]);   // 64-bit integers: exact whatever the magnitudes
+        const int64_t thr = -e.bias[i];                                                               // covered <=> e + bias >= 0 <=> e >= -bias
+        q.A[i] = (double)(-e.dy[i] * 256);
+        q.B[i] = (double)(e.dx[i] * 256);
+        q.C[i] = (double)(i == 1 ? c - thr : c);
+        if (i == 0) q.t0 = (double)thr;
+        if (i == 2) q.t2 = (double)thr;
+    }
+    q.z0 = t.z[0]; q.dz1 = t.z[1] - t.z[0]; q.dz2 = t.z[2] - t.z[0];
+    q.inv_area = 1.0f / (float)t.area2;
+    q.order_id = t.order_id;
+    q.flags = (m < (1 << 24) && !force_integer) ? RASTER_EXACT_F64 : 0u;
+    q.pad[0] = q.pad[1] = q.pad[2] = q.pad[3] = 0;
+}
+
+// can any pixel of the 16x16 block (bx, by) be covered?  The largest value of each edge function over the block's pixel centres
+// (at the corner its gradient points to) against the edge's threshold: exact, so a block is dropped only when it is empty.
+__device__ __forceinline__ bool block_reachable(const RasterRec &q, int32_t bx, int32_t by) {
+    const double x0 = (double)(bx * 16), y0 = (double)(by * 16);
+    bool any = true;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double x = q.A[i] > 0.0 ? x0 + 15.0 : x0, y = q.B[i] > 0.0 ? y0 + 15.0 : y0;
+        const double best = __builtin_fma(q.A[i], x, __builtin_fma(q.B[i], y, q.C[i]));
+        const double thr = i == 0 ? q.t0 : (i == 2 ? q.t2 : 0.0);
+        any = any && best >= thr;
+    }
+    return any;
 }
 
 // coverage + barycentrics (l1, l2) + clamped depth
@@ -207,7 +247,7 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v, uint32_t lane
 
 __global__ __launch_bounds__(256) void k_setup(const ObjectRec *__restrict__ objs, const uint32_t *__restrict__ block_obj,
                                                const uint32_t *__restrict__ block_first, const GeomParams *__restrict__ gpp,
-                                               const XVert *__restrict__ xv, SetupRec *__restrict__ recs,
+                                               const XVert *__restrict__ xv, SetupRec *__restrict__ recs, RasterRec *__restrict__ rrecs,
                                                uint32_t *__restrict__ rec_of, uint2 *__restrict__ items, uint32_t item_cap,
                                                uint32_t rec_cap, uint32_t *__restrict__ counters) {
     const uint32_t oi = block_obj[blockIdx.x];
@@ -243,8 +283,27 @@ __global__ __launch_bounds__(256) void k_setup(const ObjectRec *__restrict__ obj
     uint32_t produced = 0;   // sub-triangles this lane has emitted so far = index of the next one in draw order
     for (int f = 1; __syncthreads_or(f + 1 < n); ++f) {
         SetupRec t;
+        RasterRec q = {};
         const bool has = (f + 1 < n) && setup_triangle(poly[0], poly[f], poly[f + 1], gp, t);
-        uint32_t nb = has ? tiles_of(t) : 0u;
+        // blocks of the bounding box no edge function reaches are not emitted: as a bit mask for records of up to 16 blocks
+        // (nearly all), at emission for larger ones -- their slots are taken before the wave looks at them, so those become ITEM_SKIP
+        int32_t bx0 = 0, by0 = 0;
+        uint32_t nbx = 1, nbb = 0, mask = 0, nb = 0;
+        if (has) {
+            make_raster_rec(t, (gp.raster_flags & 1) != 0, q);
+            bx0 = t.px0 >> 4; by0 = t.py0 >> 4;
+            nbx = (uint32_t)((t.px1 >> 4) - bx0 + 1);
+            nbb = tiles_of(t);
+            nb = nbb;
+            if (nbb <= 16 && (q.flags & RASTER_EXACT_F64)) {
+                uint32_t x = 0, y = 0;
+                for (uint32_t j = 0; j < nbb; ++j) {
+                    if (block_reachable(q, bx0 + (int32_t)x, by0 + (int32_t)y)) mask |= 1u << j;
+                    if (++x == nbx) { x = 0; ++y; }
+                }
+                nb = (uint32_t)__popc(mask);
+            } else if (nbb <= 16) mask = (1u << nbb) - 1u;
+        }
         const unsigned long long m = __ballot(has);
         const uint32_t iincl = wave_inclusive_sum(nb, lane);
         const uint32_t itotal = __shfl(iincl, 63);
@@ -264,38 +323,146 @@ __global__ __launch_bounds__(256) void k_setup(const ObjectRec *__restrict__ obj
         const uint32_t r = rbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
         if (has) {
             t.src_tri = src; t.object = oi; t.order_id = src * 8u + produced; t.pad = 0;
-            if (r < rec_cap) { recs[r] = t; rec_of[src * 8u + produced] = r; }
-            else nb = 0;   // record table full (flagged above; k_raster then does nothing)
+            q.order_id = t.order_id;
+            if (r < rec_cap) { recs[r] = t; rrecs[r] = q; rec_of[src * 8u + produced] = r; }
+            else nb = nbb = 0;   // record table full (flagged above; k_raster then does nothing)
             ++produced;
         }
+        const auto block_code = [&](int32_t bx, int32_t by) {
+            const bool whole = bx * 16 >= gp.sc_x0 && bx * 16 + 16 <= gp.sc_x1 && by * 16 >= gp.sc_y0 && by * 16 + 16 <= gp.sc_y1;
+            return (uint32_t)bx | ((uint32_t)by << 12) | (whole ? 0u : ITEM_SCISSOR);
+        };
         // small records: the lane writes its own items; large ones (a wall across the screen is thousands of blocks): the
         // whole wave writes them, 64 per step
-        if (nb <= 16)
-            for (uint32_t j = 0; j < nb; ++j) if (ibase + j < item_cap) items[ibase + j] = make_uint2(r, j);
-        for (unsigned long long big = __ballot(nb > 16); big != 0ull; big &= big - 1ull) {
+        if (nbb <= 16 && nb != 0) {
+            uint32_t x = 0, y = 0, at = ibase;
+            for (uint32_t j = 0; j < nbb; ++j) {
+                if ((mask >> j) & 1u) { if (at < item_cap) items[at] = make_uint2(r, block_code(bx0 + (int32_t)x, by0 + (int32_t)y)); ++at; }
+                if (++x == nbx) { x = 0; ++y; }
+            }
+        }
+        for (unsigned long long big = __ballot(nbb > 16); big != 0ull; big &= big - 1ull) {
             const int L = __ffsll((long long)big) - 1;
-            const uint32_t R = __shfl(r, L), NB = __shfl(nb, L), IB = __shfl(ibase, L);
-            for (uint32_t j = lane; j < NB; j += 64) if (IB + j < item_cap) items[IB + j] = make_uint2(R, j);
+            const uint32_t R = __shfl(r, L), NB = __shfl(nbb, L), IB = __shfl(ibase, L), NX = __shfl(nbx, L);
+            const int32_t X0 = __shfl(bx0, L), Y0 = __shfl(by0, L);
+            RasterRec w;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { w.A[i] = __shfl(q.A[i], L); w.B[i] = __shfl(q.B[i], L); w.C[i] = __shfl(q.C[i], L); }
+            w.t0 = __shfl(q.t0, L); w.t2 = __shfl(q.t2, L);
+            const bool exact = (__shfl(q.flags, L) & RASTER_EXACT_F64) != 0;
+            for (uint32_t j = lane; j < NB; j += 64) {
+                const int32_t bx = X0 + (int32_t)(j % NX), by = Y0 + (int32_t)(j / NX);
+                const bool live = !exact || block_reachable(w, bx, by);
+                if (IB + j < item_cap) items[IB + j] = make_uint2(live ? R : ITEM_SKIP, block_code(bx, by));
+            }
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// raster: one wavefront per (triangle, 16x16 block) work item, a 2x2 pixel quad per lane
+// raster: one wavefront per (triangle, 16x16 block) work item, four pixels per lane
 // ---------------------------------------------------------------------------------------------
-// one work item: the lane's 2x2 quad of the 16x16 block `local` of record t.  Everything that depends only on the
-// record and the block (edge setup, the edge functions at the block's first pixel, 64-bit) is wave-uniform and runs on the
-// scalar unit; a lane adds its own offset with two 32x32+64 multiply-adds per edge (the 24.8 coordinates, their
-// differences and the offsets inside a block all fit 32 bits), then +-dx*256 / dy*256 per pixel of the quad: the same exact
-// integers as edge_eval at every pixel.  The four early depth reads are issued together (one memory round trip per item,
-// not four), then the atomics of the pixels that still win.
+// what k_raster needs of GeomParams, read once per wave
+struct RasterFrame {
+    int32_t sc_x0, sc_y0, sc_x1, sc_y1;
+    int32_t tiles_x, tile_y0, pitch, band_tiles, shard_index, shard_count;
+};
+
+// One work item through the binary64 planes of its RasterRec (exact, see make_raster_rec).  The record sits in scalar registers;
+// nothing is set up per item: a lane evaluates the three planes at its own pixel coordinates, 15-18 v_fma_f64 for its four pixels.
+// The pixels of a lane are chosen so that every wave-wide memory instruction touches the fewest lines: the forward pass takes the
+// block as its four 8x8 tiles of the tile-major visibility plane (pixel k of lane l = pixel l of tile k: one 512-byte run per
+// load / atomic), the shadow pass as four 16x4 strips of the row-major map (four 64-byte rows).  Covered <=> no sign bit among the
+// three thresholded edge values (one v_or3 on the high words); the depth is edges.h's / the oracle's expression on the same exact
+// numerators.  Early depth test: the four reads are issued together, then the atomics of the pixels that still win.
+typedef int32_t i2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int32_t high_word(double v) { return __builtin_bit_cast(i2v, v).y; }
+typedef char __attribute__((address_space(1))) *gbytes;   // wave-uniform base (SGPR pair) + 32-bit per-lane byte offset: the saddr form, no 64-bit address arithmetic
+
+template <bool DEPTH_ONLY, bool CUT /* the block is cut by the scissor: test every pixel against it */>
+__device__ __forceinline__ void raster_item_f64(const RasterRec &t, uint32_t code, uint32_t lane, const RasterFrame &fr,
+                                                unsigned long long *__restrict__ vis, uint32_t *__restrict__ depth_bits) {
+    const int32_t ox = (int32_t)(code & 0xFFFu) << 4, oy = (int32_t)((code >> 12) & 0xFFFu) << 4;   // the block's first pixel
+    const int32_t x0 = ox + (int32_t)(DEPTH_ONLY ? lane & 15u : lane & 7u), y0 = oy + (int32_t)(DEPTH_ONLY ? lane >> 4 : lane >> 3);
+    const double xd = (double)x0, yd = (double)y0;
+    double e[4][3];
+    if (DEPTH_ONLY) {   // pixels (x0, y0 + 4k)
+        const double yk[4] = {yd, yd + 4.0, yd + 8.0, yd + 12.0};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double v = __builtin_fma(t.A[i], xd, t.C[i]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) e[k][i] = __builtin_fma(t.B[i], yk[k], v);
+        }
+    } else {            // pixels (x0 + 8 (k & 1), y0 + 8 (k >> 1))
+        const double xd8 = xd + 8.0, yd8 = yd + 8.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double u0 = __builtin_fma(t.B[i], yd, t.C[i]), u1 = __builtin_fma(t.B[i], yd8, t.C[i]);
+            e[0][i] = __builtin_fma(t.A[i], xd, u0); e[1][i] = __builtin_fma(t.A[i], xd8, u0);
+            e[2][i] = __builtin_fma(t.A[i], xd, u1); e[3][i] = __builtin_fma(t.A[i], xd8, u1);
+        }
+    }
+    // forward pass: the two tile rows of the block in the (possibly sharded) visibility plane -- wave-uniform
+    bool row_ok[2] = {true, true};
+    uint32_t row_at[2] = {0, 0};
+    if (!DEPTH_ONLY) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ty_rel = ((oy >> 3) + j) - fr.tile_y0;
+            int lrow = ty_rel;
+            if (fr.band_tiles != 0) {   // interleaved shard: rows of other shards are skipped, the own ones are packed
+                row_ok[j] = row_owned(ty_rel, fr.band_tiles, fr.shard_count, fr.shard_index);
+                lrow = row_local(ty_rel, fr.band_tiles, fr.shard_count);
+            }
+            row_at[j] = ((uint32_t)lrow * (uint32_t)fr.tiles_x + (uint32_t)(ox >> 3)) * 64u;
+        }
+    }
+    bool ok[4];
+    uint32_t at[4], zb[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int32_t px = DEPTH_ONLY ? x0 : x0 + 8 * (k & 1), py = DEPTH_ONLY ? y0 + 4 * k : y0 + 8 * (k >> 1);
+        const int32_t outside = high_word(e[k][0] - t.t0) | high_word(e[k][1]) | high_word(e[k][2] - t.t2);
+        const float l1 = (float)e[k][2] * t.inv_area, l2 = (float)e[k][0] * t.inv_area;
+        float z = fmaf(l2, t.dz2, fmaf(l1, t.dz1, t.z0));
+        z = fminf(fmaxf(z, 0.0f), 1.0f);
+        zb[k] = __float_as_uint(z);
+        ok[k] = outside >= 0 && z < 1.0f;   // depth LESS against the 1.0 clear
+        if (CUT) ok[k] = ok[k] && px >= fr.sc_x0 && px < fr.sc_x1 && py >= fr.sc_y0 && py < fr.sc_y1;
+        if (DEPTH_ONLY) at[k] = (uint32_t)py * (uint32_t)fr.pitch + (uint32_t)px;
+        else { ok[k] = ok[k] && row_ok[k >> 1]; at[k] = row_at[k >> 1] + (uint32_t)(k & 1) * 64u + lane; }
+    }
+    // byte offsets fit 32 bits: the planes are at most 16384^2 entries of 8 (4) bytes
+    if (DEPTH_ONLY) {
+        uint32_t cur[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { cur[k] = 0u; if (ok[k]) cur[k] = *(const uint32_t __attribute__((address_space(1))) *)((gbytes)depth_bits + at[k] * 4u); }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (ok[k] && zb[k] < cur[k])
+                __hip_atomic_fetch_min((uint32_t __attribute__((address_space(1))) *)((gbytes)depth_bits + at[k] * 4u), zb[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        unsigned long long cur[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { cur[k] = 0ull; if (ok[k]) cur[k] = *(const unsigned long long __attribute__((address_space(1))) *)((gbytes)vis + at[k] * 8u); }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned long long key = ((unsigned long long)zb[k] << 32) | t.order_id;   // ties: first drawn (smallest order id) wins
+            if (ok[k] && key < cur[k])
+                __hip_atomic_fetch_min((unsigned long long __attribute__((address_space(1))) *)((gbytes)vis + at[k] * 8u), key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// The same work item in 64-bit integers, for records with coordinates of 2^24 and more (triangles reaching far into the guard
+// band of a 4K / 8K target): a 2x2 quad per lane; what depends only on record and block is wave-uniform and runs on the scalar
+// unit, a lane adds its offset with 32x32+64-bit multiply-adds.  The same exact integers as edge_eval at every pixel.
 template <bool DEPTH_ONLY>
-__device__ __forceinline__ void raster_item(const SetupRec &t, uint32_t local, uint32_t lane, const GeomParams *__restrict__ gpp,
-                                            unsigned long long *__restrict__ vis, uint32_t *__restrict__ depth_bits) {
-    const int32_t bx0 = t.px0 >> 4, by0 = t.py0 >> 4;
-    const uint32_t nbx = (uint32_t)((t.px1 >> 4) - bx0 + 1);
-    const int32_t ox = (bx0 + (int32_t)(local % nbx)) * 16, oy = (by0 + (int32_t)(local / nbx)) * 16;   // the block's first pixel
-    const int32_t lx = (int32_t)(lane & 7) * 2, ly = (int32_t)(lane >> 3) * 2;                          // this lane's 2x2 quad in it
+__device__ __forceinline__ void raster_item_i64(const SetupRec &t, uint32_t code, uint32_t lane, const RasterFrame &fr,
+                                                unsigned long long *__restrict__ vis, uint32_t *__restrict__ depth_bits) {
+    const int32_t ox = (int32_t)(code & 0xFFFu) << 4, oy = (int32_t)((code >> 12) & 0xFFFu) << 4;
+    const int32_t lx = (int32_t)(lane & 7) * 2, ly = (int32_t)(lane >> 3) * 2;                          // this lane's 2x2 quad in the block
     const int32_t qx = ox + lx, qy = oy + ly;
     if (qx > t.px1 || qx + 1 < t.px0 || qy > t.py1 || qy + 1 < t.py0) return;
     Edges e;
@@ -309,58 +476,47 @@ __device__ __forceinline__ void raster_item(const SetupRec &t, uint32_t local, u
     uint32_t row_base = 0;
     bool owned = true;
     if (!DEPTH_ONLY) {
-        const int ty_rel = (qy >> 3) - gpp->tile_y0;
+        const int ty_rel = (qy >> 3) - fr.tile_y0;
         int lrow = ty_rel;
-        if (gpp->band_tiles != 0) {   // interleaved shard: rows of other shards are skipped, the own ones are packed
-            owned = row_owned(ty_rel, gpp->band_tiles, gpp->shard_count, gpp->shard_index);
-            lrow = row_local(ty_rel, gpp->band_tiles, gpp->shard_count);
+        if (fr.band_tiles != 0) {
+            owned = row_owned(ty_rel, fr.band_tiles, fr.shard_count, fr.shard_index);
+            lrow = row_local(ty_rel, fr.band_tiles, fr.shard_count);
         }
-        row_base = (uint32_t)lrow * (uint32_t)gpp->tiles_x;
+        row_base = (uint32_t)lrow * (uint32_t)fr.tiles_x;
     }
-    bool ok[4];
-    uint32_t at[4];
-    unsigned long long key[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int dx = k & 1, dy = k >> 1;
         const int32_t px = qx + dx, py = qy + dy;
-        ok[k] = owned && !(px < t.px0 || px > t.px1 || py < t.py0 || py > t.py1);
+        bool ok = owned && !(px < t.px0 || px > t.px1 || py < t.py0 || py > t.py1);   // the record's bounds are scissored
         const int64_t f0 = eq[0] + (dy ? e.dx[0] * 256 : 0) - (dx ? e.dy[0] * 256 : 0);
         const int64_t f1 = eq[1] + (dy ? e.dx[1] * 256 : 0) - (dx ? e.dy[1] * 256 : 0);
         const int64_t f2 = eq[2] + (dy ? e.dx[2] * 256 : 0) - (dx ? e.dy[2] * 256 : 0);
-        ok[k] = ok[k] && !((f0 + e.bias[0]) < 0 || (f1 + e.bias[1]) < 0 || (f2 + e.bias[2]) < 0);
+        ok = ok && !((f0 + e.bias[0]) < 0 || (f1 + e.bias[1]) < 0 || (f2 + e.bias[2]) < 0);
         const float l1 = (float)f2 * inv_area, l2 = (float)f0 * inv_area;
         float z = fmaf(l2, t.z[2] - t.z[0], fmaf(l1, t.z[1] - t.z[0], t.z[0]));
         z = fminf(fmaxf(z, 0.0f), 1.0f);
-        ok[k] = ok[k] && (z < 1.0f);   // depth LESS against the 1.0 clear
+        ok = ok && (z < 1.0f);
+        if (!ok) continue;
         if (DEPTH_ONLY) {
-            at[k] = (uint32_t)py * (uint32_t)gpp->pitch + (uint32_t)px;
-            key[k] = __float_as_uint(z);
+            uint32_t *p = depth_bits + ((uint32_t)py * (uint32_t)fr.pitch + (uint32_t)px);
+            if (__float_as_uint(z) < *p) atomicMin(p, __float_as_uint(z));
         } else {
-            at[k] = (row_base + ((uint32_t)px >> 3)) * 64u + ((uint32_t)py & 7u) * 8u + ((uint32_t)px & 7u);
-            key[k] = ((unsigned long long)__float_as_uint(z) << 32) | t.order_id;   // ties: first drawn (smallest order id) wins
+            unsigned long long *p = vis + ((row_base + ((uint32_t)px >> 3)) * 64u + ((uint32_t)py & 7u) * 8u + ((uint32_t)px & 7u));
+            const unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | t.order_id;
+            if (key < *p) atomicMin(p, key);
         }
     }
-    unsigned long long cur[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        cur[k] = 0ull;
-        if (ok[k]) cur[k] = DEPTH_ONLY ? (unsigned long long)depth_bits[at[k]] : vis[at[k]];
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (ok[k] && key[k] < cur[k]) {
-            if (DEPTH_ONLY) atomicMin(depth_bits + at[k], (uint32_t)key[k]);
-            else atomicMin(vis + at[k], key[k]);
-        }
 }
 
 // Persistent: the number of work items is only known on the device (counters[1]), so a fixed grid strides over the item
 // table and the host never waits for a count.  Software pipeline, two items deep: while item i is rasterised the record
 // of item i+1 (scalar loads, its index arrived a trip ago) and the table entry of item i+2 are in flight, so a wave pays
-// the entry -> record -> pixels chain of dependent round trips once, not per item.
+// the entry -> record -> pixels chain of dependent round trips once, not per item.  Two trips per loop iteration: the two
+// record register sets swap roles instead of being copied.
 template <bool DEPTH_ONLY>
-__global__ __launch_bounds__(256) void k_raster(const SetupRec *__restrict__ recs, const uint2 *__restrict__ items, uint32_t item_cap,
+__global__ __launch_bounds__(256) void k_raster(const SetupRec *__restrict__ recs, const RasterRec *__restrict__ rrecs,
+                                                const uint2 *__restrict__ items, uint32_t item_cap,
                                                 const uint32_t *__restrict__ counters, const GeomParams *__restrict__ gpp,
                                                 unsigned long long *__restrict__ vis, uint32_t *__restrict__ depth_bits) {
     if (counters[2]) return;   // a table overflowed in k_setup: entries are missing, the host reports the frame as dropped
@@ -369,16 +525,33 @@ __global__ __launch_bounds__(256) void k_raster(const SetupRec *__restrict__ rec
     const uint32_t stride = gridDim.x * 4;
     uint32_t item = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (item >= n_items) return;
-    uint2 e1 = items[item];
-    SetupRec cur = recs[__builtin_amdgcn_readfirstlane(e1.x)];
-    uint32_t local = __builtin_amdgcn_readfirstlane(e1.y);
-    e1 = items[min(item + stride, n_items - 1)];
-    for (; item < n_items; item += stride) {
-        const uint32_t r1 = __builtin_amdgcn_readfirstlane(e1.x), local1 = __builtin_amdgcn_readfirstlane(e1.y);
-        const SetupRec nxt = recs[r1];                                   // used next trip
-        e1 = items[min(item + 2 * stride, n_items - 1)];                 // used the trip after
-        raster_item<DEPTH_ONLY>(cur, local, lane, gpp, vis, depth_bits);
-        cur = nxt; local = local1;
+    const RasterFrame fr = {gpp->sc_x0, gpp->sc_y0, gpp->sc_x1, gpp->sc_y1, gpp->tiles_x, gpp->tile_y0, gpp->pitch,
+                            gpp->band_tiles, gpp->shard_index, gpp->shard_count};
+    const auto one = [&](const RasterRec &q, uint32_t r, uint32_t code) {
+        if (r == ITEM_SKIP) return;
+        if (q.flags & RASTER_EXACT_F64) {
+            if (code & ITEM_SCISSOR) raster_item_f64<DEPTH_ONLY, true>(q, code, lane, fr, vis, depth_bits);
+            else raster_item_f64<DEPTH_ONLY, false>(q, code, lane, fr, vis, depth_bits);
+        } else raster_item_i64<DEPTH_ONLY>(recs[r], code, lane, fr, vis, depth_bits);
+    };
+    const auto rec_index = [](uint32_t r) { return r == ITEM_SKIP ? 0u : r; };
+    uint2 en = items[item];
+    uint32_t ra = __builtin_amdgcn_readfirstlane(en.x), ca = __builtin_amdgcn_readfirstlane(en.y);
+    RasterRec a = rrecs[rec_index(ra)];
+    en = items[min(item + stride, n_items - 1)];
+    for (;;) {
+        const uint32_t rb = __builtin_amdgcn_readfirstlane(en.x), cb = __builtin_amdgcn_readfirstlane(en.y);
+        const RasterRec b = rrecs[rec_index(rb)];                      // used next trip
+        en = items[min(item + 2 * stride, n_items - 1)];               // used the trip after
+        one(a, ra, ca);
+        item += stride;
+        if (item >= n_items) break;
+        ra = __builtin_amdgcn_readfirstlane(en.x); ca = __builtin_amdgcn_readfirstlane(en.y);
+        a = rrecs[rec_index(ra)];
+        en = items[min(item + 2 * stride, n_items - 1)];
+        one(b, rb, cb);
+        item += stride;
+        if (item >= n_items) break;
     }
 }
 
@@ -481,22 +654,22 @@ hipError_t launch_vertex(const ObjectRec *objs, const uint32_t *block_obj, const
 }
 
 hipError_t launch_setup(const ObjectRec *objs, const uint32_t *block_obj, const uint32_t *block_first, uint32_t n_blocks,
-                        const GeomParams *gp, const XVert *xv, SetupRec *recs, uint32_t *rec_of, uint2 *items, uint32_t item_cap,
+                        const GeomParams *gp, const XVert *xv, SetupRec *recs, RasterRec *rrecs, uint32_t *rec_of, uint2 *items, uint32_t item_cap,
                         uint32_t rec_cap, uint32_t *counters, hipStream_t s) {
     if (n_blocks == 0) return hipSuccess;
-    k_setup<<<n_blocks, 256, 0, s>>>(objs, block_obj, block_first, gp, xv, recs, rec_of, items, item_cap, rec_cap, counters);
+    k_setup<<<n_blocks, 256, 0, s>>>(objs, block_obj, block_first, gp, xv, recs, rrecs, rec_of, items, item_cap, rec_cap, counters);
     return hipGetLastError();
 }
 
-hipError_t launch_raster_vis(const SetupRec *recs, const uint2 *items, uint32_t item_cap, const uint32_t *counters, uint32_t grid_blocks,
+hipError_t launch_raster_vis(const SetupRec *recs, const RasterRec *rrecs, const uint2 *items, uint32_t item_cap, const uint32_t *counters, uint32_t grid_blocks,
                              const GeomParams *gp, unsigned long long *vis, hipStream_t s) {
-    k_raster<false><<<grid_blocks, 256, 0, s>>>(recs, items, item_cap, counters, gp, vis, nullptr);
+    k_raster<false><<<grid_blocks, 256, 0, s>>>(recs, rrecs, items, item_cap, counters, gp, vis, nullptr);
     return hipGetLastError();
 }
 
-hipError_t launch_raster_depth(const SetupRec *recs, const uint2 *items, uint32_t item_cap, const uint32_t *counters, uint32_t grid_blocks,
+hipError_t launch_raster_depth(const SetupRec *recs, const RasterRec *rrecs, const uint2 *items, uint32_t item_cap, const uint32_t *counters, uint32_t grid_blocks,
                                const GeomParams *gp, uint32_t *depth_bits, hipStream_t s) {
-    k_raster<true><<<grid_blocks, 256, 0, s>>>(recs, items, item_cap, counters, gp, nullptr, depth_bits);
+    k_raster<true><<<grid_blocks, 256, 0, s>>>(recs, rrecs, items, item_cap, counters, gp, nullptr, depth_bits);
     return hipGetLastError();
 }
 

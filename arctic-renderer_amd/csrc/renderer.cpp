@@ -155,7 +155,7 @@ struct ArcticRenderer {
     bool visbuffer = true;          // arctic_render_frame shades straight from the visibility plane (no G-buffer)
     // per-frame geometry scratch
     PassTables tables[2];   // [0] forward pass, [1] shadow pass
-    DevBuf d_xverts, d_recs, d_rec_of, d_items, d_geo_counters, d_stage;
+    DevBuf d_xverts, d_recs, d_rrecs, d_rec_of, d_items, d_geo_counters, d_stage;
     uint32_t item_cap = 0;          // entries of d_items (work-item table of the rasteriser)
     bool recs_worst_case = false;   // record table at 7 per source triangle (after an overflow of the 2-per-triangle table)
     uint32_t item_cap_floor = 1u << 22;   // its smallest size (ARCTIC_OPT_ITEM_TABLE_FLOOR; tests shrink it to reach the overflow path)
@@ -324,6 +324,7 @@ int run_geometry(ArcticRenderer *r, const ArcticScene *sc, bool shadow_pass) {
         gp.tiles_x = (int32_t)r->tiles_x; gp.tile_y0 = (int32_t)r->tile_y0; gp.pitch = 0;
         gp.band_tiles = (int32_t)(r->band_rows / TILE); gp.shard_index = (int32_t)r->shard_index; gp.shard_count = (int32_t)r->shard_count;
     }
+    gp.raster_flags = (r->debug & 32) ? 1 : 0;
     PassTables &T = r->tables[shadow_pass ? 1 : 0];
     r->geo_owner = shadow_pass ? 2 : 1;
     uint32_t n_objs, n_xverts, n_src, n_vblocks, n_tblocks;
@@ -351,19 +352,20 @@ int run_geometry(ArcticRenderer *r, const ArcticScene *sc, bool shadow_pass) {
         r->item_cap = (uint32_t)std::min<uint64_t>(want, 0x7FFFFFF0ull);
     }
     HIPCHECK(r, r->d_recs.ensure((size_t)n_slots * sizeof(SetupRec)));
+    HIPCHECK(r, r->d_rrecs.ensure((size_t)n_slots * sizeof(RasterRec)));
     HIPCHECK(r, r->d_rec_of.ensure((size_t)n_src * 8 * 4));
     uint32_t *counters = r->d_geo_counters.as<uint32_t>() + (shadow_pass ? 4 : 0);
     HIPCHECK(r, hipMemsetAsync(counters, 0, 16, r->stream));
     HIPCHECK(r, launch_setup(objs, T.tblock_obj, T.tblock_first, n_tblocks, d_gp, r->d_xverts.as<XVert>(), r->d_recs.as<SetupRec>(),
-                             r->d_rec_of.as<uint32_t>(), r->d_items.as<uint2>(), r->item_cap, n_slots, counters, r->stream));
+                             r->d_rrecs.as<RasterRec>(), r->d_rec_of.as<uint32_t>(), r->d_items.as<uint2>(), r->item_cap, n_slots, counters, r->stream));
     // counts for arctic_stats() and the overflow flag: copied to pinned memory, looked at only when the stream has been synchronised
     HIPCHECK(r, hipMemcpyAsync(h, counters, 8, hipMemcpyDeviceToHost, r->stream));
     HIPCHECK(r, hipMemcpyAsync(r->h_counts + 4 + (shadow_pass ? 1 : 0), counters + 2, 4, hipMemcpyDeviceToHost, r->stream));
     if (shadow_pass)
-        HIPCHECK(r, launch_raster_depth(r->d_recs.as<SetupRec>(), r->d_items.as<uint2>(), r->item_cap, counters, r->raster_blocks, d_gp,
+        HIPCHECK(r, launch_raster_depth(r->d_recs.as<SetupRec>(), r->d_rrecs.as<RasterRec>(), r->d_items.as<uint2>(), r->item_cap, counters, r->raster_blocks, d_gp,
                                         r->d_shadow.as<uint32_t>(), r->stream));
     else
-        HIPCHECK(r, launch_raster_vis(r->d_recs.as<SetupRec>(), r->d_items.as<uint2>(), r->item_cap, counters, r->raster_blocks, d_gp,
+        HIPCHECK(r, launch_raster_vis(r->d_recs.as<SetupRec>(), r->d_rrecs.as<RasterRec>(), r->d_items.as<uint2>(), r->item_cap, counters, r->raster_blocks, d_gp,
                                       r->d_vis.as<unsigned long long>(), r->stream));
     return ARCTIC_OK;
 }
@@ -606,7 +608,7 @@ void arctic_destroy(ArcticRenderer *r) {
     for (void *p : r->tex_allocs) (void)hipFree(p);
     DevBuf *bufs[] = {&r->d_tex, &r->d_lut, &r->d_lights, &r->d_light_pairs, &r->d_shadow, &r->d_env, &r->d_vis, &r->d_p0, &r->d_p1, &r->d_p2, &r->d_p3, &r->d_p4,
                       &r->d_rgba8, &r->d_ldr, &r->d_hdr, &r->d_counter, &r->d_shadow_blocks, &r->d_shadow_bounds, &r->d_staging, &r->d_layout, &r->d_xverts,
-                      &r->d_recs, &r->d_rec_of, &r->d_items, &r->d_geo_counters, &r->d_stage, &r->tables[0].d, &r->tables[1].d};
+                      &r->d_recs, &r->d_rrecs, &r->d_rec_of, &r->d_items, &r->d_geo_counters, &r->d_stage, &r->tables[0].d, &r->tables[1].d};
     for (PassTables &T : r->tables) { if (T.h) (void)hipHostFree(T.h); if (T.copied) (void)hipEventDestroy(T.copied); }
     for (DevBuf *b : bufs) b->release();
     delete r;

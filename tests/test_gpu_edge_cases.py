@@ -78,6 +78,23 @@ def test_degenerate_and_huge_triangles(pkg, oracle, hip):
     check(both(pkg, oracle, hip, 96, 64, 128, mats, [(tri_mesh(pkg, pts), idx, 0)], [(np.eye(4), 0)], lights, settings=(2, 2.2, 1.0)))
 
 
+def test_triangles_beyond_the_binary64_range_take_the_integer_rasteriser(pkg, oracle, hip):
+    """the rasteriser evaluates edge functions as binary64 planes when every snapped coordinate is below 2^24 (exact), in
+    64-bit integers otherwise: a 3840-pixel-wide target with triangles clipped at the +-64 w guard band reaches
+    64 * 1920 * 256 = 2^24.9, next to ordinary triangles in the same frame -- both paths in one item stream."""
+    rng = np.random.default_rng(19)
+    mats = [pkg.scenes.make_material_textures(rng, 16)]
+    pts = [(-50000, -40000, -6), (50000, -40000, -6), (0, 60000, -6),     # NDC +-140: cut at the guard band on both sides
+           (-30000, -2, -3), (30000, -2, -3), (0, 1.5, -3),                # a long thin one in front of it
+           (-6, -2, 0), (6, -2, 0), (0, 2, 0),                             # ordinary
+           (100, -1, 1), (140, -1, 1), (120, 1, 1)]                        # ordinary, near the right edge of the wide frame
+    idx = list(range(12))
+    lights = pkg.scenes.random_lights(rng, 2, (-2, -2, 0.5), (2, 2, 3))
+    outs = both(pkg, oracle, hip, 3840, 64, 128, mats, [(tri_mesh(pkg, pts), idx, 0)], [(np.eye(4), 0)], lights)
+    assert (outs[0][2][1] != 0xFFFFFFFF).mean() > 0.5
+    check(outs)
+
+
 def test_one_texel_textures_and_wrapping_uv(pkg, oracle, hip):
     """1x1 and 2x3 textures, texture coordinates far outside [0,1] and negative (WRAP)."""
     rng = np.random.default_rng(10)

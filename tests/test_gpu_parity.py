@@ -63,6 +63,24 @@ def test_gbuffer_bit_exact(pair):
     assert s_o[0] == s_h[0] and s_o[2] == s_h[2]   # same number of set-up triangles (forward, shadow)
 
 
+def test_integer_rasteriser_equals_binary64_rasteriser(pair):
+    """debug bit 5 sends every record through the 64-bit integer rasteriser (the path of records with coordinates of 2^24 and
+    more) instead of the binary64 planes: same shadow map, same visibility, same G-buffer, bit for bit."""
+    sc, o, r = pair
+    ref_map = r.read_shadow_map().copy() if sc.shadow_size else None
+    ref_g = [x.copy() for x in r.read_gbuffer()]
+    r.set_option("debug", 32)
+    try:
+        r.pass_shadow_map(sc.desc); r.pass_gbuffer(sc.desc)
+        if sc.shadow_size:
+            np.testing.assert_array_equal(r.read_shadow_map().view(np.uint32), ref_map.view(np.uint32))
+        for a, b in zip(ref_g, r.read_gbuffer()):
+            np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+    finally:
+        r.set_option("debug", 0)
+        r.pass_shadow_map(sc.desc); r.pass_gbuffer(sc.desc)
+
+
 @pytest.mark.parametrize("tm", [0, 1, 2], ids=["reinhard", "exposure", "aces"])
 def test_shade_parity(pair, tm):
     sc, o, r = pair
