@@ -176,16 +176,17 @@ inline uint32_t shadow_bounds_pitch(uint32_t S) { return S >= 4 && S <= 4900 ? (
 // ---- kernel launchers (geometry.hip, shade.hip) ---------------------------------------------
 // every launcher enqueues on `s` and returns the launch error, never synchronises.
 hipError_t launch_vertex(const ObjectRec *objs, const uint32_t *block_obj, const uint32_t *block_first,
-                         uint32_t n_blocks, const GeomParams *gp, XVert *xv, int clip_only, hipStream_t s);
+                         uint32_t n_blocks, const GeomParams &gp, XVert *xv, int clip_only, uint32_t *counters /*zeroed here for k_setup*/, hipStream_t s);
 hipError_t launch_setup(const ObjectRec *objs, const uint32_t *block_obj, const uint32_t *block_first, uint32_t n_blocks,
-                        const GeomParams *gp, const XVert *xv, SetupRec *recs, RasterRec *rrecs, uint32_t *rec_of /*8 per source triangle*/,
-                        uint2 *items, uint32_t item_cap, uint32_t rec_cap, uint32_t *counters /*records, items, overflow: zeroed before*/, hipStream_t s);
+                        const GeomParams &gp, const XVert *xv, SetupRec *recs, RasterRec *rrecs, uint32_t *rec_of /*8 per source triangle*/,
+                        uint2 *items, uint32_t item_cap, uint32_t rec_cap, uint32_t *counters /*records, items, overflow: zeroed by launch_vertex*/, hipStream_t s);
+uint32_t raster_grid_blocks(bool depth_only, uint32_t cu_count);
 hipError_t launch_raster_vis(const SetupRec *recs, const RasterRec *rrecs, const uint2 *items, uint32_t item_cap, const uint32_t *counters, uint32_t grid_blocks,
-                             const GeomParams *gp, unsigned long long *vis, hipStream_t s);
+                             const GeomParams &gp, unsigned long long *vis, uint32_t *host_counts /*mapped: records, items*/, uint32_t *host_overflow, hipStream_t s);
 hipError_t launch_raster_depth(const SetupRec *recs, const RasterRec *rrecs, const uint2 *items, uint32_t item_cap, const uint32_t *counters, uint32_t grid_blocks,
-                               const GeomParams *gp, uint32_t *depth_bits, hipStream_t s);
+                               const GeomParams &gp, uint32_t *depth_bits, uint32_t *host_counts, uint32_t *host_overflow, hipStream_t s);
 hipError_t launch_resolve(const unsigned long long *vis, const SetupRec *recs, const uint32_t *rec_of, const ObjectRec *objs, const XVert *xv,
-                          const GeomParams *gp, uint32_t n_tiles, GBuffer g, hipStream_t s);
+                          const GeomParams &gp, uint32_t n_tiles, GBuffer g, hipStream_t s);
 hipError_t launch_fill_u64(unsigned long long *p, unsigned long long v, size_t n, hipStream_t s);
 hipError_t launch_fill_u32(uint32_t *p, uint32_t v, size_t n, hipStream_t s);
 hipError_t launch_shade(const ShadeParams &sp, const ShadeLaunch &L);

@@ -202,8 +202,9 @@ __device__ __forceinline__ void normalize3(const float *v, float *o) {
 // forward.hlsl:50-66 vs_main for every vertex of every object in one launch
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_vertex(const ObjectRec *__restrict__ objs, const uint32_t *__restrict__ block_obj,
-                                                const uint32_t *__restrict__ block_first, const GeomParams *__restrict__ gpp,
-                                                XVert *__restrict__ xv, int clip_only) {
+                                                const uint32_t *__restrict__ block_first, const GeomParams gp,
+                                                XVert *__restrict__ xv, int clip_only, uint32_t *__restrict__ counters) {
+    if (blockIdx.x == 0 && threadIdx.x < 4) counters[threadIdx.x] = 0;   // k_setup's slot counters and overflow flag (no memset launch)
     const ObjectRec &ob = objs[block_obj[blockIdx.x]];
     uint32_t vi = block_first[blockIdx.x] + threadIdx.x;
     if (vi >= ob.n_vertices) return;
@@ -212,14 +213,14 @@ __global__ __launch_bounds__(256) void k_vertex(const ObjectRec *__restrict__ ob
     mat_vec(ob.trs, src[0], src[1], src[2], 1.0f, world);
     XVert &o = xv[ob.first_xvert + vi];
     float clip[4];
-    mat_vec(gpp->clip_from_world, world[0], world[1], world[2], world[3], clip);
+    mat_vec(gp.clip_from_world, world[0], world[1], world[2], world[3], clip);
     o.clip[0] = clip[0]; o.clip[1] = clip[1]; o.clip[2] = clip[2]; o.clip[3] = clip[3];
     if (clip_only) return;   // depth.hlsl:7-10
     float t[3], b[3], n[3], ls[4];
     normalize3(src + 6, t);
     normalize3(src + 3, n);
     normalize3(src + 9, b);
-    mat_vec(gpp->light_from_world, world[0], world[1], world[2], world[3], ls);
+    mat_vec(gp.light_from_world, world[0], world[1], world[2], world[3], ls);
     o.attr[0] = src[12]; o.attr[1] = src[13];
     o.attr[2] = t[0]; o.attr[3] = t[1]; o.attr[4] = t[2];
     o.attr[5] = b[0]; o.attr[6] = b[1]; o.attr[7] = b[2];
@@ -246,7 +247,7 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v, uint32_t lane
 }
 
 __global__ __launch_bounds__(256) void k_setup(const ObjectRec *__restrict__ objs, const uint32_t *__restrict__ block_obj,
-                                               const uint32_t *__restrict__ block_first, const GeomParams *__restrict__ gpp,
+                                               const uint32_t *__restrict__ block_first, const GeomParams gp,
                                                const XVert *__restrict__ xv, SetupRec *__restrict__ recs, RasterRec *__restrict__ rrecs,
                                                uint32_t *__restrict__ rec_of, uint2 *__restrict__ items, uint32_t item_cap,
                                                uint32_t rec_cap, uint32_t *__restrict__ counters) {
@@ -254,7 +255,6 @@ __global__ __launch_bounds__(256) void k_setup(const ObjectRec *__restrict__ obj
     const ObjectRec &ob = objs[oi];
     const uint32_t ti = block_first[blockIdx.x] + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63;
-    const GeomParams gp = *gpp;
     const uint32_t src = ob.first_triangle + ti;
     int n = 0;   // vertices of the clipped polygon; 0: no triangle in this lane
     CV poly[MAX_POLY];
@@ -374,15 +374,21 @@ struct RasterFrame {
 // block as its four 8x8 tiles of the tile-major visibility plane (pixel k of lane l = pixel l of tile k: one 512-byte run per
 // load / atomic), the shadow pass as four 16x4 strips of the row-major map (four 64-byte rows).  Covered <=> no sign bit among the
 // three thresholded edge values (one v_or3 on the high words); the depth is edges.h's / the oracle's expression on the same exact
-// numerators.  Early depth test: the four reads are issued together, then the atomics of the pixels that still win.
+// numerators.
 typedef int32_t i2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int32_t high_word(double v) { return __builtin_bit_cast(i2v, v).y; }
 typedef char __attribute__((address_space(1))) *gbytes;   // wave-uniform base (SGPR pair) + 32-bit per-lane byte offset: the saddr form, no 64-bit address arithmetic
 
-template <bool DEPTH_ONLY, bool CUT /* the block is cut by the scissor: test every pixel against it */>
-__device__ __forceinline__ void raster_item_f64(const RasterRec &t, uint32_t code, uint32_t lane, const RasterFrame &fr,
-                                                unsigned long long *__restrict__ vis, uint32_t *__restrict__ depth_bits) {
+// the four pixels of a lane in one work item: covered and nearer than the clear value?, where, and the depth bits
+struct LanePixels {
+    bool ok[4];
+    uint32_t at[4], zb[4];
+};
+
+template <bool DEPTH_ONLY>
+__device__ __forceinline__ void item_pixels(const RasterRec &t, uint32_t code, uint32_t lane, const RasterFrame &fr, LanePixels &p) {
     const int32_t ox = (int32_t)(code & 0xFFFu) << 4, oy = (int32_t)((code >> 12) & 0xFFFu) << 4;   // the block's first pixel
+    const bool cut = (code & ITEM_SCISSOR) != 0;   // the block is cut by the scissor: test every pixel against it
     const int32_t x0 = ox + (int32_t)(DEPTH_ONLY ? lane & 15u : lane & 7u), y0 = oy + (int32_t)(DEPTH_ONLY ? lane >> 4 : lane >> 3);
     const double xd = (double)x0, yd = (double)y0;
     double e[4][3];
@@ -418,40 +424,26 @@ __device__ __forceinline__ void raster_item_f64(const RasterRec &t, uint32_t cod
             row_at[j] = ((uint32_t)lrow * (uint32_t)fr.tiles_x + (uint32_t)(ox >> 3)) * 64u;
         }
     }
-    bool ok[4];
-    uint32_t at[4], zb[4];
+    // the scissor test as sign bits, zero for blocks inside the scissor
+    int32_t out_x[2] = {0, 0}, out_y[4] = {0, 0, 0, 0};
+    if (cut) {
+#pragma unroll
+        for (int j = 0; j < (DEPTH_ONLY ? 1 : 2); ++j) { const int32_t px = x0 + 8 * j; out_x[j] = (px - fr.sc_x0) | (fr.sc_x1 - 1 - px); }
+#pragma unroll
+        for (int j = 0; j < (DEPTH_ONLY ? 4 : 2); ++j) { const int32_t py = y0 + (DEPTH_ONLY ? 4 : 8) * j; out_y[j] = (py - fr.sc_y0) | (fr.sc_y1 - 1 - py); }
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int32_t px = DEPTH_ONLY ? x0 : x0 + 8 * (k & 1), py = DEPTH_ONLY ? y0 + 4 * k : y0 + 8 * (k >> 1);
-        const int32_t outside = high_word(e[k][0] - t.t0) | high_word(e[k][1]) | high_word(e[k][2] - t.t2);
+        const int32_t outside = high_word(e[k][0] - t.t0) | high_word(e[k][1]) | high_word(e[k][2] - t.t2)
+                              | out_x[DEPTH_ONLY ? 0 : k & 1] | out_y[DEPTH_ONLY ? k : k >> 1];
         const float l1 = (float)e[k][2] * t.inv_area, l2 = (float)e[k][0] * t.inv_area;
         float z = fmaf(l2, t.dz2, fmaf(l1, t.dz1, t.z0));
         z = fminf(fmaxf(z, 0.0f), 1.0f);
-        zb[k] = __float_as_uint(z);
-        ok[k] = outside >= 0 && z < 1.0f;   // depth LESS against the 1.0 clear
-        if (CUT) ok[k] = ok[k] && px >= fr.sc_x0 && px < fr.sc_x1 && py >= fr.sc_y0 && py < fr.sc_y1;
-        if (DEPTH_ONLY) at[k] = (uint32_t)py * (uint32_t)fr.pitch + (uint32_t)px;
-        else { ok[k] = ok[k] && row_ok[k >> 1]; at[k] = row_at[k >> 1] + (uint32_t)(k & 1) * 64u + lane; }
-    }
-    // byte offsets fit 32 bits: the planes are at most 16384^2 entries of 8 (4) bytes
-    if (DEPTH_ONLY) {
-        uint32_t cur[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { cur[k] = 0u; if (ok[k]) cur[k] = *(const uint32_t __attribute__((address_space(1))) *)((gbytes)depth_bits + at[k] * 4u); }
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (ok[k] && zb[k] < cur[k])
-                __hip_atomic_fetch_min((uint32_t __attribute__((address_space(1))) *)((gbytes)depth_bits + at[k] * 4u), zb[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-        unsigned long long cur[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { cur[k] = 0ull; if (ok[k]) cur[k] = *(const unsigned long long __attribute__((address_space(1))) *)((gbytes)vis + at[k] * 8u); }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const unsigned long long key = ((unsigned long long)zb[k] << 32) | t.order_id;   // ties: first drawn (smallest order id) wins
-            if (ok[k] && key < cur[k])
-                __hip_atomic_fetch_min((unsigned long long __attribute__((address_space(1))) *)((gbytes)vis + at[k] * 8u), key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        p.zb[k] = __float_as_uint(z);
+        p.ok[k] = outside >= 0 && z < 1.0f;   // depth LESS against the 1.0 clear
+        if (DEPTH_ONLY) p.at[k] = (uint32_t)py * (uint32_t)fr.pitch + (uint32_t)px;
+        else { p.ok[k] = p.ok[k] && row_ok[k >> 1]; p.at[k] = row_at[k >> 1] + (uint32_t)(k & 1) * 64u + lane; }
     }
 }
 
@@ -510,48 +502,87 @@ __device__ __forceinline__ void raster_item_i64(const SetupRec &t, uint32_t code
 }
 
 // Persistent: the number of work items is only known on the device (counters[1]), so a fixed grid strides over the item
-// table and the host never waits for a count.  Software pipeline, two items deep: while item i is rasterised the record
-// of item i+1 (scalar loads, its index arrived a trip ago) and the table entry of item i+2 are in flight, so a wave pays
-// the entry -> record -> pixels chain of dependent round trips once, not per item.  Two trips per loop iteration: the two
-// record register sets swap roles instead of being copied.
+// table and the host never waits for a count.  A wave takes ITEMS work items per trip: their early depth reads are issued
+// together and their atomics follow together, because that is what a trip costs -- the wait for the reads cannot complete
+// before the previous trip's atomics have (loads, stores and atomics retire through one in-order counter on gfx9), so a trip is
+// two memory round trips whatever it carries (measured: one item per trip 84 us at 4K, the arithmetic alone would be 30).
+// The table entries of the next trip are in flight while this one runs.
+constexpr int ITEMS = 1;
 template <bool DEPTH_ONLY>
 __global__ __launch_bounds__(256) void k_raster(const SetupRec *__restrict__ recs, const RasterRec *__restrict__ rrecs,
                                                 const uint2 *__restrict__ items, uint32_t item_cap,
-                                                const uint32_t *__restrict__ counters, const GeomParams *__restrict__ gpp,
-                                                unsigned long long *__restrict__ vis, uint32_t *__restrict__ depth_bits) {
+                                                const uint32_t *__restrict__ counters, const GeomParams gp,
+                                                unsigned long long *__restrict__ vis, uint32_t *__restrict__ depth_bits,
+                                                uint32_t *__restrict__ host_counts, uint32_t *__restrict__ host_overflow) {
+    // records, work items and the overflow flag for the host (pinned, mapped memory: no copy launches); read after a synchronise
+    if (blockIdx.x == 0 && threadIdx.x == 0) { host_counts[0] = counters[0]; host_counts[1] = counters[1]; *host_overflow = counters[2]; }
     if (counters[2]) return;   // a table overflowed in k_setup: entries are missing, the host reports the frame as dropped
     const uint32_t n_items = min(counters[1], item_cap);
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t stride = gridDim.x * 4;
-    uint32_t item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    uint32_t item = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (item >= n_items) return;
-    const RasterFrame fr = {gpp->sc_x0, gpp->sc_y0, gpp->sc_x1, gpp->sc_y1, gpp->tiles_x, gpp->tile_y0, gpp->pitch,
-                            gpp->band_tiles, gpp->shard_index, gpp->shard_count};
-    const auto one = [&](const RasterRec &q, uint32_t r, uint32_t code) {
-        if (r == ITEM_SKIP) return;
-        if (q.flags & RASTER_EXACT_F64) {
-            if (code & ITEM_SCISSOR) raster_item_f64<DEPTH_ONLY, true>(q, code, lane, fr, vis, depth_bits);
-            else raster_item_f64<DEPTH_ONLY, false>(q, code, lane, fr, vis, depth_bits);
-        } else raster_item_i64<DEPTH_ONLY>(recs[r], code, lane, fr, vis, depth_bits);
-    };
-    const auto rec_index = [](uint32_t r) { return r == ITEM_SKIP ? 0u : r; };
-    uint2 en = items[item];
-    uint32_t ra = __builtin_amdgcn_readfirstlane(en.x), ca = __builtin_amdgcn_readfirstlane(en.y);
-    RasterRec a = rrecs[rec_index(ra)];
-    en = items[min(item + stride, n_items - 1)];
-    for (;;) {
-        const uint32_t rb = __builtin_amdgcn_readfirstlane(en.x), cb = __builtin_amdgcn_readfirstlane(en.y);
-        const RasterRec b = rrecs[rec_index(rb)];                      // used next trip
-        en = items[min(item + 2 * stride, n_items - 1)];               // used the trip after
-        one(a, ra, ca);
-        item += stride;
-        if (item >= n_items) break;
-        ra = __builtin_amdgcn_readfirstlane(en.x); ca = __builtin_amdgcn_readfirstlane(en.y);
-        a = rrecs[rec_index(ra)];
-        en = items[min(item + 2 * stride, n_items - 1)];
-        one(b, rb, cb);
-        item += stride;
-        if (item >= n_items) break;
+    const RasterFrame fr = {gp.sc_x0, gp.sc_y0, gp.sc_x1, gp.sc_y1, gp.tiles_x, gp.tile_y0, gp.pitch, gp.band_tiles, gp.shard_index, gp.shard_count};
+    const uint2 none = make_uint2(ITEM_SKIP, 0u);
+    uint2 en[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) en[j] = item + j * stride < n_items ? items[item + j * stride] : none;
+    for (; item < n_items; item += ITEMS * stride) {
+        uint32_t r[ITEMS], code[ITEMS];
+        RasterRec q[ITEMS];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            r[j] = __builtin_amdgcn_readfirstlane(en[j].x); code[j] = __builtin_amdgcn_readfirstlane(en[j].y);
+            q[j] = rrecs[r[j] == ITEM_SKIP ? 0u : r[j]];
+        }
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) { const uint32_t nxt = item + (ITEMS + j) * stride; en[j] = nxt < n_items ? items[nxt] : none; }
+        LanePixels p[ITEMS];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            if (r[j] != ITEM_SKIP && !(q[j].flags & RASTER_EXACT_F64)) {   // rare: the record's own integer path, start to finish
+                raster_item_i64<DEPTH_ONLY>(recs[r[j]], code[j], lane, fr, vis, depth_bits);
+                r[j] = ITEM_SKIP;
+            }
+            item_pixels<DEPTH_ONLY>(q[j], code[j], lane, fr, p[j]);
+            if (r[j] == ITEM_SKIP) p[j].ok[0] = p[j].ok[1] = p[j].ok[2] = p[j].ok[3] = false;
+        }
+        // byte offsets fit 32 bits: the planes are at most 16384^2 entries of 8 (4) bytes
+        if (DEPTH_ONLY) {
+            uint32_t cur[ITEMS][4];
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    cur[j][k] = 0u;
+                    if (p[j].ok[k]) cur[j][k] = *(const uint32_t __attribute__((address_space(1))) *)((gbytes)depth_bits + p[j].at[k] * 4u);
+                }
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (p[j].ok[k] && p[j].zb[k] < cur[j][k])
+                        __hip_atomic_fetch_min((uint32_t __attribute__((address_space(1))) *)((gbytes)depth_bits + p[j].at[k] * 4u), p[j].zb[k],
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            unsigned long long cur[ITEMS][4];
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    cur[j][k] = 0ull;
+                    if (p[j].ok[k]) cur[j][k] = *(const unsigned long long __attribute__((address_space(1))) *)((gbytes)vis + p[j].at[k] * 8u);
+                }
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned long long key = ((unsigned long long)p[j].zb[k] << 32) | q[j].order_id;   // ties: first drawn (smallest order id) wins
+                    if (p[j].ok[k] && key < cur[j][k])
+                        __hip_atomic_fetch_min((unsigned long long __attribute__((address_space(1))) *)((gbytes)vis + p[j].at[k] * 8u), key,
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+        }
     }
 }
 
@@ -560,7 +591,7 @@ __global__ __launch_bounds__(256) void k_raster(const SetupRec *__restrict__ rec
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_resolve(const unsigned long long *__restrict__ vis, const SetupRec *__restrict__ recs,
                                                  const uint32_t *__restrict__ rec_of, const ObjectRec *__restrict__ objs, const XVert *__restrict__ xv,
-                                                 const GeomParams *__restrict__ gpp, uint32_t n_tiles, GBuffer g) {
+                                                 const GeomParams gp, uint32_t n_tiles, GBuffer g) {
     uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tile >= n_tiles) return;
     uint32_t lane = threadIdx.x & 63;
@@ -572,8 +603,8 @@ __global__ __launch_bounds__(256) void k_resolve(const unsigned long long *__res
     uint32_t mat = NO_MATERIAL;
     if (key != ~0ull) {
         const SetupRec &t = recs[rec_of[(uint32_t)key]];   // low word = order id (k_setup)
-        int32_t tx = (int32_t)(tile % (uint32_t)gpp->tiles_x);
-        int32_t ty = row_global((int)(tile / (uint32_t)gpp->tiles_x), gpp->band_tiles, gpp->shard_count, gpp->shard_index) + gpp->tile_y0;
+        int32_t tx = (int32_t)(tile % (uint32_t)gp.tiles_x);
+        int32_t ty = row_global((int)(tile / (uint32_t)gp.tiles_x), gp.band_tiles, gp.shard_count, gp.shard_index) + gp.tile_y0;
         int32_t px = tx * 8 + (int32_t)(lane & 7), py = ty * 8 + (int32_t)(lane >> 3);
         float B[3];
         source_barycentrics(t, px, py, B);
@@ -647,34 +678,44 @@ inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 }  // namespace
 
 hipError_t launch_vertex(const ObjectRec *objs, const uint32_t *block_obj, const uint32_t *block_first, uint32_t n_blocks,
-                         const GeomParams *gp, XVert *xv, int clip_only, hipStream_t s) {
+                         const GeomParams &gp, XVert *xv, int clip_only, uint32_t *counters, hipStream_t s) {
     if (n_blocks == 0) return hipSuccess;
-    k_vertex<<<n_blocks, 256, 0, s>>>(objs, block_obj, block_first, gp, xv, clip_only);
+    k_vertex<<<n_blocks, 256, 0, s>>>(objs, block_obj, block_first, gp, xv, clip_only, counters);
     return hipGetLastError();
 }
 
 hipError_t launch_setup(const ObjectRec *objs, const uint32_t *block_obj, const uint32_t *block_first, uint32_t n_blocks,
-                        const GeomParams *gp, const XVert *xv, SetupRec *recs, RasterRec *rrecs, uint32_t *rec_of, uint2 *items, uint32_t item_cap,
+                        const GeomParams &gp, const XVert *xv, SetupRec *recs, RasterRec *rrecs, uint32_t *rec_of, uint2 *items, uint32_t item_cap,
                         uint32_t rec_cap, uint32_t *counters, hipStream_t s) {
     if (n_blocks == 0) return hipSuccess;
     k_setup<<<n_blocks, 256, 0, s>>>(objs, block_obj, block_first, gp, xv, recs, rrecs, rec_of, items, item_cap, rec_cap, counters);
     return hipGetLastError();
 }
 
+// the persistent grid of k_raster: exactly the waves that are resident at once (a grid larger than that runs its last blocks
+// after the others have finished their share of the items)
+uint32_t raster_grid_blocks(bool depth_only, uint32_t cu_count) {
+    int per_cu = 0;
+    const hipError_t e = depth_only ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_raster<true>, 256, 0)
+                                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_raster<false>, 256, 0);
+    if (e != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 4; }
+    return cu_count * (uint32_t)per_cu;
+}
+
 hipError_t launch_raster_vis(const SetupRec *recs, const RasterRec *rrecs, const uint2 *items, uint32_t item_cap, const uint32_t *counters, uint32_t grid_blocks,
-                             const GeomParams *gp, unsigned long long *vis, hipStream_t s) {
-    k_raster<false><<<grid_blocks, 256, 0, s>>>(recs, rrecs, items, item_cap, counters, gp, vis, nullptr);
+                             const GeomParams &gp, unsigned long long *vis, uint32_t *host_counts, uint32_t *host_overflow, hipStream_t s) {
+    k_raster<false><<<grid_blocks, 256, 0, s>>>(recs, rrecs, items, item_cap, counters, gp, vis, nullptr, host_counts, host_overflow);
     return hipGetLastError();
 }
 
 hipError_t launch_raster_depth(const SetupRec *recs, const RasterRec *rrecs, const uint2 *items, uint32_t item_cap, const uint32_t *counters, uint32_t grid_blocks,
-                               const GeomParams *gp, uint32_t *depth_bits, hipStream_t s) {
-    k_raster<true><<<grid_blocks, 256, 0, s>>>(recs, rrecs, items, item_cap, counters, gp, nullptr, depth_bits);
+                               const GeomParams &gp, uint32_t *depth_bits, uint32_t *host_counts, uint32_t *host_overflow, hipStream_t s) {
+    k_raster<true><<<grid_blocks, 256, 0, s>>>(recs, rrecs, items, item_cap, counters, gp, nullptr, depth_bits, host_counts, host_overflow);
     return hipGetLastError();
 }
 
 hipError_t launch_resolve(const unsigned long long *vis, const SetupRec *recs, const uint32_t *rec_of, const ObjectRec *objs, const XVert *xv,
-                          const GeomParams *gp, uint32_t n_tiles, GBuffer g, hipStream_t s) {
+                          const GeomParams &gp, uint32_t n_tiles, GBuffer g, hipStream_t s) {
     if (n_tiles == 0) return hipSuccess;
     k_resolve<<<div_up(n_tiles, 4), 256, 0, s>>>(vis, recs, rec_of, objs, xv, gp, n_tiles, g);
     return hipGetLastError();

@@ -117,8 +117,9 @@ struct PassTables {
     DevBuf d;                   // device arena
     hipEvent_t copied = nullptr;
     bool pending = false;
+    std::vector<char> last;     // what the device arena holds: an unchanged object list is not uploaded again
+    GeomParams gp;              // this pass's frame constants (kernel argument, by value)
     // device views into the arena (valid after upload)
-    const GeomParams *gp = nullptr;
     const ObjectRec *objs = nullptr;
     const uint32_t *vblock_obj = nullptr, *vblock_first = nullptr, *tblock_obj = nullptr, *tblock_first = nullptr;
 };
@@ -162,7 +163,7 @@ struct ArcticRenderer {
     uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t light_stats[2] = {0, 0};   // stats[8], [9]: (tile, light) pairs with n.wi <= 0 in every lit lane; tiles with a lit pixel
     int keep_float = 0, count_evals = 0, culling = 1, debug = 0, hdr16 = 0;
-    uint32_t raster_blocks = 2048;  // persistent grid of k_raster
+    uint32_t raster_blocks[2] = {2048, 2048};  // persistent grid of k_raster: [0] forward pass, [1] shadow pass
     // render_frame re-renders the shadow map only when its inputs changed (sun, objects, meshes): the reference redraws it
     // every frame (renderer.cpp:300-337), but a depth map of unchanged geometry from an unchanged light is the same map
     std::vector<uint8_t> shadow_key; bool shadow_cache = true;
@@ -179,7 +180,8 @@ struct ArcticRenderer {
     uint32_t layout_world = 0; bool layout_from_comm = false;
     bool shadow_sharded = false;                      // ARCTIC_OPT_SHADOW_SHARDED
     uint32_t shadow_rows_alloc = 0;                   // rows the shadow buffer holds (>= shadow_size: padded to world * ceil(S / world))
-    uint32_t *h_counts = nullptr;   // pinned: [0] records, [1] work items (forward), [2], [3] the same for the shadow pass, [4], [5] item-table overflow flags
+    uint32_t *dh_counts = nullptr;  // the device's address of h_counts
+    uint32_t *h_counts = nullptr;   // pinned, mapped: [0] records, [1] work items (forward), [2], [3] the same for the shadow pass, [4], [5] item-table overflow flags
     std::string err;
 
     int fail(int code, const char *fmt, ...) {
@@ -236,7 +238,8 @@ int alloc_targets(ArcticRenderer *r) {
     return ARCTIC_OK;
 }
 
-// Scene.objects -> frame constants + ObjectRec[] + block tables in one asynchronous upload
+// Scene.objects -> ObjectRec[] + block tables in one asynchronous upload, skipped while the list stays byte-identical (a
+// static scene under a moving camera: the frame constants travel as a kernel argument, so such frames copy nothing)
 int upload_pass_tables(ArcticRenderer *r, PassTables &T, const GeomParams &gp, const ArcticScene *sc, uint32_t &n_objs,
                        uint32_t &n_xverts, uint32_t &n_src_tris, uint32_t &n_vblocks, uint32_t &n_tblocks) {
     std::vector<ObjectRec> objs;
@@ -268,28 +271,33 @@ int upload_pass_tables(ArcticRenderer *r, PassTables &T, const GeomParams &gp, c
     n_vblocks = (uint32_t)vb_obj.size(); n_tblocks = (uint32_t)tb_obj.size();
     // arena layout (16-byte aligned sections)
     auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
-    const size_t o_gp = 0, o_objs = align16(sizeof(GeomParams)), o_vo = align16(o_objs + objs.size() * sizeof(ObjectRec)),
+    const size_t o_objs = 0, o_vo = align16(o_objs + objs.size() * sizeof(ObjectRec)),
                  o_vf = align16(o_vo + vb_obj.size() * 4), o_to = align16(o_vf + vb_first.size() * 4),
                  o_tf = align16(o_to + tb_obj.size() * 4), total = align16(o_tf + tb_first.size() * 4) + 16;
-    if (T.pending) { HIPCHECK(r, hipEventSynchronize(T.copied)); T.pending = false; }
-    if (total > T.h_cap) {
-        if (T.h) HIPCHECK(r, hipHostFree(T.h));
-        T.h = nullptr; T.h_cap = 0;
-        HIPCHECK(r, hipHostMalloc(&T.h, total * 2));
-        T.h_cap = total * 2;
-    }
-    if (!T.copied) HIPCHECK(r, hipEventCreateWithFlags(&T.copied, hipEventDisableTiming));
-    HIPCHECK(r, T.d.ensure(total));
-    char *h = static_cast<char *>(T.h);
-    std::memcpy(h + o_gp, &gp, sizeof gp);
+    T.gp = gp;
+    std::vector<char> stage(total, 0);
+    char *h = stage.data();
     if (!objs.empty()) std::memcpy(h + o_objs, objs.data(), objs.size() * sizeof(ObjectRec));
     if (!vb_obj.empty()) { std::memcpy(h + o_vo, vb_obj.data(), vb_obj.size() * 4); std::memcpy(h + o_vf, vb_first.data(), vb_first.size() * 4); }
     if (!tb_obj.empty()) { std::memcpy(h + o_to, tb_obj.data(), tb_obj.size() * 4); std::memcpy(h + o_tf, tb_first.data(), tb_first.size() * 4); }
-    HIPCHECK(r, hipMemcpyAsync(T.d.p, T.h, total, hipMemcpyHostToDevice, r->stream));
-    HIPCHECK(r, hipEventRecord(T.copied, r->stream));
-    T.pending = true;
+    if (!(T.d.p && stage == T.last)) {
+        if (T.pending) { HIPCHECK(r, hipEventSynchronize(T.copied)); T.pending = false; }
+        if (total > T.h_cap) {
+            if (T.h) HIPCHECK(r, hipHostFree(T.h));
+            T.h = nullptr; T.h_cap = 0;
+            HIPCHECK(r, hipHostMalloc(&T.h, total * 2));
+            T.h_cap = total * 2;
+        }
+        if (!T.copied) HIPCHECK(r, hipEventCreateWithFlags(&T.copied, hipEventDisableTiming));
+        T.last.clear();
+        HIPCHECK(r, T.d.ensure(total));
+        std::memcpy(T.h, h, total);
+        HIPCHECK(r, hipMemcpyAsync(T.d.p, T.h, total, hipMemcpyHostToDevice, r->stream));
+        HIPCHECK(r, hipEventRecord(T.copied, r->stream));
+        T.pending = true;
+        T.last.swap(stage);
+    }
     const char *d = T.d.as<char>();
-    T.gp = reinterpret_cast<const GeomParams *>(d + o_gp);
     T.objs = reinterpret_cast<const ObjectRec *>(d + o_objs);
     T.vblock_obj = reinterpret_cast<const uint32_t *>(d + o_vo); T.vblock_first = reinterpret_cast<const uint32_t *>(d + o_vf);
     T.tblock_obj = reinterpret_cast<const uint32_t *>(d + o_to); T.tblock_first = reinterpret_cast<const uint32_t *>(d + o_tf);
@@ -330,10 +338,11 @@ int run_geometry(ArcticRenderer *r, const ArcticScene *sc, bool shadow_pass) {
     uint32_t n_objs, n_xverts, n_src, n_vblocks, n_tblocks;
     int rc = upload_pass_tables(r, T, gp, sc, n_objs, n_xverts, n_src, n_vblocks, n_tblocks);
     if (rc != ARCTIC_OK) return rc;
-    const GeomParams *d_gp = T.gp;
-    if (n_objs == 0 || n_src == 0) { r->h_counts[shadow_pass ? 2 : 0] = r->h_counts[shadow_pass ? 3 : 1] = 0; return ARCTIC_OK; }
+    const GeomParams &d_gp = T.gp;
+    if (n_objs == 0 || n_src == 0 || n_vblocks == 0) { r->h_counts[shadow_pass ? 2 : 0] = r->h_counts[shadow_pass ? 3 : 1] = 0; return ARCTIC_OK; }
     const ObjectRec *objs = T.objs;
-    HIPCHECK(r, launch_vertex(objs, T.vblock_obj, T.vblock_first, n_vblocks, d_gp, r->d_xverts.as<XVert>(), shadow_pass ? 1 : 0, r->stream));
+    HIPCHECK(r, launch_vertex(objs, T.vblock_obj, T.vblock_first, n_vblocks, d_gp, r->d_xverts.as<XVert>(), shadow_pass ? 1 : 0,
+                              r->d_geo_counters.as<uint32_t>() + (shadow_pass ? 4 : 0), r->stream));
     // Record slots: a triangle clipped against 6 planes yields at most 7 triangles, so 7 * n_src slots can never overflow.
     // Records and work items are allocated on the device from two counters (k_setup): no count pass, no scan, and neither
     // count has to come back to the host -- the frame stays asynchronous.
@@ -345,7 +354,6 @@ int run_geometry(ArcticRenderer *r, const ArcticScene *sc, bool shadow_pass) {
     // work-item table: explicit (record, 16x16 block) pairs.  Its size follows the largest count seen so far (pinned
     // h_counts, refreshed asynchronously each pass) with 4x headroom; an overflow drops work, is flagged by the kernel and
     // reported by the next call that synchronises (arctic_flush / read-backs) -- and the table has grown by then.
-    uint32_t *h = r->h_counts + (shadow_pass ? 2 : 0);
     const uint64_t want = std::max<uint64_t>(r->item_cap_floor, 4ull * std::max(r->h_counts[1], r->h_counts[3]));
     if (want > r->item_cap) {
         HIPCHECK(r, r->d_items.ensure((size_t)want * 8));
@@ -354,19 +362,18 @@ int run_geometry(ArcticRenderer *r, const ArcticScene *sc, bool shadow_pass) {
     HIPCHECK(r, r->d_recs.ensure((size_t)n_slots * sizeof(SetupRec)));
     HIPCHECK(r, r->d_rrecs.ensure((size_t)n_slots * sizeof(RasterRec)));
     HIPCHECK(r, r->d_rec_of.ensure((size_t)n_src * 8 * 4));
-    uint32_t *counters = r->d_geo_counters.as<uint32_t>() + (shadow_pass ? 4 : 0);
-    HIPCHECK(r, hipMemsetAsync(counters, 0, 16, r->stream));
+    uint32_t *counters = r->d_geo_counters.as<uint32_t>() + (shadow_pass ? 4 : 0);   // zeroed by k_vertex
     HIPCHECK(r, launch_setup(objs, T.tblock_obj, T.tblock_first, n_tblocks, d_gp, r->d_xverts.as<XVert>(), r->d_recs.as<SetupRec>(),
                              r->d_rrecs.as<RasterRec>(), r->d_rec_of.as<uint32_t>(), r->d_items.as<uint2>(), r->item_cap, n_slots, counters, r->stream));
-    // counts for arctic_stats() and the overflow flag: copied to pinned memory, looked at only when the stream has been synchronised
-    HIPCHECK(r, hipMemcpyAsync(h, counters, 8, hipMemcpyDeviceToHost, r->stream));
-    HIPCHECK(r, hipMemcpyAsync(r->h_counts + 4 + (shadow_pass ? 1 : 0), counters + 2, 4, hipMemcpyDeviceToHost, r->stream));
+    // counts for arctic_stats() and the overflow flag: k_raster stores them into pinned, mapped memory (no copy launches between
+    // the kernels); looked at only when the stream has been synchronised
+    uint32_t *dh = r->dh_counts + (shadow_pass ? 2 : 0), *dh_overflow = r->dh_counts + 4 + (shadow_pass ? 1 : 0);
     if (shadow_pass)
-        HIPCHECK(r, launch_raster_depth(r->d_recs.as<SetupRec>(), r->d_rrecs.as<RasterRec>(), r->d_items.as<uint2>(), r->item_cap, counters, r->raster_blocks, d_gp,
-                                        r->d_shadow.as<uint32_t>(), r->stream));
+        HIPCHECK(r, launch_raster_depth(r->d_recs.as<SetupRec>(), r->d_rrecs.as<RasterRec>(), r->d_items.as<uint2>(), r->item_cap, counters, r->raster_blocks[1], d_gp,
+                                        r->d_shadow.as<uint32_t>(), dh, dh_overflow, r->stream));
     else
-        HIPCHECK(r, launch_raster_vis(r->d_recs.as<SetupRec>(), r->d_rrecs.as<RasterRec>(), r->d_items.as<uint2>(), r->item_cap, counters, r->raster_blocks, d_gp,
-                                      r->d_vis.as<unsigned long long>(), r->stream));
+        HIPCHECK(r, launch_raster_vis(r->d_recs.as<SetupRec>(), r->d_rrecs.as<RasterRec>(), r->d_items.as<uint2>(), r->item_cap, counters, r->raster_blocks[0], d_gp,
+                                      r->d_vis.as<unsigned long long>(), dh, dh_overflow, r->stream));
     return ARCTIC_OK;
 }
 
@@ -576,9 +583,11 @@ ArcticRenderer *arctic_create(const ArcticCreateInfo *info, char *err, uint64_t 
         hipDeviceProp_t prop;
         if ((e = hipGetDeviceProperties(&prop, r->device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
         r->cu_count = (uint32_t)std::max(1, prop.multiProcessorCount);
-        r->raster_blocks = (uint32_t)std::max(1, prop.multiProcessorCount) * 8;
-        if ((e = hipHostMalloc((void **)&r->h_counts, 64)) != hipSuccess) return bail("hipHostMalloc", e);
+        r->raster_blocks[0] = raster_grid_blocks(false, r->cu_count);
+        r->raster_blocks[1] = raster_grid_blocks(true, r->cu_count);
+        if ((e = hipHostMalloc((void **)&r->h_counts, 64, hipHostMallocMapped)) != hipSuccess) return bail("hipHostMalloc", e);
         std::memset(r->h_counts, 0, 64);
+        if ((e = hipHostGetDevicePointer((void **)&r->dh_counts, r->h_counts, 0)) != hipSuccess) return bail("hipHostGetDevicePointer", e);
     }
     float lut[256];
     for (int i = 0; i < 256; ++i) lut[i] = srgb8_to_linear(i);
