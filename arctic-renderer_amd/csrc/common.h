@@ -88,6 +88,7 @@ static_assert(sizeof(RasterRec) == 128, "RasterRec layout");
 constexpr uint32_t RASTER_EXACT_F64 = 1u;
 // a work item = {record, block}: block = bx | by << 12 | ITEM_SCISSOR (the 16x16 block is cut by the scissor / the target's edge);
 // record ITEM_SKIP: an entry of a large record whose block no edge function reaches (its slot was taken before that was known)
+constexpr uint32_t SETUP_THREADS = 512;   // triangles per workgroup of k_setup (one pair of slot atomics per workgroup)
 constexpr uint32_t ITEM_SCISSOR = 1u << 24;
 constexpr uint32_t ITEM_SKIP = 0xFFFFFFFFu;
 
@@ -179,7 +180,8 @@ hipError_t launch_vertex(const ObjectRec *objs, const uint32_t *block_obj, const
                          uint32_t n_blocks, const GeomParams &gp, XVert *xv, int clip_only, uint32_t *counters /*zeroed here for k_setup*/, hipStream_t s);
 hipError_t launch_setup(const ObjectRec *objs, const uint32_t *block_obj, const uint32_t *block_first, uint32_t n_blocks,
                         const GeomParams &gp, const XVert *xv, SetupRec *recs, RasterRec *rrecs, uint32_t *rec_of /*8 per source triangle*/,
-                        uint2 *items, uint32_t item_cap, uint32_t rec_cap, uint32_t *counters /*records, items, overflow: zeroed by launch_vertex*/, hipStream_t s);
+                        uint2 *items, uint32_t item_cap, uint32_t rec_cap, uint32_t *counters /*records, items, overflow, clip-list length: zeroed by launch_vertex*/,
+                        uint2 *clip_list /*one entry per source triangle*/, hipStream_t s);
 uint32_t raster_grid_blocks(bool depth_only, uint32_t cu_count);
 hipError_t launch_raster_vis(const SetupRec *recs, const RasterRec *rrecs, const uint2 *items, uint32_t item_cap, const uint32_t *counters, uint32_t grid_blocks,
                              const GeomParams &gp, unsigned long long *vis, uint32_t *host_counts /*mapped: records, items*/, uint32_t *host_overflow, hipStream_t s);

@@ -63,27 +63,42 @@ __device__ __forceinline__ CV clip_lerp(const CV &in, const CV &out, float din, 
     return r;
 }
 
-// Sutherland-Hodgman against near, far and the four guard-band planes
-__device__ int clip_polygon(CV *poly, int n) {
-    CV tmp[MAX_POLY];
+// Sutherland-Hodgman against near, far and the four guard-band planes.  The polygons (up to MAX_POLY vertices, two buffers that
+// change roles per plane) live in LDS, one column per lane: indexed private arrays would be scratch memory, ten times the latency.
+struct PolyStore {
+    float v[2][MAX_POLY][7][64];
+    __device__ __forceinline__ CV get(int buf, int i, uint32_t lane) const {
+        CV r; const float(*p)[64] = v[buf][i];
+        r.x = p[0][lane]; r.y = p[1][lane]; r.z = p[2][lane]; r.w = p[3][lane]; r.b0 = p[4][lane]; r.b1 = p[5][lane]; r.b2 = p[6][lane];
+        return r;
+    }
+    __device__ __forceinline__ void put(int buf, int i, uint32_t lane, const CV &c) {
+        float(*p)[64] = v[buf][i];
+        p[0][lane] = c.x; p[1][lane] = c.y; p[2][lane] = c.z; p[3][lane] = c.w; p[4][lane] = c.b0; p[5][lane] = c.b1; p[6][lane] = c.b2;
+    }
+};
+// the triangle is in buffer 0, vertices 0..2; returns the vertex count of the clipped polygon and the buffer that holds it
+__device__ __forceinline__ int clip_polygon(PolyStore &P, uint32_t lane, int &buf) {
+    int n = 3;
+    buf = 0;
     for (int plane = 0; plane < 6; ++plane) {
-        float d[MAX_POLY];
         bool all_in = true, any_in = false;
         for (int i = 0; i < n; ++i) {
-            d[i] = plane_dist(poly[i], plane);
-            if (d[i] >= 0.0f) any_in = true; else all_in = false;
+            if (plane_dist(P.get(buf, i, lane), plane) >= 0.0f) any_in = true; else all_in = false;
         }
         if (all_in) continue;
         if (!any_in) return 0;
         int m = 0;
         for (int i = 0; i < n; ++i) {
-            int j = (i + 1 == n) ? 0 : i + 1;
-            bool in_i = d[i] >= 0.0f, in_j = d[j] >= 0.0f;
-            if (in_i) tmp[m++] = poly[i];
-            if (in_i != in_j) tmp[m++] = in_i ? clip_lerp(poly[i], poly[j], d[i], d[j]) : clip_lerp(poly[j], poly[i], d[j], d[i]);
+            const int j = (i + 1 == n) ? 0 : i + 1;
+            const CV vi = P.get(buf, i, lane), vj = P.get(buf, j, lane);
+            const float di = plane_dist(vi, plane), dj = plane_dist(vj, plane);
+            const bool in_i = di >= 0.0f, in_j = dj >= 0.0f;
+            if (in_i) P.put(buf ^ 1, m++, lane, vi);
+            if (in_i != in_j) P.put(buf ^ 1, m++, lane, in_i ? clip_lerp(vi, vj, di, dj) : clip_lerp(vj, vi, dj, di));
         }
         n = m;
-        for (int i = 0; i < n; ++i) poly[i] = tmp[i];
+        buf ^= 1;
         if (n < 3) return 0;
     }
     return n;
@@ -92,34 +107,33 @@ __device__ int clip_polygon(CV *poly, int n) {
 __device__ __forceinline__ int32_t snap(float s) { return (int32_t)floorf(s * 256.0f + 0.5f); }
 
 // viewport transform, snapping, culling, orientation, pixel bounds.  false = nothing to rasterise.
-__device__ bool setup_triangle(const CV &a, const CV &b, const CV &c, const GeomParams &gp, SetupRec &t) {
-    const CV *v[3] = {&a, &b, &c};
-    float hx = 0.5f * gp.vp_w, hy = 0.5f * gp.vp_h;
+__device__ __forceinline__ bool setup_triangle(const CV &a, const CV &b, const CV &c, const GeomParams &gp, SetupRec &t) {
+    if (!(a.w > 0.0f) || !(b.w > 0.0f) || !(c.w > 0.0f)) return false;
+    const float hx = 0.5f * gp.vp_w, hy = 0.5f * gp.vp_h;
     int32_t X[3], Y[3];
     float z[3], iw[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        if (!(v[i]->w > 0.0f)) return false;
-        iw[i] = 1.0f / v[i]->w;
-        float nx = v[i]->x * iw[i], ny = v[i]->y * iw[i];
-        z[i] = v[i]->z * iw[i];
+    const auto project = [&](const CV &v, int i) {
+        iw[i] = 1.0f / v.w;
+        const float nx = v.x * iw[i], ny = v.y * iw[i];
+        z[i] = v.z * iw[i];
         X[i] = snap((nx + 1.0f) * hx);   // D3D viewport: X = (x+1) * W/2
         Y[i] = snap((1.0f - ny) * hy);   //               Y = (1-y) * H/2
-    }
+    };
+    project(a, 0); project(b, 1); project(c, 2);
     int64_t area2 = (int64_t)(X[1] - X[0]) * (int64_t)(Y[2] - Y[0]) - (int64_t)(X[2] - X[0]) * (int64_t)(Y[1] - Y[0]);
     if (area2 == 0) return false;
     // y-down: area2 > 0 <=> clockwise as seen; front = counter-clockwise (FrontCounterClockwise = TRUE)
     bool front = area2 < 0;
     if (gp.cull_front ? front : !front) return false;
-    int i1 = 1, i2 = 2;
-    if (area2 < 0) { i1 = 2; i2 = 1; area2 = -area2; }
-    const int o[3] = {0, i1, i2};
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        int k = o[i];
-        t.X[i] = X[k]; t.Y[i] = Y[k]; t.z[i] = z[k]; t.iw[i] = iw[k];
-        t.bary[i][0] = v[k]->b0; t.bary[i][1] = v[k]->b1; t.bary[i][2] = v[k]->b2;
-    }
+    // oriented so that area2 > 0: vertices 1 and 2 change places (selects, no indexed private arrays: those live in scratch memory)
+    const bool swap = area2 < 0;
+    if (swap) area2 = -area2;
+    t.X[0] = X[0]; t.Y[0] = Y[0]; t.z[0] = z[0]; t.iw[0] = iw[0];
+    t.X[1] = swap ? X[2] : X[1]; t.Y[1] = swap ? Y[2] : Y[1]; t.z[1] = swap ? z[2] : z[1]; t.iw[1] = swap ? iw[2] : iw[1];
+    t.X[2] = swap ? X[1] : X[2]; t.Y[2] = swap ? Y[1] : Y[2]; t.z[2] = swap ? z[1] : z[2]; t.iw[2] = swap ? iw[1] : iw[2];
+    t.bary[0][0] = a.b0; t.bary[0][1] = a.b1; t.bary[0][2] = a.b2;
+    t.bary[1][0] = swap ? c.b0 : b.b0; t.bary[1][1] = swap ? c.b1 : b.b1; t.bary[1][2] = swap ? c.b2 : b.b2;
+    t.bary[2][0] = swap ? b.b0 : c.b0; t.bary[2][1] = swap ? b.b1 : c.b1; t.bary[2][2] = swap ? b.b2 : c.b2;
     t.area2 = area2;
     int32_t xmin = min(X[0], min(X[1], X[2])), xmax = max(X[0], max(X[1], X[2]));
     int32_t ymin = min(Y[0], min(Y[1], Y[2])), ymax = max(Y[0], max(Y[1], Y[2]));
@@ -246,115 +260,197 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v, uint32_t lane
     return v;
 }
 
-__global__ __launch_bounds__(256) void k_setup(const ObjectRec *__restrict__ objs, const uint32_t *__restrict__ block_obj,
-                                               const uint32_t *__restrict__ block_first, const GeomParams gp,
-                                               const XVert *__restrict__ xv, SetupRec *__restrict__ recs, RasterRec *__restrict__ rrecs,
-                                               uint32_t *__restrict__ rec_of, uint2 *__restrict__ items, uint32_t item_cap,
-                                               uint32_t rec_cap, uint32_t *__restrict__ counters) {
+struct SetupTables {
+    SetupRec *recs; RasterRec *rrecs; uint32_t *rec_of; uint2 *items; uint32_t item_cap, rec_cap;
+    uint32_t *counters;   // [0] records, [1] work items (one 64-bit word), [2] overflow flag, [3] entries of the clip list
+};
+
+// clip-space vertices of source triangle ti of object ob; false: no such triangle / an index out of range
+__device__ __forceinline__ bool load_triangle(const ObjectRec &ob, uint32_t ti, const XVert *__restrict__ xv, CV &a, CV &b, CV &c) {
+    if (ti >= ob.n_triangles) return false;
+    const uint32_t i0 = ob.indices[3 * ti], i1 = ob.indices[3 * ti + 1], i2 = ob.indices[3 * ti + 2];
+    if (!(i0 < ob.n_vertices && i1 < ob.n_vertices && i2 < ob.n_vertices)) return false;
+    const auto fetch = [&](uint32_t i, CV &v, float b0, float b1, float b2) {
+        const float4 p = *reinterpret_cast<const float4 *>(xv[ob.first_xvert + i].clip);
+        v.x = p.x; v.y = p.y; v.z = p.z; v.w = p.w; v.b0 = b0; v.b1 = b1; v.b2 = b2;
+    };
+    fetch(i0, a, 1.0f, 0.0f, 0.0f); fetch(i1, b, 0.0f, 1.0f, 0.0f); fetch(i2, c, 0.0f, 0.0f, 1.0f);
+    return true;
+}
+__device__ __forceinline__ bool inside_all_planes(const CV &v) {
+    bool inside = true;
+#pragma unroll
+    for (int p = 0; p < 6; ++p) inside = inside && (plane_dist(v, p) >= 0.0f);
+    return inside;
+}
+
+// what a set-up triangle will put into the tables: its RasterRec and its work items.  Blocks of the bounding box no edge function
+// reaches are not emitted: as a bit mask for records of up to 16 blocks (nearly all), at emission for larger ones -- their slots
+// are taken before the wave looks at them, so those become ITEM_SKIP
+struct EmitPlan {
+    RasterRec q;
+    int32_t bx0, by0;
+    uint32_t nbx, nbb /*blocks of the bounding box*/, mask, nb /*item slots*/;
+};
+__device__ __forceinline__ void plan_triangle(bool has, const SetupRec &t, const GeomParams &gp, EmitPlan &e) {
+    e.q = RasterRec{};
+    e.bx0 = e.by0 = 0; e.nbx = 1; e.nbb = e.mask = e.nb = 0;
+    if (!has) return;
+    make_raster_rec(t, (gp.raster_flags & 1) != 0, e.q);
+    e.bx0 = t.px0 >> 4; e.by0 = t.py0 >> 4;
+    e.nbx = (uint32_t)((t.px1 >> 4) - e.bx0 + 1);
+    e.nbb = tiles_of(t);
+    e.nb = e.nbb;
+    if (e.nbb <= 16 && (e.q.flags & RASTER_EXACT_F64)) {
+        uint32_t x = 0, y = 0;
+        for (uint32_t j = 0; j < e.nbb; ++j) {
+            if (block_reachable(e.q, e.bx0 + (int32_t)x, e.by0 + (int32_t)y)) e.mask |= 1u << j;
+            if (++x == e.nbx) { x = 0; ++y; }
+        }
+        e.nb = (uint32_t)__popc(e.mask);
+    } else if (e.nbb <= 16) e.mask = (1u << e.nbb) - 1u;
+}
+// record slot r and item slots [ibase, ibase + e.nb) are this lane's: write them.  Called by whole waves (large records are
+// written by all lanes together).
+__device__ __forceinline__ void place_triangle(bool has, SetupRec &t, EmitPlan &e, uint32_t r, uint32_t ibase, uint32_t src, uint32_t oi, uint32_t sub,
+                                               const GeomParams &gp, const SetupTables &T) {
+    const uint32_t lane = threadIdx.x & 63;
+    if (has) {
+        t.src_tri = src; t.object = oi; t.order_id = src * 8u + sub; t.pad = 0;
+        e.q.order_id = t.order_id;
+        if (r < T.rec_cap) { T.recs[r] = t; T.rrecs[r] = e.q; T.rec_of[src * 8u + sub] = r; }
+        else e.nb = e.nbb = 0;   // record table full (flagged by the caller; k_raster then does nothing)
+    }
+    const auto block_code = [&](int32_t bx, int32_t by) {
+        const bool whole = bx * 16 >= gp.sc_x0 && bx * 16 + 16 <= gp.sc_x1 && by * 16 >= gp.sc_y0 && by * 16 + 16 <= gp.sc_y1;
+        return (uint32_t)bx | ((uint32_t)by << 12) | (whole ? 0u : ITEM_SCISSOR);
+    };
+    // small records: the lane writes its own items; large ones (a wall across the screen is thousands of blocks): the
+    // whole wave writes them, 64 per step
+    if (e.nbb <= 16 && e.nb != 0) {
+        uint32_t x = 0, y = 0, at = ibase;
+        for (uint32_t j = 0; j < e.nbb; ++j) {
+            if ((e.mask >> j) & 1u) { if (at < T.item_cap) T.items[at] = make_uint2(r, block_code(e.bx0 + (int32_t)x, e.by0 + (int32_t)y)); ++at; }
+            if (++x == e.nbx) { x = 0; ++y; }
+        }
+    }
+    for (unsigned long long big = __ballot(e.nbb > 16); big != 0ull; big &= big - 1ull) {
+        const int L = __ffsll((long long)big) - 1;
+        const uint32_t R = __shfl(r, L), NB = __shfl(e.nbb, L), IB = __shfl(ibase, L), NX = __shfl(e.nbx, L);
+        const int32_t X0 = __shfl(e.bx0, L), Y0 = __shfl(e.by0, L);
+        RasterRec w;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { w.A[i] = __shfl(e.q.A[i], L); w.B[i] = __shfl(e.q.B[i], L); w.C[i] = __shfl(e.q.C[i], L); }
+        w.t0 = __shfl(e.q.t0, L); w.t2 = __shfl(e.q.t2, L);
+        const bool exact = (__shfl(e.q.flags, L) & RASTER_EXACT_F64) != 0;
+        for (uint32_t j = lane; j < NB; j += 64) {
+            const int32_t bx = X0 + (int32_t)(j % NX), by = Y0 + (int32_t)(j / NX);
+            const bool live = !exact || block_reachable(w, bx, by);
+            if (IB + j < T.item_cap) T.items[IB + j] = make_uint2(live ? R : ITEM_SKIP, block_code(bx, by));
+        }
+    }
+}
+// slots for nr records and ni work items: ONE 64-bit atomicAdd (records low, items high; same-address atomics retire at ~88
+// per microsecond: one per wave was 40 us of k_setup at 4K)
+__device__ __forceinline__ unsigned long long take_slots(uint32_t nr, uint32_t ni, const SetupTables &T) {
+    const unsigned long long base = (nr | ni) ? atomicAdd(reinterpret_cast<unsigned long long *>(T.counters), (unsigned long long)nr | ((unsigned long long)ni << 32)) : 0ull;
+    if ((uint32_t)(base >> 32) + ni > T.item_cap || (uint32_t)base + nr > T.rec_cap) T.counters[2] = 1;   // a table is full: reported by the host
+    return base;
+}
+
+// The common case, no private arrays and no LDS polygons: triangles inside all six planes are set up and emitted here (the
+// workgroup takes its slots with one atomic, split among the waves through LDS); triangles a plane cuts go to the clip list
+// for k_setup_clipped.  (With the clipper inside, its polygons in scratch memory, this kernel took 43 us at 4K.)
+__global__ __launch_bounds__(SETUP_THREADS) void k_setup(const ObjectRec *__restrict__ objs, const uint32_t *__restrict__ block_obj,
+                                                         const uint32_t *__restrict__ block_first, const GeomParams gp,
+                                                         const XVert *__restrict__ xv, SetupTables T, uint2 *__restrict__ clip_list) {
+    constexpr uint32_t WAVES = SETUP_THREADS / 64;
+    __shared__ uint32_t s_count[WAVES][2], s_base[2];
     const uint32_t oi = block_obj[blockIdx.x];
     const ObjectRec &ob = objs[oi];
     const uint32_t ti = block_first[blockIdx.x] + threadIdx.x;
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t src = ob.first_triangle + ti;
-    int n = 0;   // vertices of the clipped polygon; 0: no triangle in this lane
-    CV poly[MAX_POLY];
-    if (ti < ob.n_triangles) {
-        const uint32_t idx[3] = {ob.indices[3 * ti], ob.indices[3 * ti + 1], ob.indices[3 * ti + 2]};
-        if (idx[0] < ob.n_vertices && idx[1] < ob.n_vertices && idx[2] < ob.n_vertices) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    CV a, b, c;
+    const bool valid = load_triangle(ob, ti, xv, a, b, c);
+    // the clipper's own first decision (clip_polygon): the first plane that does not hold all three vertices either holds none
+    // -- nothing to draw -- or cuts the triangle; no such plane: the triangle goes through untouched
+    bool inside = valid, straddles = false;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const float *c = xv[ob.first_xvert + idx[k]].clip;
-                poly[k].x = c[0]; poly[k].y = c[1]; poly[k].z = c[2]; poly[k].w = c[3];
-                poly[k].b0 = k == 0 ? 1.0f : 0.0f; poly[k].b1 = k == 1 ? 1.0f : 0.0f; poly[k].b2 = k == 2 ? 1.0f : 0.0f;
-            }
-            bool inside = true;
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-#pragma unroll
-                for (int p = 0; p < 6; ++p) inside = inside && (plane_dist(poly[k], p) >= 0.0f);
-            n = inside ? 3 : clip_polygon(poly, 3);
-        }
+    for (int p = 5; p >= 0; --p) {
+        const bool ia = plane_dist(a, p) >= 0.0f, ib = plane_dist(b, p) >= 0.0f, ic = plane_dist(c, p) >= 0.0f;
+        if (!(ia && ib && ic)) { inside = false; straddles = valid && (ia || ib || ic); }   // descending p: the first such plane decides last
     }
-    // the fan over the polygon, one triangle per trip (one trip unless a triangle of this workgroup was clipped); every trip
-    // takes the workgroup's record slots and work-item slots with ONE atomicAdd each (a same-address atomic retires at
-    // ~88 per microsecond: one per wave was 40 us of this kernel), split among the four waves through LDS
-    __shared__ uint32_t s_count[4][2], s_base[2];
-    const uint32_t wave = threadIdx.x >> 6;
-    uint32_t produced = 0;   // sub-triangles this lane has emitted so far = index of the next one in draw order
-    for (int f = 1; __syncthreads_or(f + 1 < n); ++f) {
-        SetupRec t;
-        RasterRec q = {};
-        const bool has = (f + 1 < n) && setup_triangle(poly[0], poly[f], poly[f + 1], gp, t);
-        // blocks of the bounding box no edge function reaches are not emitted: as a bit mask for records of up to 16 blocks
-        // (nearly all), at emission for larger ones -- their slots are taken before the wave looks at them, so those become ITEM_SKIP
-        int32_t bx0 = 0, by0 = 0;
-        uint32_t nbx = 1, nbb = 0, mask = 0, nb = 0;
-        if (has) {
-            make_raster_rec(t, (gp.raster_flags & 1) != 0, q);
-            bx0 = t.px0 >> 4; by0 = t.py0 >> 4;
-            nbx = (uint32_t)((t.px1 >> 4) - bx0 + 1);
-            nbb = tiles_of(t);
-            nb = nbb;
-            if (nbb <= 16 && (q.flags & RASTER_EXACT_F64)) {
-                uint32_t x = 0, y = 0;
-                for (uint32_t j = 0; j < nbb; ++j) {
-                    if (block_reachable(q, bx0 + (int32_t)x, by0 + (int32_t)y)) mask |= 1u << j;
-                    if (++x == nbx) { x = 0; ++y; }
-                }
-                nb = (uint32_t)__popc(mask);
-            } else if (nbb <= 16) mask = (1u << nbb) - 1u;
-        }
-        const unsigned long long m = __ballot(has);
-        const uint32_t iincl = wave_inclusive_sum(nb, lane);
-        const uint32_t itotal = __shfl(iincl, 63);
-        if (lane == 0) { s_count[wave][0] = (uint32_t)__popcll(m); s_count[wave][1] = itotal; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const uint32_t nr = s_count[0][0] + s_count[1][0] + s_count[2][0] + s_count[3][0];
-            const uint32_t ni = s_count[0][1] + s_count[1][1] + s_count[2][1] + s_count[3][1];
-            s_base[0] = nr ? atomicAdd(&counters[0], nr) : 0u;
-            s_base[1] = ni ? atomicAdd(&counters[1], ni) : 0u;
-            if (s_base[1] + ni > item_cap || s_base[0] + nr > rec_cap) counters[2] = 1;   // a table is full: reported by the host
-        }
-        __syncthreads();
-        uint32_t rbase = s_base[0], ibase = s_base[1];
-        for (uint32_t w = 0; w < wave; ++w) { rbase += s_count[w][0]; ibase += s_count[w][1]; }
-        ibase += iincl - nb;
-        const uint32_t r = rbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        if (has) {
-            t.src_tri = src; t.object = oi; t.order_id = src * 8u + produced; t.pad = 0;
-            q.order_id = t.order_id;
-            if (r < rec_cap) { recs[r] = t; rrecs[r] = q; rec_of[src * 8u + produced] = r; }
-            else nb = nbb = 0;   // record table full (flagged above; k_raster then does nothing)
-            ++produced;
-        }
-        const auto block_code = [&](int32_t bx, int32_t by) {
-            const bool whole = bx * 16 >= gp.sc_x0 && bx * 16 + 16 <= gp.sc_x1 && by * 16 >= gp.sc_y0 && by * 16 + 16 <= gp.sc_y1;
-            return (uint32_t)bx | ((uint32_t)by << 12) | (whole ? 0u : ITEM_SCISSOR);
-        };
-        // small records: the lane writes its own items; large ones (a wall across the screen is thousands of blocks): the
-        // whole wave writes them, 64 per step
-        if (nbb <= 16 && nb != 0) {
-            uint32_t x = 0, y = 0, at = ibase;
-            for (uint32_t j = 0; j < nbb; ++j) {
-                if ((mask >> j) & 1u) { if (at < item_cap) items[at] = make_uint2(r, block_code(bx0 + (int32_t)x, by0 + (int32_t)y)); ++at; }
-                if (++x == nbx) { x = 0; ++y; }
+    const unsigned long long cm = __ballot(straddles);
+    if (cm) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&T.counters[3], (uint32_t)__popcll(cm));
+        base = __shfl(base, 0);
+        if (straddles) clip_list[base + (uint32_t)__popcll(cm & ((1ull << lane) - 1ull))] = make_uint2(oi, ti);
+    }
+    SetupRec t;
+    const bool has = inside && setup_triangle(a, b, c, gp, t);
+    EmitPlan e;
+    plan_triangle(has, t, gp, e);
+    const unsigned long long m = __ballot(has);
+    const uint32_t iincl = wave_inclusive_sum(e.nb, lane);
+    if (lane == 63) { s_count[wave][0] = (uint32_t)__popcll(m); s_count[wave][1] = iincl; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t nr = 0, ni = 0;
+        for (uint32_t w = 0; w < WAVES; ++w) { nr += s_count[w][0]; ni += s_count[w][1]; }
+        const unsigned long long base = take_slots(nr, ni, T);
+        s_base[0] = (uint32_t)base; s_base[1] = (uint32_t)(base >> 32);
+    }
+    __syncthreads();
+    uint32_t rbase = s_base[0], ibase = s_base[1];
+    for (uint32_t w = 0; w < wave; ++w) { rbase += s_count[w][0]; ibase += s_count[w][1]; }
+    place_triangle(has, t, e, rbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), ibase + iincl - e.nb, ob.first_triangle + ti, oi, 0u, gp, T);
+}
+
+// The triangles of the clip list, one wave per workgroup, a lane per triangle: Sutherland-Hodgman in LDS, then the fan over the
+// polygon twice -- once to count records and work items (one atomic per wave for all of them), once to write them.
+__global__ __launch_bounds__(64) void k_setup_clipped(const ObjectRec *__restrict__ objs, const GeomParams gp, const XVert *__restrict__ xv,
+                                                      SetupTables T, const uint2 *__restrict__ clip_list) {
+    __shared__ PolyStore P;
+    const uint32_t count = T.counters[3], lane = threadIdx.x;
+    for (uint32_t first = blockIdx.x * 64; first < count; first += gridDim.x * 64) {   // uniform per wave
+        const uint32_t entry_at = first + lane;
+        int n = 0, buf = 0;   // vertices of the clipped polygon (0: no triangle in this lane) and where it is
+        uint32_t oi = 0, src = 0;
+        if (entry_at < count) {
+            const uint2 entry = clip_list[entry_at];
+            oi = entry.x;
+            const ObjectRec &ob = objs[oi];
+            src = ob.first_triangle + entry.y;
+            CV a, b, c;
+            if (load_triangle(ob, entry.y, xv, a, b, c)) {
+                P.put(0, 0, lane, a); P.put(0, 1, lane, b); P.put(0, 2, lane, c);
+                n = clip_polygon(P, lane, buf);
             }
         }
-        for (unsigned long long big = __ballot(nbb > 16); big != 0ull; big &= big - 1ull) {
-            const int L = __ffsll((long long)big) - 1;
-            const uint32_t R = __shfl(r, L), NB = __shfl(nbb, L), IB = __shfl(ibase, L), NX = __shfl(nbx, L);
-            const int32_t X0 = __shfl(bx0, L), Y0 = __shfl(by0, L);
-            RasterRec w;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) { w.A[i] = __shfl(q.A[i], L); w.B[i] = __shfl(q.B[i], L); w.C[i] = __shfl(q.C[i], L); }
-            w.t0 = __shfl(q.t0, L); w.t2 = __shfl(q.t2, L);
-            const bool exact = (__shfl(q.flags, L) & RASTER_EXACT_F64) != 0;
-            for (uint32_t j = lane; j < NB; j += 64) {
-                const int32_t bx = X0 + (int32_t)(j % NX), by = Y0 + (int32_t)(j / NX);
-                const bool live = !exact || block_reachable(w, bx, by);
-                if (IB + j < item_cap) items[IB + j] = make_uint2(live ? R : ITEM_SKIP, block_code(bx, by));
-            }
+        const int n_max = __reduce_max_sync(~0ull, n);
+        uint32_t nr = 0, ni = 0;
+        for (int f = 1; f + 1 < n_max; ++f) {
+            SetupRec t;
+            EmitPlan e;
+            const bool has = (f + 1 < n) && setup_triangle(P.get(buf, 0, lane), P.get(buf, f, lane), P.get(buf, f + 1, lane), gp, t);
+            plan_triangle(has, t, gp, e);
+            nr += has ? 1u : 0u; ni += e.nb;
+        }
+        const uint32_t rincl = wave_inclusive_sum(nr, lane), iincl = wave_inclusive_sum(ni, lane);
+        unsigned long long base = 0;
+        if (lane == 63) base = take_slots(rincl, iincl, T);
+        base = __shfl(base, 63);
+        uint32_t r = (uint32_t)base + rincl - nr, ibase = (uint32_t)(base >> 32) + iincl - ni, produced = 0;
+        for (int f = 1; f + 1 < n_max; ++f) {
+            SetupRec t;
+            EmitPlan e;
+            const bool has = (f + 1 < n) && setup_triangle(P.get(buf, 0, lane), P.get(buf, f, lane), P.get(buf, f + 1, lane), gp, t);
+            plan_triangle(has, t, gp, e);
+            const uint32_t slots = e.nb;   // place_triangle zeroes nb when the record table is full; the slots stay taken
+            place_triangle(has, t, e, r, ibase, src, oi, produced, gp, T);
+            if (has) { ++r; ++produced; }
+            ibase += slots;
         }
     }
 }
@@ -501,13 +597,40 @@ __device__ __forceinline__ void raster_item_i64(const SetupRec &t, uint32_t code
     }
 }
 
+// early depth test and depth write of one work item: the four reads are issued together, then the atomics of the pixels that still
+// win.  Byte offsets fit 32 bits (the planes are at most 16384^2 entries of 8 / 4 bytes): wave-uniform base + per-lane offset.
+template <bool DEPTH_ONLY>
+__device__ __forceinline__ void depth_test_and_write(const LanePixels &p, uint32_t order_id, unsigned long long *__restrict__ vis, uint32_t *__restrict__ depth_bits) {
+    if (DEPTH_ONLY) {
+        uint32_t cur[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { cur[k] = 0u; if (p.ok[k]) cur[k] = *(const uint32_t __attribute__((address_space(1))) *)((gbytes)depth_bits + p.at[k] * 4u); }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (p.ok[k] && p.zb[k] < cur[k])
+                __hip_atomic_fetch_min((uint32_t __attribute__((address_space(1))) *)((gbytes)depth_bits + p.at[k] * 4u), p.zb[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        unsigned long long cur[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { cur[k] = 0ull; if (p.ok[k]) cur[k] = *(const unsigned long long __attribute__((address_space(1))) *)((gbytes)vis + p.at[k] * 8u); }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned long long key = ((unsigned long long)p.zb[k] << 32) | order_id;   // ties: first drawn (smallest order id) wins
+            if (p.ok[k] && key < cur[k])
+                __hip_atomic_fetch_min((unsigned long long __attribute__((address_space(1))) *)((gbytes)vis + p.at[k] * 8u), key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // Persistent: the number of work items is only known on the device (counters[1]), so a fixed grid strides over the item
-// table and the host never waits for a count.  A wave takes ITEMS work items per trip: their early depth reads are issued
-// together and their atomics follow together, because that is what a trip costs -- the wait for the reads cannot complete
-// before the previous trip's atomics have (loads, stores and atomics retire through one in-order counter on gfx9), so a trip is
-// two memory round trips whatever it carries (measured: one item per trip 84 us at 4K, the arithmetic alone would be 30).
-// The table entries of the next trip are in flight while this one runs.
-constexpr int ITEMS = 1;
+// table and the host never waits for a count.  Software pipeline, two items deep: while item i is rasterised the record
+// of item i+1 (scalar loads, its index arrived a trip ago) and the table entry of item i+2 are in flight, so a wave pays
+// the entry -> record -> pixels chain of dependent round trips once, not per item.  Two trips per loop iteration: the two
+// record register sets swap roles instead of being copied.
+// What bounds it (tools/experiments/atomic_rates.hip, profiles/): the memory side retires ~25 atomic requests per ns -- a
+// request = the lanes of one instruction that fall into one 64-byte segment, whatever their number, workgroup or agent scope,
+// 32 or 64 bit -- and a 4K frame issues 1.65 M of them (5.8 of 8 pixels per request: triangle edges and 1.15x overdraw): 66 us
+// of the kernel's 84.  Two items per trip, chunked instead of strided item order and dropping the early read change nothing.
 template <bool DEPTH_ONLY>
 __global__ __launch_bounds__(256) void k_raster(const SetupRec *__restrict__ recs, const RasterRec *__restrict__ rrecs,
                                                 const uint2 *__restrict__ items, uint32_t item_cap,
@@ -520,69 +643,35 @@ __global__ __launch_bounds__(256) void k_raster(const SetupRec *__restrict__ rec
     const uint32_t n_items = min(counters[1], item_cap);
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t stride = gridDim.x * 4;
-    uint32_t item = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t item = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (item >= n_items) return;
     const RasterFrame fr = {gp.sc_x0, gp.sc_y0, gp.sc_x1, gp.sc_y1, gp.tiles_x, gp.tile_y0, gp.pitch, gp.band_tiles, gp.shard_index, gp.shard_count};
-    const uint2 none = make_uint2(ITEM_SKIP, 0u);
-    uint2 en[ITEMS];
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) en[j] = item + j * stride < n_items ? items[item + j * stride] : none;
-    for (; item < n_items; item += ITEMS * stride) {
-        uint32_t r[ITEMS], code[ITEMS];
-        RasterRec q[ITEMS];
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
-            r[j] = __builtin_amdgcn_readfirstlane(en[j].x); code[j] = __builtin_amdgcn_readfirstlane(en[j].y);
-            q[j] = rrecs[r[j] == ITEM_SKIP ? 0u : r[j]];
-        }
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j) { const uint32_t nxt = item + (ITEMS + j) * stride; en[j] = nxt < n_items ? items[nxt] : none; }
-        LanePixels p[ITEMS];
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
-            if (r[j] != ITEM_SKIP && !(q[j].flags & RASTER_EXACT_F64)) {   // rare: the record's own integer path, start to finish
-                raster_item_i64<DEPTH_ONLY>(recs[r[j]], code[j], lane, fr, vis, depth_bits);
-                r[j] = ITEM_SKIP;
-            }
-            item_pixels<DEPTH_ONLY>(q[j], code[j], lane, fr, p[j]);
-            if (r[j] == ITEM_SKIP) p[j].ok[0] = p[j].ok[1] = p[j].ok[2] = p[j].ok[3] = false;
-        }
-        // byte offsets fit 32 bits: the planes are at most 16384^2 entries of 8 (4) bytes
-        if (DEPTH_ONLY) {
-            uint32_t cur[ITEMS][4];
-#pragma unroll
-            for (int j = 0; j < ITEMS; ++j)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    cur[j][k] = 0u;
-                    if (p[j].ok[k]) cur[j][k] = *(const uint32_t __attribute__((address_space(1))) *)((gbytes)depth_bits + p[j].at[k] * 4u);
-                }
-#pragma unroll
-            for (int j = 0; j < ITEMS; ++j)
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (p[j].ok[k] && p[j].zb[k] < cur[j][k])
-                        __hip_atomic_fetch_min((uint32_t __attribute__((address_space(1))) *)((gbytes)depth_bits + p[j].at[k] * 4u), p[j].zb[k],
-                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            unsigned long long cur[ITEMS][4];
-#pragma unroll
-            for (int j = 0; j < ITEMS; ++j)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    cur[j][k] = 0ull;
-                    if (p[j].ok[k]) cur[j][k] = *(const unsigned long long __attribute__((address_space(1))) *)((gbytes)vis + p[j].at[k] * 8u);
-                }
-#pragma unroll
-            for (int j = 0; j < ITEMS; ++j)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const unsigned long long key = ((unsigned long long)p[j].zb[k] << 32) | q[j].order_id;   // ties: first drawn (smallest order id) wins
-                    if (p[j].ok[k] && key < cur[j][k])
-                        __hip_atomic_fetch_min((unsigned long long __attribute__((address_space(1))) *)((gbytes)vis + p[j].at[k] * 8u), key,
-                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-        }
+    const auto one = [&](const RasterRec &q, uint32_t r, uint32_t code) {
+        if (r == ITEM_SKIP) return;
+        if (q.flags & RASTER_EXACT_F64) {
+            LanePixels p;
+            item_pixels<DEPTH_ONLY>(q, code, lane, fr, p);
+            depth_test_and_write<DEPTH_ONLY>(p, q.order_id, vis, depth_bits);
+        } else raster_item_i64<DEPTH_ONLY>(recs[r], code, lane, fr, vis, depth_bits);
+    };
+    const auto rec_index = [](uint32_t r) { return r == ITEM_SKIP ? 0u : r; };
+    uint2 en = items[item];
+    uint32_t ra = __builtin_amdgcn_readfirstlane(en.x), ca = __builtin_amdgcn_readfirstlane(en.y);
+    RasterRec a = rrecs[rec_index(ra)];
+    en = items[min(item + stride, n_items - 1)];
+    for (;;) {
+        const uint32_t rb = __builtin_amdgcn_readfirstlane(en.x), cb = __builtin_amdgcn_readfirstlane(en.y);
+        const RasterRec b = rrecs[rec_index(rb)];                      // used next trip
+        en = items[min(item + 2 * stride, n_items - 1)];               // used the trip after
+        one(a, ra, ca);
+        item += stride;
+        if (item >= n_items) break;
+        ra = __builtin_amdgcn_readfirstlane(en.x); ca = __builtin_amdgcn_readfirstlane(en.y);
+        a = rrecs[rec_index(ra)];
+        en = items[min(item + 2 * stride, n_items - 1)];
+        one(b, rb, cb);
+        item += stride;
+        if (item >= n_items) break;
     }
 }
 
@@ -686,9 +775,12 @@ hipError_t launch_vertex(const ObjectRec *objs, const uint32_t *block_obj, const
 
 hipError_t launch_setup(const ObjectRec *objs, const uint32_t *block_obj, const uint32_t *block_first, uint32_t n_blocks,
                         const GeomParams &gp, const XVert *xv, SetupRec *recs, RasterRec *rrecs, uint32_t *rec_of, uint2 *items, uint32_t item_cap,
-                        uint32_t rec_cap, uint32_t *counters, hipStream_t s) {
+                        uint32_t rec_cap, uint32_t *counters, uint2 *clip_list, hipStream_t s) {
     if (n_blocks == 0) return hipSuccess;
-    k_setup<<<n_blocks, 256, 0, s>>>(objs, block_obj, block_first, gp, xv, recs, rrecs, rec_of, items, item_cap, rec_cap, counters);
+    const SetupTables T = {recs, rrecs, rec_of, items, item_cap, rec_cap, counters};
+    k_setup<<<n_blocks, SETUP_THREADS, 0, s>>>(objs, block_obj, block_first, gp, xv, T, clip_list);
+    // the clip list's length stays on the device: a fixed small grid strides over it (empty in most frames of most scenes)
+    k_setup_clipped<<<std::min<uint32_t>(n_blocks * (SETUP_THREADS / 64), 512u), 64, 0, s>>>(objs, gp, xv, T, clip_list);
     return hipGetLastError();
 }
 

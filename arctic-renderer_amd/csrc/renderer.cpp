@@ -156,7 +156,7 @@ struct ArcticRenderer {
     bool visbuffer = true;          // arctic_render_frame shades straight from the visibility plane (no G-buffer)
     // per-frame geometry scratch
     PassTables tables[2];   // [0] forward pass, [1] shadow pass
-    DevBuf d_xverts, d_recs, d_rrecs, d_rec_of, d_items, d_geo_counters, d_stage;
+    DevBuf d_xverts, d_recs, d_rrecs, d_clip_list, d_rec_of, d_items, d_geo_counters, d_stage;
     uint32_t item_cap = 0;          // entries of d_items (work-item table of the rasteriser)
     bool recs_worst_case = false;   // record table at 7 per source triangle (after an overflow of the 2-per-triangle table)
     uint32_t item_cap_floor = 1u << 22;   // its smallest size (ARCTIC_OPT_ITEM_TABLE_FLOOR; tests shrink it to reach the overflow path)
@@ -261,7 +261,7 @@ int upload_pass_tables(ArcticRenderer *r, PassTables &T, const GeomParams &gp, c
         rec.pad = 0;
         uint32_t oi = (uint32_t)objs.size();
         for (uint32_t b = 0; b < rec.n_vertices; b += 256) { vb_obj.push_back(oi); vb_first.push_back(b); }
-        for (uint32_t b = 0; b < rec.n_triangles; b += 256) { tb_obj.push_back(oi); tb_first.push_back(b); }
+        for (uint32_t b = 0; b < rec.n_triangles; b += SETUP_THREADS) { tb_obj.push_back(oi); tb_first.push_back(b); }
         xv += rec.n_vertices;
         tri += rec.n_triangles;
         objs.push_back(rec);
@@ -362,9 +362,11 @@ int run_geometry(ArcticRenderer *r, const ArcticScene *sc, bool shadow_pass) {
     HIPCHECK(r, r->d_recs.ensure((size_t)n_slots * sizeof(SetupRec)));
     HIPCHECK(r, r->d_rrecs.ensure((size_t)n_slots * sizeof(RasterRec)));
     HIPCHECK(r, r->d_rec_of.ensure((size_t)n_src * 8 * 4));
+    HIPCHECK(r, r->d_clip_list.ensure((size_t)n_src * 8));
     uint32_t *counters = r->d_geo_counters.as<uint32_t>() + (shadow_pass ? 4 : 0);   // zeroed by k_vertex
     HIPCHECK(r, launch_setup(objs, T.tblock_obj, T.tblock_first, n_tblocks, d_gp, r->d_xverts.as<XVert>(), r->d_recs.as<SetupRec>(),
-                             r->d_rrecs.as<RasterRec>(), r->d_rec_of.as<uint32_t>(), r->d_items.as<uint2>(), r->item_cap, n_slots, counters, r->stream));
+                             r->d_rrecs.as<RasterRec>(), r->d_rec_of.as<uint32_t>(), r->d_items.as<uint2>(), r->item_cap, n_slots, counters,
+                             r->d_clip_list.as<uint2>(), r->stream));
     // counts for arctic_stats() and the overflow flag: k_raster stores them into pinned, mapped memory (no copy launches between
     // the kernels); looked at only when the stream has been synchronised
     uint32_t *dh = r->dh_counts + (shadow_pass ? 2 : 0), *dh_overflow = r->dh_counts + 4 + (shadow_pass ? 1 : 0);
@@ -617,7 +619,7 @@ void arctic_destroy(ArcticRenderer *r) {
     for (void *p : r->tex_allocs) (void)hipFree(p);
     DevBuf *bufs[] = {&r->d_tex, &r->d_lut, &r->d_lights, &r->d_light_pairs, &r->d_shadow, &r->d_env, &r->d_vis, &r->d_p0, &r->d_p1, &r->d_p2, &r->d_p3, &r->d_p4,
                       &r->d_rgba8, &r->d_ldr, &r->d_hdr, &r->d_counter, &r->d_shadow_blocks, &r->d_shadow_bounds, &r->d_staging, &r->d_layout, &r->d_xverts,
-                      &r->d_recs, &r->d_rrecs, &r->d_rec_of, &r->d_items, &r->d_geo_counters, &r->d_stage, &r->tables[0].d, &r->tables[1].d};
+                      &r->d_recs, &r->d_rrecs, &r->d_clip_list, &r->d_rec_of, &r->d_items, &r->d_geo_counters, &r->d_stage, &r->tables[0].d, &r->tables[1].d};
     for (PassTables &T : r->tables) { if (T.h) (void)hipHostFree(T.h); if (T.copied) (void)hipEventDestroy(T.copied); }
     for (DevBuf *b : bufs) b->release();
     delete r;
