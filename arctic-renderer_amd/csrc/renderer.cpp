@@ -309,6 +309,10 @@ int upload_pass_tables(ArcticRenderer *r, PassTables &T, const GeomParams &gp, c
 
 // vertex -> clip/setup -> raster, shared by the forward prepass and the shadow pass
 int run_geometry(ArcticRenderer *r, const ArcticScene *sc, bool shadow_pass) {
+    // the pass's target is cleared by the vertex kernel's launch (or by a fill when there is nothing to draw)
+    unsigned long long *clear = shadow_pass ? r->d_shadow.as<unsigned long long>() : r->d_vis.as<unsigned long long>();
+    const unsigned long long clear_value = shadow_pass ? 0x3F8000003F800000ull : ~0ull;   // depth 1.0 (shadow_map_pass.cpp:124-131) / no triangle
+    const size_t clear_count = shadow_pass ? ((size_t)r->shadow_size * r->shadow_size + 1) / 2 : r->n_tiles() * TILE_PIXELS;
     GeomParams gp;
     std::memset(&gp, 0, sizeof gp);
     sun_proj_view(sc->sun.position, sc->sun.rotation, gp.light_from_world);
@@ -339,10 +343,14 @@ int run_geometry(ArcticRenderer *r, const ArcticScene *sc, bool shadow_pass) {
     int rc = upload_pass_tables(r, T, gp, sc, n_objs, n_xverts, n_src, n_vblocks, n_tblocks);
     if (rc != ARCTIC_OK) return rc;
     const GeomParams &d_gp = T.gp;
-    if (n_objs == 0 || n_src == 0 || n_vblocks == 0) { r->h_counts[shadow_pass ? 2 : 0] = r->h_counts[shadow_pass ? 3 : 1] = 0; return ARCTIC_OK; }
+    if (n_objs == 0 || n_src == 0 || n_vblocks == 0) {
+        r->h_counts[shadow_pass ? 2 : 0] = r->h_counts[shadow_pass ? 3 : 1] = 0;
+        HIPCHECK(r, launch_fill_u64(clear, clear_value, clear_count, r->stream));
+        return ARCTIC_OK;
+    }
     const ObjectRec *objs = T.objs;
     HIPCHECK(r, launch_vertex(objs, T.vblock_obj, T.vblock_first, n_vblocks, d_gp, r->d_xverts.as<XVert>(), shadow_pass ? 1 : 0,
-                              r->d_geo_counters.as<uint32_t>() + (shadow_pass ? 4 : 0), r->stream));
+                              r->d_geo_counters.as<uint32_t>() + (shadow_pass ? 4 : 0), clear, clear_value, clear_count, r->stream));
     // Record slots: a triangle clipped against 6 planes yields at most 7 triangles, so 7 * n_src slots can never overflow.
     // Records and work items are allocated on the device from two counters (k_setup): no count pass, no scan, and neither
     // count has to come back to the host -- the frame stays asynchronous.
@@ -382,8 +390,6 @@ int run_geometry(ArcticRenderer *r, const ArcticScene *sc, bool shadow_pass) {
 int pass_shadow_map(ArcticRenderer *r, const ArcticScene *sc) {
     if (r->shadow_size == 0) return ARCTIC_OK;
     Range zone("Shadow Map Pass");
-    size_t n = (size_t)r->shadow_size * r->shadow_size;
-    HIPCHECK(r, launch_fill_u32(r->d_shadow.as<uint32_t>(), 0x3F800000u, n, r->stream));   // clear to 1.0 (shadow_map_pass.cpp:124-131)
     r->bounds_valid = false;
     int rc = run_geometry(r, sc, true);
     if (rc != ARCTIC_OK) return rc;
@@ -401,7 +407,6 @@ int pass_shadow_map(ArcticRenderer *r, const ArcticScene *sc) {
 // visibility only: vertex -> setup -> raster of the camera view
 int pass_visibility(ArcticRenderer *r, const ArcticScene *sc) {
     Range zone("Forward Pass: visibility");
-    HIPCHECK(r, launch_fill_u64(r->d_vis.as<unsigned long long>(), ~0ull, r->n_tiles() * TILE_PIXELS, r->stream));
     r->have_gbuffer = false;
     int rc = run_geometry(r, sc, false);
     if (rc != ARCTIC_OK) return rc;
@@ -600,7 +605,7 @@ ArcticRenderer *arctic_create(const ArcticCreateInfo *info, char *err, uint64_t 
     if ((e = r->d_tex.ensure(48)) != hipSuccess) return bail("hipMalloc tex table", e);
     if (r->shadow_size) {
         size_t n = (size_t)r->shadow_size * r->shadow_size;
-        if ((e = r->d_shadow.ensure(n * 4)) != hipSuccess) return bail("hipMalloc shadow map", e);
+        if ((e = r->d_shadow.ensure(n * 4 + 8)) != hipSuccess) return bail("hipMalloc shadow map", e);   // + 8: cleared in 8-byte words
         if ((e = launch_fill_u32(r->d_shadow.as<uint32_t>(), 0x3F800000u, n, r->stream)) != hipSuccess) return bail("clear shadow map", e);
     }
     if (alloc_targets(r) != ARCTIC_OK) { say(r->err.c_str()); arctic_destroy(r); return nullptr; }
@@ -1085,7 +1090,7 @@ int arctic_comm_init(ArcticRenderer *r, const void *id_bytes, int rank, int worl
         if ((size_t)per * world > r->shadow_size) {
             const size_t n = (size_t)per * world * r->shadow_size;
             if (r->d_shadow.cap < n * 4) {
-                HIPCHECK(r, r->d_shadow.ensure(n * 4));
+                HIPCHECK(r, r->d_shadow.ensure(n * 4 + 8));
                 HIPCHECK(r, launch_fill_u32(r->d_shadow.as<uint32_t>(), 0x3F800000u, n, r->stream));
                 r->shadow_key.clear(); r->bounds_valid = false;
             }
