@@ -153,7 +153,7 @@ struct ShadeParams {
                                  // [3] (tile, light) pairs with n.wi <= 0 in every lit lane, [4] tiles with a lit pixel
     int32_t culling;
     // whole frames without a G-buffer (k_material_vis): the visibility plane and what the prepass left behind
-    const unsigned long long *vis; const SetupRec *recs; const uint32_t *rec_of; const ObjectRec *objs; const XVert *xv;
+    const unsigned long long *vis; const SetupRec *recs; const RasterRec *rrecs; const uint32_t *rec_of; const ObjectRec *objs; const XVert *xv;
     // skybox (skybox.hlsl:61-90): environment map for pixels without geometry; env == null -> black
     const float4 *env;                  // RGBA32F equirect, row-major
     uint32_t env_w, env_h;
@@ -188,7 +188,7 @@ hipError_t launch_raster_vis(const SetupRec *recs, const RasterRec *rrecs, const
                              const GeomParams &gp, unsigned long long *vis, uint32_t *host_counts /*mapped: records, items*/, uint32_t *host_overflow, hipStream_t s);
 hipError_t launch_raster_depth(const SetupRec *recs, const RasterRec *rrecs, const uint2 *items, uint32_t item_cap, const uint32_t *counters, uint32_t grid_blocks,
                                const GeomParams &gp, uint32_t *depth_bits, uint32_t *host_counts, uint32_t *host_overflow, hipStream_t s);
-hipError_t launch_resolve(const unsigned long long *vis, const SetupRec *recs, const uint32_t *rec_of, const ObjectRec *objs, const XVert *xv,
+hipError_t launch_resolve(const unsigned long long *vis, const SetupRec *recs, const RasterRec *rrecs, const uint32_t *rec_of, const ObjectRec *objs, const XVert *xv,
                           const GeomParams &gp, uint32_t n_tiles, GBuffer g, hipStream_t s);
 hipError_t launch_fill_u64(unsigned long long *p, unsigned long long v, size_t n, hipStream_t s);
 hipError_t launch_fill_u32(uint32_t *p, uint32_t v, size_t n, hipStream_t s);

@@ -34,13 +34,22 @@ __device__ __forceinline__ int64_t edge_eval(const Edges &e, int i, int32_t px, 
 // VSOut attributes are interpolated with): screen-space barycentrics from the edge functions, 1/w correction, then through
 // the record's own barycentric coordinates in its source triangle, so clipped triangles need no vertices of their own.
 // Every operation rounds once, in this order, wherever it is compiled (the callers disable fp contraction).
-__device__ __forceinline__ void source_barycentrics(const SetupRec &t, int32_t px, int32_t py, float B[3]) {
+// The two edge functions come from the record's binary64 planes (RasterRec: exact integers, the same values as edge_eval) unless
+// the record's coordinates are too large for those (RASTER_EXACT_F64 clear: the 64-bit integer path).
+__device__ __forceinline__ void source_barycentrics(const SetupRec &t, const RasterRec &q, int32_t px, int32_t py, float B[3]) {
 #pragma clang fp contract(off)
-    Edges e;
-    make_edges(t, e);
-    const float inv_area = 1.0f / (float)t.area2;
-    const float l1 = (float)edge_eval(e, 2, px, py) * inv_area;
-    const float l2 = (float)edge_eval(e, 0, px, py) * inv_area;
+    float l1, l2;
+    if (q.flags & RASTER_EXACT_F64) {
+        const double x = (double)px, y = (double)py;
+        l1 = (float)__builtin_fma(q.A[2], x, __builtin_fma(q.B[2], y, q.C[2])) * q.inv_area;
+        l2 = (float)__builtin_fma(q.A[0], x, __builtin_fma(q.B[0], y, q.C[0])) * q.inv_area;
+    } else {
+        Edges e;
+        make_edges(t, e);
+        const float inv_area = 1.0f / (float)t.area2;
+        l1 = (float)edge_eval(e, 2, px, py) * inv_area;
+        l2 = (float)edge_eval(e, 0, px, py) * inv_area;
+    }
     const float l0 = (1.0f - l1) - l2;
     const float pw0 = l0 * t.iw[0], pw1 = l1 * t.iw[1], pw2 = l2 * t.iw[2];
     const float rr = 1.0f / ((pw0 + pw1) + pw2);

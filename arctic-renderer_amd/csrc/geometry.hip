@@ -682,7 +682,7 @@ __global__ __launch_bounds__(256) void k_raster(const SetupRec *__restrict__ rec
 // ---------------------------------------------------------------------------------------------
 // resolve: visibility -> interpolated attributes, tile-major G-buffer
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_resolve(const unsigned long long *__restrict__ vis, const SetupRec *__restrict__ recs,
+__global__ __launch_bounds__(256) void k_resolve(const unsigned long long *__restrict__ vis, const SetupRec *__restrict__ recs, const RasterRec *__restrict__ rrecs,
                                                  const uint32_t *__restrict__ rec_of, const ObjectRec *__restrict__ objs, const XVert *__restrict__ xv,
                                                  const GeomParams gp, uint32_t n_tiles, GBuffer g) {
     uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -695,12 +695,13 @@ __global__ __launch_bounds__(256) void k_resolve(const unsigned long long *__res
     for (int k = 0; k < 18; ++k) a[k] = 0.0f;
     uint32_t mat = NO_MATERIAL;
     if (key != ~0ull) {
-        const SetupRec &t = recs[rec_of[(uint32_t)key]];   // low word = order id (k_setup)
+        const uint32_t ri = rec_of[(uint32_t)key];   // low word = order id (k_setup)
+        const SetupRec &t = recs[ri];
         int32_t tx = (int32_t)(tile % (uint32_t)gp.tiles_x);
         int32_t ty = row_global((int)(tile / (uint32_t)gp.tiles_x), gp.band_tiles, gp.shard_count, gp.shard_index) + gp.tile_y0;
         int32_t px = tx * 8 + (int32_t)(lane & 7), py = ty * 8 + (int32_t)(lane >> 3);
         float B[3];
-        source_barycentrics(t, px, py, B);
+        source_barycentrics(t, rrecs[ri], px, py, B);
         const ObjectRec &ob = objs[t.object];
         uint32_t lt = t.src_tri - ob.first_triangle;
         const float *A0 = xv[ob.first_xvert + ob.indices[3 * lt]].attr;
@@ -811,10 +812,10 @@ hipError_t launch_raster_depth(const SetupRec *recs, const RasterRec *rrecs, con
     return hipGetLastError();
 }
 
-hipError_t launch_resolve(const unsigned long long *vis, const SetupRec *recs, const uint32_t *rec_of, const ObjectRec *objs, const XVert *xv,
+hipError_t launch_resolve(const unsigned long long *vis, const SetupRec *recs, const RasterRec *rrecs, const uint32_t *rec_of, const ObjectRec *objs, const XVert *xv,
                           const GeomParams &gp, uint32_t n_tiles, GBuffer g, hipStream_t s) {
     if (n_tiles == 0) return hipSuccess;
-    k_resolve<<<div_up(n_tiles, 4), 256, 0, s>>>(vis, recs, rec_of, objs, xv, gp, n_tiles, g);
+    k_resolve<<<div_up(n_tiles, 4), 256, 0, s>>>(vis, recs, rrecs, rec_of, objs, xv, gp, n_tiles, g);
     return hipGetLastError();
 }
 

@@ -419,7 +419,7 @@ int resolve_gbuffer(ArcticRenderer *r) {
     Range zone("Forward Pass: G-buffer");
     if (!r->have_vis || r->geo_owner != 1)
         return r->fail(ARCTIC_E_STATE, "no G-buffer: the frame was shaded from the visibility plane and a later pass has replaced its records (run arctic_pass_gbuffer)");
-    HIPCHECK(r, launch_resolve(r->d_vis.as<unsigned long long>(), r->d_recs.as<SetupRec>(), r->d_rec_of.as<uint32_t>(), r->tables[0].objs,
+    HIPCHECK(r, launch_resolve(r->d_vis.as<unsigned long long>(), r->d_recs.as<SetupRec>(), r->d_rrecs.as<RasterRec>(), r->d_rec_of.as<uint32_t>(), r->tables[0].objs,
                                r->d_xverts.as<XVert>(), r->tables[0].gp, (uint32_t)r->n_tiles(), r->gbuffer(),
                                r->stream));
     r->have_gbuffer = true;
@@ -438,7 +438,7 @@ int fill_shade_params(ArcticRenderer *r, const ArcticScene *sc, const ArcticSett
     }
     std::memset(&sp, 0, sizeof sp);
     sp.g = r->gbuffer();
-    sp.vis = r->d_vis.as<unsigned long long>(); sp.recs = r->d_recs.as<SetupRec>(); sp.rec_of = r->d_rec_of.as<uint32_t>();
+    sp.vis = r->d_vis.as<unsigned long long>(); sp.recs = r->d_recs.as<SetupRec>(); sp.rrecs = r->d_rrecs.as<RasterRec>(); sp.rec_of = r->d_rec_of.as<uint32_t>();
     sp.objs = r->tables[0].objs; sp.xv = r->d_xverts.as<XVert>();
     sp.tex = r->d_tex.as<TexDesc>();
     sp.n_materials = (uint32_t)(r->tex.size() / 3);

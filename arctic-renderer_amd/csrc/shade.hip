@@ -851,8 +851,9 @@ __global__ __launch_bounds__(256) void k_material_vis(const ShadeParams sp) {
     float B[3] = {0.0f, 0.0f, 0.0f};
     uint32_t v0 = 0, v1 = 0, v2 = 0;   // the source triangle's transformed vertices (indices, not pointers: they stay live across the tile)
     if (key != ~0ull) {
-        const SetupRec &t = sp.recs[sp.rec_of[(uint32_t)key]];   // low word of the key = order id (k_setup)
-        source_barycentrics(t, px, py, B);
+        const uint32_t ri = sp.rec_of[(uint32_t)key];   // low word of the key = order id (k_setup)
+        const SetupRec &t = sp.recs[ri];
+        source_barycentrics(t, sp.rrecs[ri], px, py, B);
         const ObjectRec &ob = sp.objs[t.object];
         const uint32_t lt = t.src_tri - ob.first_triangle;
         v0 = ob.first_xvert + ob.indices[3 * lt]; v1 = ob.first_xvert + ob.indices[3 * lt + 1]; v2 = ob.first_xvert + ob.indices[3 * lt + 2];
