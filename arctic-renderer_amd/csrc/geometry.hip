@@ -479,14 +479,11 @@ typedef int32_t i2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int32_t high_word(double v) { return __builtin_bit_cast(i2v, v).y; }
 typedef char __attribute__((address_space(1))) *gbytes;   // wave-uniform base (SGPR pair) + 32-bit per-lane byte offset: the saddr form, no 64-bit address arithmetic
 
-// the four pixels of a lane in one work item: covered and nearer than the clear value?, where, and the depth bits
-struct LanePixels {
-    bool ok[4];
-    uint32_t at[4], zb[4];
-};
+// the four pixels of a lane in one work item: the depth bits where the pixel is covered and nearer than the clear value, else NONE
+constexpr uint32_t NO_DEPTH = 0xFFFFFFFFu;
 
 template <bool DEPTH_ONLY>
-__device__ __forceinline__ void item_pixels(const RasterRec &t, uint32_t code, uint32_t lane, const RasterFrame &fr, LanePixels &p) {
+__device__ __forceinline__ void item_pixels(const RasterRec &t, uint32_t code, uint32_t lane, const RasterFrame &fr, uint32_t zb[4]) {
     const int32_t ox = (int32_t)(code & 0xFFFu) << 4, oy = (int32_t)((code >> 12) & 0xFFFu) << 4;   // the block's first pixel
     const bool cut = (code & ITEM_SCISSOR) != 0;   // the block is cut by the scissor: test every pixel against it
     const int32_t x0 = ox + (int32_t)(DEPTH_ONLY ? lane & 15u : lane & 7u), y0 = oy + (int32_t)(DEPTH_ONLY ? lane >> 4 : lane >> 3);
@@ -509,21 +506,6 @@ __device__ __forceinline__ void item_pixels(const RasterRec &t, uint32_t code, u
             e[2][i] = __builtin_fma(t.A[i], xd, u1); e[3][i] = __builtin_fma(t.A[i], xd8, u1);
         }
     }
-    // forward pass: the two tile rows of the block in the (possibly sharded) visibility plane -- wave-uniform
-    bool row_ok[2] = {true, true};
-    uint32_t row_at[2] = {0, 0};
-    if (!DEPTH_ONLY) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int ty_rel = ((oy >> 3) + j) - fr.tile_y0;
-            int lrow = ty_rel;
-            if (fr.band_tiles != 0) {   // interleaved shard: rows of other shards are skipped, the own ones are packed
-                row_ok[j] = row_owned(ty_rel, fr.band_tiles, fr.shard_count, fr.shard_index);
-                lrow = row_local(ty_rel, fr.band_tiles, fr.shard_count);
-            }
-            row_at[j] = ((uint32_t)lrow * (uint32_t)fr.tiles_x + (uint32_t)(ox >> 3)) * 64u;
-        }
-    }
     // the scissor test as sign bits, zero for blocks inside the scissor
     int32_t out_x[2] = {0, 0}, out_y[4] = {0, 0, 0, 0};
     if (cut) {
@@ -534,16 +516,39 @@ __device__ __forceinline__ void item_pixels(const RasterRec &t, uint32_t code, u
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int32_t px = DEPTH_ONLY ? x0 : x0 + 8 * (k & 1), py = DEPTH_ONLY ? y0 + 4 * k : y0 + 8 * (k >> 1);
         const int32_t outside = high_word(e[k][0] - t.t0) | high_word(e[k][1]) | high_word(e[k][2] - t.t2)
                               | out_x[DEPTH_ONLY ? 0 : k & 1] | out_y[DEPTH_ONLY ? k : k >> 1];
         const float l1 = (float)e[k][2] * t.inv_area, l2 = (float)e[k][0] * t.inv_area;
         float z = fmaf(l2, t.dz2, fmaf(l1, t.dz1, t.z0));
         z = fminf(fmaxf(z, 0.0f), 1.0f);
-        p.zb[k] = __float_as_uint(z);
-        p.ok[k] = outside >= 0 && z < 1.0f;   // depth LESS against the 1.0 clear
-        if (DEPTH_ONLY) p.at[k] = (uint32_t)py * (uint32_t)fr.pitch + (uint32_t)px;
-        else { p.ok[k] = p.ok[k] && row_ok[k >> 1]; p.at[k] = row_at[k >> 1] + (uint32_t)(k & 1) * 64u + lane; }
+        zb[k] = (outside >= 0 && z < 1.0f) ? __float_as_uint(z) : NO_DEPTH;   // depth LESS against the 1.0 clear
+    }
+}
+
+// where the four pixels of a lane live for block `code`: element index in the visibility plane / the depth map, and whether the
+// (wave-uniform) tile row is this shard's
+template <bool DEPTH_ONLY>
+__device__ __forceinline__ void block_targets(uint32_t code, uint32_t lane, const RasterFrame &fr, uint32_t at[4], bool mine[4]) {
+    const int32_t ox = (int32_t)(code & 0xFFFu) << 4, oy = (int32_t)((code >> 12) & 0xFFFu) << 4;
+    if (DEPTH_ONLY) {
+        const uint32_t x0 = (uint32_t)ox + (lane & 15u), y0 = (uint32_t)oy + (lane >> 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { at[k] = (y0 + 4u * k) * (uint32_t)fr.pitch + x0; mine[k] = true; }
+    } else {
+        bool row_ok[2] = {true, true};
+        uint32_t row_at[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ty_rel = ((oy >> 3) + j) - fr.tile_y0;
+            int lrow = ty_rel;
+            if (fr.band_tiles != 0) {   // interleaved shard: rows of other shards are skipped, the own ones are packed
+                row_ok[j] = row_owned(ty_rel, fr.band_tiles, fr.shard_count, fr.shard_index);
+                lrow = row_local(ty_rel, fr.band_tiles, fr.shard_count);
+            }
+            row_at[j] = ((uint32_t)lrow * (uint32_t)fr.tiles_x + (uint32_t)(ox >> 3)) * 64u;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { at[k] = row_at[k >> 1] + (uint32_t)(k & 1) * 64u + lane; mine[k] = row_ok[k >> 1]; }
     }
 }
 
@@ -601,82 +606,120 @@ __device__ __forceinline__ void raster_item_i64(const SetupRec &t, uint32_t code
     }
 }
 
-// early depth test and depth write of one work item: the four reads are issued together, then the atomics of the pixels that still
-// win.  Byte offsets fit 32 bits (the planes are at most 16384^2 entries of 8 / 4 bytes): wave-uniform base + per-lane offset.
-template <bool DEPTH_ONLY>
-__device__ __forceinline__ void depth_test_and_write(const LanePixels &p, uint32_t order_id, unsigned long long *__restrict__ vis, uint32_t *__restrict__ depth_bits) {
-    if (DEPTH_ONLY) {
-        uint32_t cur[4];
+// ascending bitonic sort of one (key, value) pair per lane across the wave
+__device__ __forceinline__ void wave_sort(uint32_t &key, uint32_t &val, uint32_t lane) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { cur[k] = 0u; if (p.ok[k]) cur[k] = *(const uint32_t __attribute__((address_space(1))) *)((gbytes)depth_bits + p.at[k] * 4u); }
+    for (uint32_t k = 2; k <= 64; k <<= 1)
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (p.ok[k] && p.zb[k] < cur[k])
-                __hip_atomic_fetch_min((uint32_t __attribute__((address_space(1))) *)((gbytes)depth_bits + p.at[k] * 4u), p.zb[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-        unsigned long long cur[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { cur[k] = 0ull; if (p.ok[k]) cur[k] = *(const unsigned long long __attribute__((address_space(1))) *)((gbytes)vis + p.at[k] * 8u); }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const unsigned long long key = ((unsigned long long)p.zb[k] << 32) | order_id;   // ties: first drawn (smallest order id) wins
-            if (p.ok[k] && key < cur[k])
-                __hip_atomic_fetch_min((unsigned long long __attribute__((address_space(1))) *)((gbytes)vis + p.at[k] * 8u), key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            const uint32_t pk = __shfl_xor(key, (int)j), pv = __shfl_xor(val, (int)j);
+            const bool keep_low = ((lane & j) == 0) == ((lane & k) == 0);   // this lane keeps the smaller of the pair
+            const bool take = keep_low ? pk < key : pk > key;
+            if (take) { key = pk; val = pv; }
         }
-    }
 }
 
-// Persistent: the number of work items is only known on the device (counters[1]), so a fixed grid strides over the item
-// table and the host never waits for a count.  Software pipeline, two items deep: while item i is rasterised the record
-// of item i+1 (scalar loads, its index arrived a trip ago) and the table entry of item i+2 are in flight, so a wave pays
-// the entry -> record -> pixels chain of dependent round trips once, not per item.  Two trips per loop iteration: the two
-// record register sets swap roles instead of being copied.
-// What bounds it (tools/experiments/atomic_rates.hip, profiles/): the memory side retires ~25 atomic requests per ns -- a
-// request = the lanes of one instruction that fall into one 64-byte segment, whatever their number, workgroup or agent scope,
-// 32 or 64 bit -- and a 4K frame issues 1.65 M of them (5.8 of 8 pixels per request: triangle edges and 1.15x overdraw): 66 us
-// of the kernel's 84.  Two items per trip, chunked instead of strided item order and dropping the early read change nothing.
-template <bool DEPTH_ONLY>
+// A wave's accumulator for one 16x16 block: the smallest key seen per pixel, four pixels per lane.  Forward pass: key = depth
+// bits << 32 | order id (ties: first drawn wins); shadow pass: the depth bits.
+template <bool DEPTH_ONLY> struct KeyOf { typedef unsigned long long type; };
+template <> struct KeyOf<true> { typedef uint32_t type; };
+
+// Persistent: the number of work items is only known on the device (counters[1]), so a fixed grid strides over the item table
+// and the host never waits for a count.
+// What bounds a rasteriser that sends every covered pixel to memory on its own (tools/experiments/atomic_rates.hip, profiles/):
+// the memory side retires ~25 atomic requests per ns -- a request = the lanes of one instruction that fall into one 64-byte
+// segment, whatever their number, workgroup or agent scope, 32 or 64 bit -- and a 4K frame issued 1.65 M of them (5.8 of 8
+// pixels per request: triangle edges and overdraw): 66 us of 85.  So requests are merged before they leave the wave: a wave takes
+// CHUNK consecutive work items (neighbouring triangles of a mesh), sorts them by block (bitonic sort across the lanes), and walks
+// the runs of equal block with the block's 256 keys in registers (four per lane): an item costs its plane evaluations and a
+// min per pixel, a run costs ONE early depth read and ONE atomicMin per pixel that still wins.  The memory side of a run is
+// split around the next run: reads issued when the run ends, atomics when the next one ends -- the reads' latency, and the wait
+// for the previous atomics that comes with it (loads, stores and atomics retire through one in-order counter), hide behind the
+// next run's arithmetic.
+#ifndef RASTER_CHUNK
+#define RASTER_CHUNK 32
+#endif
+template <bool DEPTH_ONLY, uint32_t CHUNK>
 __global__ __launch_bounds__(256) void k_raster(const SetupRec *__restrict__ recs, const RasterRec *__restrict__ rrecs,
                                                 const uint2 *__restrict__ items, uint32_t item_cap,
                                                 const uint32_t *__restrict__ counters, const GeomParams gp,
                                                 unsigned long long *__restrict__ vis, uint32_t *__restrict__ depth_bits,
                                                 uint32_t *__restrict__ host_counts, uint32_t *__restrict__ host_overflow) {
+    typedef typename KeyOf<DEPTH_ONLY>::type Key;
+    constexpr Key NONE = (Key)~(Key)0;
     // records, work items and the overflow flag for the host (pinned, mapped memory: no copy launches); read after a synchronise
     if (blockIdx.x == 0 && threadIdx.x == 0) { host_counts[0] = counters[0]; host_counts[1] = counters[1]; *host_overflow = counters[2]; }
     if (counters[2]) return;   // a table overflowed in k_setup: entries are missing, the host reports the frame as dropped
     const uint32_t n_items = min(counters[1], item_cap);
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t stride = gridDim.x * 4;
-    uint32_t item = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (item >= n_items) return;
+    const uint32_t wave = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n_waves = gridDim.x * 4;
     const RasterFrame fr = {gp.sc_x0, gp.sc_y0, gp.sc_x1, gp.sc_y1, gp.tiles_x, gp.tile_y0, gp.pitch, gp.band_tiles, gp.shard_index, gp.shard_count};
-    const auto one = [&](const RasterRec &q, uint32_t r, uint32_t code) {
-        if (r == ITEM_SKIP) return;
-        if (q.flags & RASTER_EXACT_F64) {
-            LanePixels p;
-            item_pixels<DEPTH_ONLY>(q, code, lane, fr, p);
-            depth_test_and_write<DEPTH_ONLY>(p, q.order_id, vis, depth_bits);
-        } else raster_item_i64<DEPTH_ONLY>(recs[r], code, lane, fr, vis, depth_bits);
+    // the finished run whose reads are in flight: its keys, where they go, what the target holds
+    bool pending = false;
+    Key pend_key[4] = {NONE, NONE, NONE, NONE}, pend_cur[4] = {0, 0, 0, 0};
+    uint32_t pend_at[4] = {0, 0, 0, 0};
+    const auto write_pending = [&]() {
+        if (!pending) return;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (pend_key[k] != NONE && pend_key[k] < pend_cur[k]) {
+                if (DEPTH_ONLY) __hip_atomic_fetch_min((uint32_t __attribute__((address_space(1))) *)((gbytes)depth_bits + pend_at[k] * 4u), (uint32_t)pend_key[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else __hip_atomic_fetch_min((unsigned long long __attribute__((address_space(1))) *)((gbytes)vis + pend_at[k] * 8u), (unsigned long long)pend_key[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        pending = false;
     };
-    const auto rec_index = [](uint32_t r) { return r == ITEM_SKIP ? 0u : r; };
-    uint2 en = items[item];
-    uint32_t ra = __builtin_amdgcn_readfirstlane(en.x), ca = __builtin_amdgcn_readfirstlane(en.y);
-    RasterRec a = rrecs[rec_index(ra)];
-    en = items[min(item + stride, n_items - 1)];
-    for (;;) {
-        const uint32_t rb = __builtin_amdgcn_readfirstlane(en.x), cb = __builtin_amdgcn_readfirstlane(en.y);
-        const RasterRec b = rrecs[rec_index(rb)];                      // used next trip
-        en = items[min(item + 2 * stride, n_items - 1)];               // used the trip after
-        one(a, ra, ca);
-        item += stride;
-        if (item >= n_items) break;
-        ra = __builtin_amdgcn_readfirstlane(en.x); ca = __builtin_amdgcn_readfirstlane(en.y);
-        a = rrecs[rec_index(ra)];
-        en = items[min(item + 2 * stride, n_items - 1)];
-        one(b, rb, cb);
-        item += stride;
-        if (item >= n_items) break;
+    // byte offsets fit 32 bits (the planes are at most 16384^2 entries of 8 / 4 bytes): wave-uniform base + per-lane offset
+    const auto read_run = [&](const Key acc[4], uint32_t code) {
+        bool mine[4];
+        block_targets<DEPTH_ONLY>(code, lane, fr, pend_at, mine);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            pend_key[k] = mine[k] ? acc[k] : NONE;
+            pend_cur[k] = 0;
+            if (pend_key[k] != NONE) {
+                if (DEPTH_ONLY) pend_cur[k] = (Key) * (const uint32_t __attribute__((address_space(1))) *)((gbytes)depth_bits + pend_at[k] * 4u);
+                else pend_cur[k] = (Key) * (const unsigned long long __attribute__((address_space(1))) *)((gbytes)vis + pend_at[k] * 8u);
+            }
+        }
+        pending = true;
+    };
+    // few items: shorter chunks, so that every resident wave has one (a 512^2 frame is 20 k items for 6 k waves)
+    const uint32_t chunk = min(CHUNK, max(1u, (n_items + n_waves - 1) / n_waves));
+    for (uint32_t first = wave * chunk; first < n_items; first += n_waves * chunk) {   // uniform per wave
+        uint32_t code = 0xFFFFFFFFu, rec = ITEM_SKIP;
+        if (lane < chunk && first + lane < n_items) {
+            const uint2 en = items[first + lane];
+            rec = en.x;
+            if (rec != ITEM_SKIP) code = en.y;
+        }
+        wave_sort(code, rec, lane);   // skipped entries sort to the end
+        const uint32_t n_live = (uint32_t)__popcll(__ballot(rec != ITEM_SKIP));
+        if (n_live == 0) continue;
+        Key acc[4] = {NONE, NONE, NONE, NONE};
+        uint32_t run_code = __builtin_amdgcn_readlane(code, 0);
+        for (uint32_t i = 0; i < n_live; ++i) {
+            const uint32_t c = __builtin_amdgcn_readlane(code, i), r = __builtin_amdgcn_readlane(rec, i);
+            if (c != run_code) {   // the run is complete: write the one before it, start this one's reads
+                write_pending();
+                read_run(acc, run_code);
+                acc[0] = acc[1] = acc[2] = acc[3] = NONE;
+                run_code = c;
+            }
+            const RasterRec q = rrecs[r];   // two scalar loads (prefetching the next item's record bought nothing: 72 -> 74 us)
+            if (q.flags & RASTER_EXACT_F64) {
+                uint32_t zb[4];
+                item_pixels<DEPTH_ONLY>(q, c, lane, fr, zb);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const Key key = DEPTH_ONLY ? (Key)zb[k] : (zb[k] == NO_DEPTH ? NONE : (Key)(((unsigned long long)zb[k] << 32) | q.order_id));
+                    acc[k] = key < acc[k] ? key : acc[k];
+                }
+            } else raster_item_i64<DEPTH_ONLY>(recs[r], c, lane, fr, vis, depth_bits);   // rare: the record's own integer path, straight to memory
+        }
+        write_pending();
+        read_run(acc, run_code);
     }
+    write_pending();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -794,21 +837,21 @@ hipError_t launch_setup(const ObjectRec *objs, const uint32_t *block_obj, const 
 // after the others have finished their share of the items)
 uint32_t raster_grid_blocks(bool depth_only, uint32_t cu_count) {
     int per_cu = 0;
-    const hipError_t e = depth_only ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_raster<true>, 256, 0)
-                                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_raster<false>, 256, 0);
+    const hipError_t e = depth_only ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_raster<true, RASTER_CHUNK>, 256, 0)
+                                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_raster<false, RASTER_CHUNK>, 256, 0);
     if (e != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 4; }
     return cu_count * (uint32_t)per_cu;
 }
 
 hipError_t launch_raster_vis(const SetupRec *recs, const RasterRec *rrecs, const uint2 *items, uint32_t item_cap, const uint32_t *counters, uint32_t grid_blocks,
                              const GeomParams &gp, unsigned long long *vis, uint32_t *host_counts, uint32_t *host_overflow, hipStream_t s) {
-    k_raster<false><<<grid_blocks, 256, 0, s>>>(recs, rrecs, items, item_cap, counters, gp, vis, nullptr, host_counts, host_overflow);
+    k_raster<false, RASTER_CHUNK><<<grid_blocks, 256, 0, s>>>(recs, rrecs, items, item_cap, counters, gp, vis, nullptr, host_counts, host_overflow);
     return hipGetLastError();
 }
 
 hipError_t launch_raster_depth(const SetupRec *recs, const RasterRec *rrecs, const uint2 *items, uint32_t item_cap, const uint32_t *counters, uint32_t grid_blocks,
                                const GeomParams &gp, uint32_t *depth_bits, uint32_t *host_counts, uint32_t *host_overflow, hipStream_t s) {
-    k_raster<true><<<grid_blocks, 256, 0, s>>>(recs, rrecs, items, item_cap, counters, gp, nullptr, depth_bits, host_counts, host_overflow);
+    k_raster<true, RASTER_CHUNK><<<grid_blocks, 256, 0, s>>>(recs, rrecs, items, item_cap, counters, gp, nullptr, depth_bits, host_counts, host_overflow);
     return hipGetLastError();
 }
 
