@@ -161,6 +161,7 @@ struct ShadeParams {
     float ndc_sx, ndc_sy;               // 2/width, 2/height of the whole frame
     int32_t band_tiles, shard_index, shard_count, tile_y0;   // local tile row -> global row (see row_global)
     int32_t hdr16;                      // 1: round ps_main's colour through binary16 like the reference's RGBA16F target
+    int32_t compact_tables;             // 1: the record, vertex and object tables are below 4 GiB each: k_material_vis addresses them with 32-bit byte offsets
     int32_t debug;                      // timing experiments only: 1 skip material textures, 2 skip shadow test
 };
 struct ShadeLaunch {

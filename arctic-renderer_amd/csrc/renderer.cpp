@@ -438,6 +438,8 @@ int fill_shade_params(ArcticRenderer *r, const ArcticScene *sc, const ArcticSett
     }
     std::memset(&sp, 0, sizeof sp);
     sp.g = r->gbuffer();
+    sp.compact_tables = (r->d_recs.cap < (1ull << 32) && r->d_rrecs.cap < (1ull << 32) && r->d_xverts.cap < (1ull << 32) && r->d_rec_of.cap < (1ull << 32) &&
+                         r->tables[0].d.cap < (1ull << 32) && !(r->debug & 64)) ? 1 : 0;
     sp.vis = r->d_vis.as<unsigned long long>(); sp.recs = r->d_recs.as<SetupRec>(); sp.rrecs = r->d_rrecs.as<RasterRec>(); sp.rec_of = r->d_rec_of.as<uint32_t>();
     sp.objs = r->tables[0].objs; sp.xv = r->d_xverts.as<XVert>();
     sp.tex = r->d_tex.as<TexDesc>();

@@ -850,8 +850,54 @@ __global__ __launch_bounds__(256) void k_material_vis(const ShadeParams sp) {
     cur.a = make_float4(0.0f, 0.0f, 0.0f, 0.0f); cur.b0 = 0.0f; cur.b1 = 0.0f; cur.b2 = __uint_as_float(NO_MATERIAL);
     float B[3] = {0.0f, 0.0f, 0.0f};
     uint32_t v0 = 0, v1 = 0, v2 = 0;   // the source triangle's transformed vertices (indices, not pointers: they stay live across the tile)
-    if (key != ~0ull) {
-        const uint32_t ri = sp.rec_of[(uint32_t)key];   // low word of the key = order id (k_setup)
+    // attribute k of transformed vertex v: XVert::attr at byte 16 + 4k of a 96-byte record.  With compact tables (below 4 GiB each, the
+    // host says) every gather is a wave-uniform base + a 32-bit byte offset: no 64-bit multiply-adds per lane and load
+    const bool compact = sp.compact_tables != 0;
+    if (key != ~0ull && compact) {
+        const uint32_t ri = gload_u32(sp.rec_of, (uint32_t)key << 2);   // low word of the key = order id (k_setup)
+        const uint32_t so = ri << 7;                                     // SetupRec and RasterRec are 128 bytes
+        const float4u qf = gload_f4u(sp.rrecs, so + 96u);                // dz2, inv_area, order id, flags
+        const uint2 ids = gload_u2(sp.recs, so + 112u);                  // src_tri, object
+        if (__float_as_uint(qf.w) & RASTER_EXACT_F64) {
+            typedef double d2v __attribute__((ext_vector_type(2)));
+            const auto ld2 = [&](uint32_t o) { return *(const d2v __attribute__((address_space(1))) *)((gchar)sp.rrecs + o); };
+            const auto ld1 = [&](uint32_t o) { return *(const double __attribute__((address_space(1))) *)((gchar)sp.rrecs + o); };
+            const double A0 = ld1(so), C0 = ld1(so + 48u), A2 = ld1(so + 16u), B0 = ld1(so + 24u), B2 = ld1(so + 40u), C2 = ld1(so + 64u);
+            (void)ld2;
+            const float4u s2 = gload_f4u(sp.recs, so + 32u);             // z[2], iw[0..2]
+            const float4u b0 = gload_f4u(sp.recs, so + 48u), b1 = gload_f4u(sp.recs, so + 64u);   // bary[0][0..2], bary[1][0] | bary[1][1..2], bary[2][0..1]
+            const float b22 = __uint_as_float(gload_u32(sp.recs, so + 80u));
+            {   // source_barycentrics (edges.h), on the fields just loaded: the same operations in the same order
+#pragma clang fp contract(off)
+                const double x = (double)px, y = (double)py;
+                const float l1 = (float)__builtin_fma(A2, x, __builtin_fma(B2, y, C2)) * qf.y;
+                const float l2 = (float)__builtin_fma(A0, x, __builtin_fma(B0, y, C0)) * qf.y;
+                const float l0 = (1.0f - l1) - l2;
+                const float pw0 = l0 * s2.y, pw1 = l1 * s2.z, pw2 = l2 * s2.w;
+                const float rr = 1.0f / ((pw0 + pw1) + pw2);
+                const float c0 = pw0 * rr, c1 = pw1 * rr, c2 = pw2 * rr;
+                B[0] = (c0 * b0.x + c1 * b0.w) + c2 * b1.z;
+                B[1] = (c0 * b0.y + c1 * b1.x) + c2 * b1.w;
+                B[2] = (c0 * b0.z + c1 * b1.y) + c2 * b22;
+            }
+        } else source_barycentrics(sp.recs[ri], sp.rrecs[ri], px, py, B);   // rare: coordinates of 2^24 and more
+        const uint32_t oo = ids.y * (uint32_t)sizeof(ObjectRec);
+        const uint2 ip = gload_u2(sp.objs, oo + 72u);                    // ObjectRec::indices
+        const uint2 fx = gload_u2(sp.objs, oo + 88u);                    // first_xvert, first_triangle
+        cur.b2 = __uint_as_float(gload_u32(sp.objs, oo + 96u));          // material
+        const uint32_t *ind = reinterpret_cast<const uint32_t *>(((unsigned long long)ip.y << 32) | ip.x) + 3u * (ids.x - fx.y);
+        v0 = fx.x + ind[0]; v1 = fx.x + ind[1]; v2 = fx.x + ind[2];
+        const uint32_t a0 = v0 * 96u + 16u, a1 = v1 * 96u + 16u, a2 = v2 * 96u + 16u;
+        const float2 u0 = gload_f2(sp.xv, a0), u1 = gload_f2(sp.xv, a1), u2 = gload_f2(sp.xv, a2);                    // attr 0, 1
+        const float4u w0 = gload_f4u(sp.xv, a0 + 56u), w1 = gload_f4u(sp.xv, a1 + 56u), w2 = gload_f4u(sp.xv, a2 + 56u);   // attr 14..17
+        const auto mix = [&](float x0, float x1, float x2) {
+#pragma clang fp contract(off)
+            return (B[0] * x0 + B[1] * x1) + B[2] * x2;   // interpolate_attr (edges.h)
+        };
+        cur.a = make_float4(mix(u0.x, u1.x, u2.x), mix(u0.y, u1.y, u2.y), mix(w0.x, w1.x, w2.x), mix(w0.y, w1.y, w2.y));
+        cur.b0 = mix(w0.z, w1.z, w2.z); cur.b1 = mix(w0.w, w1.w, w2.w);
+    } else if (key != ~0ull) {
+        const uint32_t ri = sp.rec_of[(uint32_t)key];
         const SetupRec &t = sp.recs[ri];
         source_barycentrics(t, sp.rrecs[ri], px, py, B);
         const ObjectRec &ob = sp.objs[t.object];
@@ -865,10 +911,24 @@ __global__ __launch_bounds__(256) void k_material_vis(const ShadeParams sp) {
     }
     shade_tile<LOOP, STATS, LDS_SHADOW>(sp, lut, shadow_tiles[LDS_SHADOW ? wave : 0], ty, tx, lane, cur, [&](float4 &gc, float4 &gd, float4 &ge) {
         // attribute order (XVert::attr): uv 0-1, t 2-4, b 5-7, n 8-10, world 11-13, light space 14-17; planes as gbuffer_pack
-        const float *A0 = sp.xv[v0].attr, *A1 = sp.xv[v1].attr, *A2 = sp.xv[v2].attr;
-        gc = make_float4(interpolate_attr(B, A0, A1, A2, 11), interpolate_attr(B, A0, A1, A2, 12), interpolate_attr(B, A0, A1, A2, 13), interpolate_attr(B, A0, A1, A2, 2));
-        gd = make_float4(interpolate_attr(B, A0, A1, A2, 3), interpolate_attr(B, A0, A1, A2, 4), interpolate_attr(B, A0, A1, A2, 5), interpolate_attr(B, A0, A1, A2, 6));
-        ge = make_float4(interpolate_attr(B, A0, A1, A2, 7), interpolate_attr(B, A0, A1, A2, 8), interpolate_attr(B, A0, A1, A2, 9), interpolate_attr(B, A0, A1, A2, 10));
+        const auto mix = [&](float x0, float x1, float x2) {
+#pragma clang fp contract(off)
+            return (B[0] * x0 + B[1] * x1) + B[2] * x2;
+        };
+        if (compact) {
+            const uint32_t a0 = v0 * 96u + 24u, a1 = v1 * 96u + 24u, a2 = v2 * 96u + 24u;   // attr 2..13: three float4 per vertex
+            const float4u p0 = gload_f4u(sp.xv, a0), p1 = gload_f4u(sp.xv, a1), p2 = gload_f4u(sp.xv, a2);                     // attr 2..5
+            const float4u q0 = gload_f4u(sp.xv, a0 + 16u), q1 = gload_f4u(sp.xv, a1 + 16u), q2 = gload_f4u(sp.xv, a2 + 16u);   // attr 6..9
+            const float4u r0 = gload_f4u(sp.xv, a0 + 32u), r1 = gload_f4u(sp.xv, a1 + 32u), r2 = gload_f4u(sp.xv, a2 + 32u);   // attr 10..13
+            gc = make_float4(mix(r0.y, r1.y, r2.y), mix(r0.z, r1.z, r2.z), mix(r0.w, r1.w, r2.w), mix(p0.x, p1.x, p2.x));
+            gd = make_float4(mix(p0.y, p1.y, p2.y), mix(p0.z, p1.z, p2.z), mix(p0.w, p1.w, p2.w), mix(q0.x, q1.x, q2.x));
+            ge = make_float4(mix(q0.y, q1.y, q2.y), mix(q0.z, q1.z, q2.z), mix(q0.w, q1.w, q2.w), mix(r0.x, r1.x, r2.x));
+        } else {
+            const float *A0 = sp.xv[v0].attr, *A1 = sp.xv[v1].attr, *A2 = sp.xv[v2].attr;
+            gc = make_float4(interpolate_attr(B, A0, A1, A2, 11), interpolate_attr(B, A0, A1, A2, 12), interpolate_attr(B, A0, A1, A2, 13), interpolate_attr(B, A0, A1, A2, 2));
+            gd = make_float4(interpolate_attr(B, A0, A1, A2, 3), interpolate_attr(B, A0, A1, A2, 4), interpolate_attr(B, A0, A1, A2, 5), interpolate_attr(B, A0, A1, A2, 6));
+            ge = make_float4(interpolate_attr(B, A0, A1, A2, 7), interpolate_attr(B, A0, A1, A2, 8), interpolate_attr(B, A0, A1, A2, 9), interpolate_attr(B, A0, A1, A2, 10));
+        }
     });
 }
 

@@ -139,6 +139,13 @@ def test_frame_from_visibility_plane_equals_frame_through_gbuffer(pair):
         np.testing.assert_array_equal(x.view(np.uint32), y.view(np.uint32))
     r.pass_shade(sc.desc, sc.settings)          # and the G-buffer API keeps working after such a frame
     np.testing.assert_array_equal(r.read_output()[0].view(np.uint32), a_ldr.view(np.uint32))
+    r.set_option("debug", 64)                   # the same frame with 64-bit pointer gathers (the path of tables of 4 GiB and more)
+    try:
+        c = r.render_frame(sc.desc, sc.settings)
+        np.testing.assert_array_equal(c, b)
+        np.testing.assert_array_equal(r.read_output()[0].view(np.uint32), a_ldr.view(np.uint32))
+    finally:
+        r.set_option("debug", 0)
 
 
 def test_light_paths_agree(pair, pkg):
