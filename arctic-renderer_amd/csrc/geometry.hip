@@ -8,16 +8,18 @@
 // shadow_map_pass.cpp:96-97) and perspective-correct interpolation of the 18
 // VSOut floats -- written out as the G-buffer instead of feeding a pixel shader.
 //
-// MI355X design: one launch per stage over ALL objects (no per-draw loop), no host read-back anywhere;
-//   vertex  : 1 thread / vertex                         -> XVert[]            (coalesced 96 B records)
-//   setup   : 1 thread / triangle: clip, set up, take record and work-item slots from device counters (one atomicAdd per
-//             workgroup and counter) -> SetupRec[] in arbitrary order + explicit work items (record, 16x16 block)
-//   raster  : persistent; 1 wavefront / work item, a 2x2 quad per lane, 64-bit atomicMin of
-//             (depth bits << 32 | order id) into a tile-major visibility plane: order-independent, so no sorting and
+// MI355X design: one launch per stage over ALL objects (no per-draw loop), no host read-back, no copies between the stages;
+//   vertex  : 1 thread / vertex -> XVert[] (coalesced 96 B records); the launch also clears the pass's target and the counters
+//   setup   : 1 thread / triangle inside all clip planes: set up, take record and work-item slots from one device counter (one
+//             64-bit atomicAdd per workgroup) -> SetupRec[] + RasterRec[] in arbitrary order + explicit work items
+//             (record, 16x16 block), only blocks an edge function can reach; triangles a plane cuts -> clip list
+//   clipped : the clip list, a lane per triangle: Sutherland-Hodgman in LDS, then the same set-up per fan triangle
+//   raster  : persistent; edge functions as exact binary64 planes of the record, four pixels per lane; a wave sorts a chunk of
+//             work items by block and merges each run in registers before ONE early read + atomicMin per pixel and run of
+//             (depth bits << 32 | order id) into a tile-major visibility plane: order-independent, so no global sorting and
 //             no per-pixel locks; order id = 8 * source triangle + sub-triangle keeps "first drawn wins" deterministic
-//   resolve : 1 lane / pixel: fetch the winner, re-derive its barycentrics from the same integer
-//             edge functions, interpolate, write the tile-major G-buffer planes (1 KiB / wave-store)
-//             (whole frames skip it: shade.hip's k_material_vis interpolates in place)
+//   resolve : 1 lane / pixel: fetch the winner, re-derive its barycentrics from the same planes, interpolate, write the
+//             tile-major G-buffer planes (1 KiB / wave-store) (whole frames skip it: shade.hip's k_material_vis interpolates in place)
 // The shadow map uses the same stages with a 32-bit atomicMin on the depth bits.
 //
 // This translation unit is compiled with -ffp-contract=off: coverage is integer and every fp32
