@@ -250,15 +250,15 @@ __global__ __launch_bounds__(256) void k_vertex(const ObjectRec *__restrict__ ob
 }
 
 // ---------------------------------------------------------------------------------------------
-// clip + setup + work-item expansion in ONE launch, one thread per source triangle.
-// Record slots and work-item slots are taken from two device counters with one wave-aggregated atomicAdd each, so
+// set-up + work-item expansion, one thread per source triangle (k_setup; cut triangles: k_setup_clipped).
+// Record slots and work-item slots are taken from one 64-bit device counter with one atomicAdd per workgroup, so
 // there is no count pass, no prefix scan and nothing for the host to wait for.  Records therefore land in arbitrary
 // order; what must stay deterministic -- "first drawn wins" on equal depth -- travels in the record instead:
 // order_id = 8 * (draw-order index of the source triangle) + (index of the sub-triangle the clipper produced), which is
 // the low word of the visibility key.  rec_of[order_id] finds the record again in k_resolve.
-// A work item is one (record, 16x16-pixel block) pair, stored explicitly: items[i] = {record, block index in the
-// record's bounding box}.
-// counters: [0] records, [1] work items, [2] set when the item table overflowed (the frame is then incomplete).
+// A work item is one (record, 16x16-pixel block) pair, stored explicitly: items[i] = {record, block coordinates + flags}
+// (ITEM_SCISSOR, ITEM_SKIP: common.h).
+// counters: [0] records, [1] work items, [2] set when a table overflowed (the frame is then incomplete), [3] clip-list entries.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v, uint32_t lane) {
 #pragma unroll
