@@ -67,15 +67,16 @@ __device__ __forceinline__ CV clip_lerp(const CV &in, const CV &out, float din, 
 
 // Sutherland-Hodgman against near, far and the four guard-band planes.  The polygons (up to MAX_POLY vertices, two buffers that
 // change roles per plane) live in LDS, one column per lane: indexed private arrays would be scratch memory, ten times the latency.
+constexpr uint32_t CLIP_LANES = 16;   // triangles per wave of k_setup_clipped: their large records are written one after the other by the whole wave
 struct PolyStore {
-    float v[2][MAX_POLY][7][64];
+    float v[2][MAX_POLY][7][CLIP_LANES];
     __device__ __forceinline__ CV get(int buf, int i, uint32_t lane) const {
-        CV r; const float(*p)[64] = v[buf][i];
+        CV r; const float(*p)[CLIP_LANES] = v[buf][i];
         r.x = p[0][lane]; r.y = p[1][lane]; r.z = p[2][lane]; r.w = p[3][lane]; r.b0 = p[4][lane]; r.b1 = p[5][lane]; r.b2 = p[6][lane];
         return r;
     }
     __device__ __forceinline__ void put(int buf, int i, uint32_t lane, const CV &c) {
-        float(*p)[64] = v[buf][i];
+        float(*p)[CLIP_LANES] = v[buf][i];
         p[0][lane] = c.x; p[1][lane] = c.y; p[2][lane] = c.z; p[3][lane] = c.w; p[4][lane] = c.b0; p[5][lane] = c.b1; p[6][lane] = c.b2;
     }
 };
@@ -413,17 +414,17 @@ __global__ __launch_bounds__(SETUP_THREADS) void k_setup(const ObjectRec *__rest
     place_triangle(has, t, e, rbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), ibase + iincl - e.nb, ob.first_triangle + ti, oi, 0u, gp, T);
 }
 
-// The triangles of the clip list, one wave per workgroup, a lane per triangle: Sutherland-Hodgman in LDS, then the fan over the
+// The triangles of the clip list, one wave per workgroup, a lane per triangle (CLIP_LANES of them): Sutherland-Hodgman in LDS, then the fan over the
 // polygon twice -- once to count records and work items (one atomic per wave for all of them), once to write them.
 __global__ __launch_bounds__(64) void k_setup_clipped(const ObjectRec *__restrict__ objs, const GeomParams gp, const XVert *__restrict__ xv,
                                                       SetupTables T, const uint2 *__restrict__ clip_list) {
     __shared__ PolyStore P;
     const uint32_t count = T.counters[3], lane = threadIdx.x;
-    for (uint32_t first = blockIdx.x * 64; first < count; first += gridDim.x * 64) {   // uniform per wave
+    for (uint32_t first = blockIdx.x * CLIP_LANES; first < count; first += gridDim.x * CLIP_LANES) {   // uniform per wave
         const uint32_t entry_at = first + lane;
         int n = 0, buf = 0;   // vertices of the clipped polygon (0: no triangle in this lane) and where it is
         uint32_t oi = 0, src = 0;
-        if (entry_at < count) {
+        if (lane < CLIP_LANES && entry_at < count) {
             const uint2 entry = clip_list[entry_at];
             oi = entry.x;
             const ObjectRec &ob = objs[oi];
@@ -831,7 +832,7 @@ hipError_t launch_setup(const ObjectRec *objs, const uint32_t *block_obj, const 
     const SetupTables T = {recs, rrecs, rec_of, items, item_cap, rec_cap, counters};
     k_setup<<<n_blocks, SETUP_THREADS, 0, s>>>(objs, block_obj, block_first, gp, xv, T, clip_list);
     // the clip list's length stays on the device: a fixed small grid strides over it (empty in most frames of most scenes)
-    k_setup_clipped<<<std::min<uint32_t>(n_blocks * (SETUP_THREADS / 64), 512u), 64, 0, s>>>(objs, gp, xv, T, clip_list);
+    k_setup_clipped<<<std::min<uint32_t>(n_blocks * (SETUP_THREADS / CLIP_LANES), 256u), 64, 0, s>>>(objs, gp, xv, T, clip_list);
     return hipGetLastError();
 }
 
