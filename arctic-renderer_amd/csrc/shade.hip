@@ -127,9 +127,17 @@ __device__ __forceinline__ void fetch_taps(const TexS &d, float u, float v, Taps
 // byte k of a word as float: v_cvt_f32_ubyteK, one instruction
 template <int K> __device__ __forceinline__ float ubyte(uint32_t w) { return (float)((w >> (8 * K)) & 0xFFu); }
 // UNORM8 channel (byte K of word W of the texel: 0 = .x, 1 = .y), bilinear, scaled to [0,1]
-template <int W, int K> __device__ __forceinline__ float filt_unorm(const Taps &t) {
+template <int W, int K> __device__ __forceinline__ float filt_bytes(const Taps &t) {   // the filtered channel on the 0..255 scale
     const uint32_t a = W ? t.q00.y : t.q00.x, b = W ? t.q10.y : t.q10.x, c = W ? t.q01.y : t.q01.x, d = W ? t.q11.y : t.q11.x;
-    return fm(t.w11, ubyte<K>(d), fm(t.w01, ubyte<K>(c), fm(t.w10, ubyte<K>(b), t.w00 * ubyte<K>(a)))) * (1.0f / 255.0f);
+    return fm(t.w11, ubyte<K>(d), fm(t.w01, ubyte<K>(c), fm(t.w10, ubyte<K>(b), t.w00 * ubyte<K>(a))));
+}
+template <int W, int K> __device__ __forceinline__ float filt_unorm(const Taps &t) { return filt_bytes<W, K>(t) * (1.0f / 255.0f); }
+// 2 s / 255 - 1 for a normal-map channel s on the 0..255 scale, with 2/255 carried as two floats: the fp32 constant alone is 5.9e-8
+// too large, a bias that tilts every normal by ~1e-7 towards its tangent-space offset -- nothing, except where n.wo is 1e-6 itself
+// (grazing views: the specular term there is proportional to n.wo; measured +0.6 % of a pixel's radiance against the oracle)
+__device__ __forceinline__ float snorm_of_bytes(float s) {
+    constexpr float HI = 0x1.010102p-7f, LO = -0x1.fdfdfep-32f;   // HI + LO = 2/255 to 2^-56
+    return fm(s, LO, fm(s, HI, -1.0f));
 }
 // sRGB8 channel (byte K of word 0), decoded per texel BEFORE filtering through the 256-entry LDS table
 template <int K> __device__ __forceinline__ float filt_srgb(const Taps &t, const float *lut) {
@@ -680,7 +688,7 @@ __device__ __forceinline__ void shade_tile(const ShadeParams &sp, const float *l
     if (live) {
         float nr, ng, nb, rough, metal;
         if (!plain) {
-            nr = filt_unorm<0, 3>(pt); ng = filt_unorm<1, 0>(pt); nb = filt_unorm<1, 1>(pt);
+            nr = filt_bytes<0, 3>(pt); ng = filt_bytes<1, 0>(pt); nb = filt_bytes<1, 1>(pt);
             rough = filt_unorm<1, 2>(pt); metal = filt_unorm<1, 3>(pt);   // metal-rough .g, .b (forward.hlsl:117,123)
         }
         if (__ballot(plain) != 0ull) {   // cold: normal and metal-rough images of the plain materials, one material at a time
@@ -693,14 +701,14 @@ __device__ __forceinline__ void shade_tile(const ShadeParams &sp, const float *l
                     Taps t1, t2;
                     fetch_taps<4>(d1, u, v, t1);
                     fetch_taps<4>(d2, u, v, t2);
-                    nr = filt_unorm<0, 0>(t1); ng = filt_unorm<0, 1>(t1); nb = filt_unorm<0, 2>(t1);
+                    nr = filt_bytes<0, 0>(t1); ng = filt_bytes<0, 1>(t1); nb = filt_bytes<0, 2>(t1);
                     rough = filt_unorm<0, 1>(t2); metal = filt_unorm<0, 2>(t2);
                 }
                 todo &= ~__ballot(mine);
             }
         }
         // get_normal :104-111: rgb with g -> 1 - g, * 2 - 1, then mul(tbn, v), tbn columns t, b, n
-        const float r = fm(nr, 2.0f, -1.0f), g = fm(ng, -2.0f, 1.0f), b = fm(nb, 2.0f, -1.0f);   // (1 - g) * 2 - 1 = 1 - 2 g
+        const float r = snorm_of_bytes(nr), g = -snorm_of_bytes(ng), b = snorm_of_bytes(nb);   // (1 - g) * 2 - 1 = -(2 g - 1); nr, ng, nb on the 0..255 scale
         const f3 n = normalize(mk(fm(ge.y, b, fm(gd.z, g, gc.w * r)), fm(ge.z, b, fm(gd.w, g, gd.x * r)), fm(ge.w, b, fm(ge.x, g, gd.y * r))));
         const f3 world = mk(gc.x, gc.y, gc.z);
         const f3 wo = normalize(mk(sp.eye[0], sp.eye[1], sp.eye[2]) - world);

@@ -4,7 +4,8 @@ where the reference formula itself is ill-conditioned in fp32 (tests/test_oracle
 n.wo ~ 1e-6, low-roughness highlights): a pixel whose LITERAL fp32 evaluation (oracle precision 32) is itself more than
 5e-5 away from the float64 value, or whose float64 value moves by more than 2.5e-5 when tangent frame and world position
 move by one fp32 ulp, is reported and must stay within 4x the larger of those two distances instead.
-usage: python tools/fuzz_parity.py [n_cases] [seed]"""
+usage: python tools/fuzz_parity.py [n_cases] [seed] [only] [size_factor]   (size_factor 8: frames of 2-3 Mpx, where the rasteriser
+merges chunks of 32 work items per wave; the default small frames give every wave a single item)"""
 import copy, sys, time
 import numpy as np
 import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..' if os.path.basename(os.path.dirname(os.path.abspath(__file__))) == 'tools' else os.path.join('..', '..')))
@@ -13,6 +14,7 @@ pkg = e.load_package()
 from oracle import oracle as O
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+size_factor = float(sys.argv[4]) if len(sys.argv) > 4 else 1.0
 only = int(sys.argv[3]) if len(sys.argv) > 3 else -1   # run just this case (the random stream is advanced identically) and dump its worst pixel
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
 threads = O.hardware_threads()
@@ -20,7 +22,7 @@ worst = dict(ldr=0.0, rgba=0.0)
 bad = 0
 for case in range(n_cases):
     cfg = int(rng.choice([2, 3, 3, 4]))
-    scale = {2: 0.2, 3: 0.08, 4: 0.06}[cfg]
+    scale = min(1.0, {2: 0.2, 3: 0.08, 4: 0.06}[cfg] * size_factor)
     sc = pkg.scenes.CONFIGS[cfg](scale=scale)
     desc = copy.deepcopy(sc.desc)
     if cfg == 2:
