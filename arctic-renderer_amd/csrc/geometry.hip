@@ -223,13 +223,23 @@ __global__ __launch_bounds__(256) void k_vertex(const ObjectRec *__restrict__ ob
                                                 XVert *__restrict__ xv, int clip_only, uint32_t *__restrict__ counters,
                                                 unsigned long long *__restrict__ clear, unsigned long long clear_value, size_t clear_count) {
     if (blockIdx.x == 0 && threadIdx.x < 4) counters[threadIdx.x] = 0;   // k_setup's slot counters and overflow flag (no memset launch)
-    // the pass's target is cleared here, a slice per workgroup: 66 MB of stores (bandwidth) under the vertex fetches (latency)
-    // instead of a launch of their own in front of them
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < clear_count; i += (size_t)gridDim.x * 256) clear[i] = clear_value;
     const ObjectRec &ob = objs[block_obj[blockIdx.x]];
     uint32_t vi = block_first[blockIdx.x] + threadIdx.x;
-    if (vi >= ob.n_vertices) return;
-    const float *src = ob.vertices + (size_t)vi * 14;
+    const bool live = vi < ob.n_vertices;
+    float src[14];
+    if (live) {
+        const float *p = ob.vertices + (size_t)vi * 14;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) src[k] = p[k];
+        if (!clip_only) {
+#pragma unroll
+            for (int k = 3; k < 14; ++k) src[k] = p[k];
+        }
+    }
+    // the pass's target is cleared here, a slice per workgroup: 66 MB of stores (bandwidth) behind the vertex fetches just issued
+    // (latency), instead of a launch of their own in front of them
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < clear_count; i += (size_t)gridDim.x * 256) clear[i] = clear_value;
+    if (!live) return;
     float world[4];
     mat_vec(ob.trs, src[0], src[1], src[2], 1.0f, world);
     XVert &o = xv[ob.first_xvert + vi];
