@@ -302,30 +302,49 @@ __device__ __forceinline__ bool inside_all_planes(const CV &v) {
 }
 
 // what a set-up triangle will put into the tables: its RasterRec and its work items.  Blocks of the bounding box no edge function
-// reaches are not emitted: as a bit mask for records of up to 16 blocks (nearly all), at emission for larger ones -- their slots
+// reaches are not emitted: as a bit mask for records of up to 64 blocks (nearly all), at emission for larger ones -- their slots
 // are taken before the wave looks at them, so those become ITEM_SKIP
+typedef int32_t i2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int32_t high_word(double v) { return __builtin_bit_cast(i2v, v).y; }   // sign and exponent: negative <=> the word is
+
+// records of up to LANE_BLOCKS blocks are expanded by their own lane (a 64-bit mask of reachable blocks); larger ones by the whole wave,
+// one record after the other -- with the limit at 16 a wave of 64 mid-sized triangles (a wall at 5 m: 7 x 7 blocks each) spent 20 us there
+constexpr uint32_t LANE_BLOCKS = 64;
 struct EmitPlan {
     RasterRec q;
     int32_t bx0, by0;
-    uint32_t nbx, nbb /*blocks of the bounding box*/, mask, nb /*item slots*/;
+    uint32_t nbx, nbb /*blocks of the bounding box*/, nb /*item slots*/;
+    unsigned long long mask;   // reachable blocks of a record of up to 64
 };
 __device__ __forceinline__ void plan_triangle(bool has, const SetupRec &t, const GeomParams &gp, EmitPlan &e) {
     e.q = RasterRec{};
-    e.bx0 = e.by0 = 0; e.nbx = 1; e.nbb = e.mask = e.nb = 0;
+    e.bx0 = e.by0 = 0; e.nbx = 1; e.nbb = e.nb = 0; e.mask = 0ull;
     if (!has) return;
     make_raster_rec(t, (gp.raster_flags & 1) != 0, e.q);
     e.bx0 = t.px0 >> 4; e.by0 = t.py0 >> 4;
     e.nbx = (uint32_t)((t.px1 >> 4) - e.bx0 + 1);
     e.nbb = tiles_of(t);
     e.nb = e.nbb;
-    if (e.nbb <= 16 && (e.q.flags & RASTER_EXACT_F64)) {
-        uint32_t x = 0, y = 0;
-        for (uint32_t j = 0; j < e.nbb; ++j) {
-            if (block_reachable(e.q, e.bx0 + (int32_t)x, e.by0 + (int32_t)y)) e.mask |= 1u << j;
-            if (++x == e.nbx) { x = 0; ++y; }
+    if (e.nbb <= LANE_BLOCKS && (e.q.flags & RASTER_EXACT_F64)) {
+        // block_reachable for every block of the bounding box, incrementally: per edge the value at the first block's best corner,
+        // then + 16 A per block to the right, + 16 B per block down (exact: integers below 2^53); reachable <=> no negative value
+        const RasterRec &q = e.q;
+        double row[3], sx[3], sy[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double x = (double)(e.bx0 * 16) + (q.A[i] > 0.0 ? 15.0 : 0.0), y = (double)(e.by0 * 16) + (q.B[i] > 0.0 ? 15.0 : 0.0);
+            row[i] = __builtin_fma(q.A[i], x, __builtin_fma(q.B[i], y, q.C[i])) - (i == 0 ? q.t0 : (i == 2 ? q.t2 : 0.0));
+            sx[i] = 16.0 * q.A[i]; sy[i] = 16.0 * q.B[i];
         }
-        e.nb = (uint32_t)__popc(e.mask);
-    } else if (e.nbb <= 16) e.mask = (1u << e.nbb) - 1u;
+        double v[3] = {row[0], row[1], row[2]};
+        uint32_t x = 0;
+        for (uint32_t j = 0; j < e.nbb; ++j) {
+            if ((high_word(v[0]) | high_word(v[1]) | high_word(v[2])) >= 0) e.mask |= 1ull << j;
+            if (++x == e.nbx) { x = 0; row[0] += sy[0]; row[1] += sy[1]; row[2] += sy[2]; v[0] = row[0]; v[1] = row[1]; v[2] = row[2]; }
+            else { v[0] += sx[0]; v[1] += sx[1]; v[2] += sx[2]; }
+        }
+        e.nb = (uint32_t)__popcll(e.mask);
+    } else if (e.nbb <= LANE_BLOCKS) e.mask = e.nbb == 64 ? ~0ull : (1ull << e.nbb) - 1ull;
 }
 // record slot r and item slots [ibase, ibase + e.nb) are this lane's: write them.  Called by whole waves (large records are
 // written by all lanes together).
@@ -344,14 +363,14 @@ __device__ __forceinline__ void place_triangle(bool has, SetupRec &t, EmitPlan &
     };
     // small records: the lane writes its own items; large ones (a wall across the screen is thousands of blocks): the
     // whole wave writes them, 64 per step
-    if (e.nbb <= 16 && e.nb != 0) {
+    if (e.nbb <= LANE_BLOCKS && e.nb != 0) {
         uint32_t x = 0, y = 0, at = ibase;
         for (uint32_t j = 0; j < e.nbb; ++j) {
-            if ((e.mask >> j) & 1u) { if (at < T.item_cap) T.items[at] = make_uint2(r, block_code(e.bx0 + (int32_t)x, e.by0 + (int32_t)y)); ++at; }
+            if ((e.mask >> j) & 1ull) { if (at < T.item_cap) T.items[at] = make_uint2(r, block_code(e.bx0 + (int32_t)x, e.by0 + (int32_t)y)); ++at; }
             if (++x == e.nbx) { x = 0; ++y; }
         }
     }
-    for (unsigned long long big = __ballot(e.nbb > 16); big != 0ull; big &= big - 1ull) {
+    for (unsigned long long big = __ballot(e.nbb > LANE_BLOCKS); big != 0ull; big &= big - 1ull) {
         const int L = __ffsll((long long)big) - 1;
         const uint32_t R = __shfl(r, L), NB = __shfl(e.nbb, L), IB = __shfl(ibase, L), NX = __shfl(e.nbx, L);
         const int32_t X0 = __shfl(e.bx0, L), Y0 = __shfl(e.by0, L);
@@ -488,8 +507,6 @@ struct RasterFrame {
 // load / atomic), the shadow pass as four 16x4 strips of the row-major map (four 64-byte rows).  Covered <=> no sign bit among the
 // three thresholded edge values (one v_or3 on the high words); the depth is edges.h's / the oracle's expression on the same exact
 // numerators.
-typedef int32_t i2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ int32_t high_word(double v) { return __builtin_bit_cast(i2v, v).y; }
 typedef char __attribute__((address_space(1))) *gbytes;   // wave-uniform base (SGPR pair) + 32-bit per-lane byte offset: the saddr form, no 64-bit address arithmetic
 
 // the four pixels of a lane in one work item: the depth bits where the pixel is covered and nearer than the clear value, else NONE
