@@ -67,7 +67,7 @@ __device__ __forceinline__ CV clip_lerp(const CV &in, const CV &out, float din, 
 
 // Sutherland-Hodgman against near, far and the four guard-band planes.  The polygons (up to MAX_POLY vertices, two buffers that
 // change roles per plane) live in LDS, one column per lane: indexed private arrays would be scratch memory, ten times the latency.
-constexpr uint32_t CLIP_LANES = 16;   // triangles per wave of k_setup_clipped: their large records are written one after the other by the whole wave
+constexpr uint32_t CLIP_LANES = 8;   // triangles per wave of k_setup_clipped: their large records are written one after the other by the whole wave
 struct PolyStore {
     float v[2][MAX_POLY][7][CLIP_LANES];
     __device__ __forceinline__ CV get(int buf, int i, uint32_t lane) const {
@@ -443,51 +443,55 @@ __global__ __launch_bounds__(SETUP_THREADS) void k_setup(const ObjectRec *__rest
     place_triangle(has, t, e, rbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), ibase + iincl - e.nb, ob.first_triangle + ti, oi, 0u, gp, T);
 }
 
-// The triangles of the clip list, one wave per workgroup, a lane per triangle (CLIP_LANES of them): Sutherland-Hodgman in LDS, then the fan over the
-// polygon twice -- once to count records and work items (one atomic per wave for all of them), once to write them.
+// The triangles of the clip list, one wave per workgroup.  First a lane per triangle (CLIP_LANES of them): Sutherland-Hodgman in
+// LDS.  Then a lane per FAN triangle -- 7 lanes per polygon (6 planes cut a triangle into at most 7), 8 polygons per round --, so
+// set-up, planning, one slot atomic and the writes happen once per round instead of once (twice: count, then write) per fan index.
 __global__ __launch_bounds__(64) void k_setup_clipped(const ObjectRec *__restrict__ objs, const GeomParams gp, const XVert *__restrict__ xv,
                                                       SetupTables T, const uint2 *__restrict__ clip_list) {
     __shared__ PolyStore P;
+    __shared__ int s_n[CLIP_LANES], s_buf[CLIP_LANES];
+    __shared__ uint32_t s_obj[CLIP_LANES], s_src[CLIP_LANES];
     const uint32_t count = T.counters[3], lane = threadIdx.x;
     for (uint32_t first = blockIdx.x * CLIP_LANES; first < count; first += gridDim.x * CLIP_LANES) {   // uniform per wave
-        const uint32_t entry_at = first + lane;
-        int n = 0, buf = 0;   // vertices of the clipped polygon (0: no triangle in this lane) and where it is
-        uint32_t oi = 0, src = 0;
-        if (lane < CLIP_LANES && entry_at < count) {
-            const uint2 entry = clip_list[entry_at];
-            oi = entry.x;
-            const ObjectRec &ob = objs[oi];
-            src = ob.first_triangle + entry.y;
-            CV a, b, c;
-            if (load_triangle(ob, entry.y, xv, a, b, c)) {
-                P.put(0, 0, lane, a); P.put(0, 1, lane, b); P.put(0, 2, lane, c);
-                n = clip_polygon(P, lane, buf);
+        if (lane < CLIP_LANES) {
+            int n = 0, buf = 0;   // vertices of the clipped polygon (0: none) and the buffer that holds it
+            uint32_t oi = 0, src = 0;
+            if (first + lane < count) {
+                const uint2 entry = clip_list[first + lane];
+                oi = entry.x;
+                const ObjectRec &ob = objs[oi];
+                src = ob.first_triangle + entry.y;
+                CV a, b, c;
+                if (load_triangle(ob, entry.y, xv, a, b, c)) {
+                    P.put(0, 0, lane, a); P.put(0, 1, lane, b); P.put(0, 2, lane, c);
+                    n = clip_polygon(P, lane, buf);
+                }
             }
+            s_n[lane] = n; s_buf[lane] = buf; s_obj[lane] = oi; s_src[lane] = src;
         }
-        const int n_max = __reduce_max_sync(~0ull, n);
-        uint32_t nr = 0, ni = 0;
-        for (int f = 1; f + 1 < n_max; ++f) {
+        __syncthreads();   // one wave: orders the LDS writes above before the reads below
+        for (uint32_t round = 0; round < CLIP_LANES / 8; ++round) {
+            const uint32_t p = round * 8 + lane / 7;   // lanes 56..63 idle
+            const int f = (int)(lane % 7) + 1;
             SetupRec t;
+            bool has = false;
+            if (lane < 56 && f + 1 < s_n[p]) {
+                const int buf = s_buf[p];
+                has = setup_triangle(P.get(buf, 0, p), P.get(buf, f, p), P.get(buf, f + 1, p), gp, t);
+            }
             EmitPlan e;
-            const bool has = (f + 1 < n) && setup_triangle(P.get(buf, 0, lane), P.get(buf, f, lane), P.get(buf, f + 1, lane), gp, t);
             plan_triangle(has, t, gp, e);
-            nr += has ? 1u : 0u; ni += e.nb;
+            const unsigned long long m = __ballot(has);
+            const uint32_t iincl = wave_inclusive_sum(e.nb, lane);
+            unsigned long long base = 0;
+            if (lane == 63) base = take_slots((uint32_t)__popcll(m), iincl, T);
+            base = __shfl(base, 63);
+            const unsigned long long below = m & ((1ull << lane) - 1ull);
+            const uint32_t sub = (uint32_t)__popcll(below >> ((lane / 7) * 7));   // set-up fan triangles of the same polygon before this one
+            place_triangle(has, t, e, (uint32_t)base + (uint32_t)__popcll(below), (uint32_t)(base >> 32) + iincl - e.nb,
+                           lane < 56 ? s_src[p] : 0u, lane < 56 ? s_obj[p] : 0u, sub, gp, T);
         }
-        const uint32_t rincl = wave_inclusive_sum(nr, lane), iincl = wave_inclusive_sum(ni, lane);
-        unsigned long long base = 0;
-        if (lane == 63) base = take_slots(rincl, iincl, T);
-        base = __shfl(base, 63);
-        uint32_t r = (uint32_t)base + rincl - nr, ibase = (uint32_t)(base >> 32) + iincl - ni, produced = 0;
-        for (int f = 1; f + 1 < n_max; ++f) {
-            SetupRec t;
-            EmitPlan e;
-            const bool has = (f + 1 < n) && setup_triangle(P.get(buf, 0, lane), P.get(buf, f, lane), P.get(buf, f + 1, lane), gp, t);
-            plan_triangle(has, t, gp, e);
-            const uint32_t slots = e.nb;   // place_triangle zeroes nb when the record table is full; the slots stay taken
-            place_triangle(has, t, e, r, ibase, src, oi, produced, gp, T);
-            if (has) { ++r; ++produced; }
-            ibase += slots;
-        }
+        __syncthreads();   // the polygons are read; the next sweep may overwrite them
     }
 }
 
