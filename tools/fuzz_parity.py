@@ -3,9 +3,10 @@ Bars as in tests/test_gpu_parity.py: shadow map / G-buffer bit-exact, float LDR 
 where the reference formula itself is ill-conditioned in fp32 (tests/test_oracle_noise_floor.py: grazing views with
 n.wo ~ 1e-6, low-roughness highlights): a pixel whose LITERAL fp32 evaluation (oracle precision 32) is itself more than
 5e-5 away from the float64 value, or whose float64 value moves by more than 2.5e-5 when tangent frame and world position
-move by one fp32 ulp, is reported and must stay within 4x the larger of those two distances instead.
-usage: python tools/fuzz_parity.py [n_cases] [seed] [only] [size_factor]   (size_factor 8: frames of 2-3 Mpx, where the rasteriser
-merges chunks of 32 work items per wave; the default small frames give every wave a single item)"""
+move by one fp32 ulp of their vectors' magnitudes, is reported and must stay within 4x the larger of those two distances instead.
+usage: python tools/fuzz_parity.py [n_cases] [seed] [only] [size_factor] [jitter]   (size_factor 8: frames of 2-3 Mpx, where the
+rasteriser merges chunks of 32 work items per wave; the default small frames give every wave a single item.  jitter 1: odd frame
+and shadow-map sizes -- ragged tiles, scissored windows, a bounds table whose last blocks are cut -- and object transforms)"""
 import copy, sys, time
 import numpy as np
 import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..' if os.path.basename(os.path.dirname(os.path.abspath(__file__))) == 'tools' else os.path.join('..', '..')))
@@ -15,6 +16,7 @@ from oracle import oracle as O
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 size_factor = float(sys.argv[4]) if len(sys.argv) > 4 else 1.0
+jitter = len(sys.argv) > 5 and sys.argv[5] == "1"
 only = int(sys.argv[3]) if len(sys.argv) > 3 else -1   # run just this case (the random stream is advanced identically) and dump its worst pixel
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
 threads = O.hardware_threads()
@@ -25,6 +27,12 @@ for case in range(n_cases):
     scale = min(1.0, {2: 0.2, 3: 0.08, 4: 0.06}[cfg] * size_factor)
     sc = pkg.scenes.CONFIGS[cfg](scale=scale)
     desc = copy.deepcopy(sc.desc)
+    if jitter:   # drawn before anything else so that the remaining stream does not depend on the scene
+        sc.width = max(9, int(sc.width * rng.uniform(0.8, 1.0)) | 1); sc.height = max(9, int(sc.height * rng.uniform(0.8, 1.0)) | 1)
+        if sc.shadow_size: sc.shadow_size = int(sc.shadow_size * rng.uniform(0.6, 1.2)) | int(rng.integers(0, 2))
+        desc.camera["aspect"] = sc.width / sc.height
+        for ob in desc.objects[: 1 + int(rng.integers(0, 3))]:   # move / scale the first few objects (glm column-major trs)
+            ob["trs"][12] += float(rng.uniform(-0.3, 0.3)); ob["trs"][13] += float(rng.uniform(0.0, 0.2)); ob["trs"][0] *= float(rng.uniform(0.9, 1.1))
     if cfg == 2:
         az, el, dist = rng.uniform(0, 360), rng.uniform(-5, 40), rng.uniform(2.5, 7.0)
         eye = np.array([dist * np.cos(np.deg2rad(el)) * np.cos(np.deg2rad(az)), 0.8 + dist * np.sin(np.deg2rad(el)), dist * np.cos(np.deg2rad(el)) * np.sin(np.deg2rad(az))])
@@ -60,10 +68,14 @@ for case in range(n_cases):
     # component -- can promise 1e-4 there, whether or not the oracle's own fp32 path happens to land close
     sens = np.zeros_like(e_hip)
     prng = np.random.default_rng(case)
+    # one ulp OF THE VECTOR a component belongs to (tangent, bitangent, normal, position): the rounding error of a dot product scales
+    # with its operands' magnitudes, and a component that is exactly 0 -- a floor at y = 0, an axis-aligned normal -- has no ulp of its own
+    vec = og[0][..., 2:14].reshape(og[0].shape[:2] + (4, 3))
+    step = np.repeat(np.spacing(np.abs(vec).max(-1, keepdims=True).astype(np.float32)), 3, axis=-1).reshape(og[0].shape[:2] + (12,))
     for pattern in range(4):
-        up = np.ones(og[0][..., 2:14].shape, bool) if pattern == 0 else (~np.ones(og[0][..., 2:14].shape, bool) if pattern == 1 else prng.random(og[0][..., 2:14].shape) < 0.5)
+        up = np.ones(step.shape, bool) if pattern == 0 else (np.zeros(step.shape, bool) if pattern == 1 else prng.random(step.shape) < 0.5)
         pert = og[0].copy()
-        pert[..., 2:14] = np.where(up, np.nextafter(pert[..., 2:14], np.float32(np.inf)), np.nextafter(pert[..., 2:14], np.float32(-np.inf)))
+        pert[..., 2:14] = (pert[..., 2:14] + np.where(up, step, -step)).astype(np.float32)
         alt = o.shade_gbuffer(desc, settings, pert, og[1], threads=threads, want=("ldr",))["ldr"]
         sens = np.maximum(sens, np.abs(alt - oldr).max(-1))
     ill = (e_f32 > 5e-5) | (sens > 2.5e-5)                   # the literal fp32 evaluation misses the float64 value, or one input ulp moves it
