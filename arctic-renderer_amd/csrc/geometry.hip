@@ -193,18 +193,6 @@ __device__ __forceinline__ bool block_reachable(const RasterRec &q, int32_t bx, 
     return any;
 }
 
-// coverage + barycentrics (l1, l2) + clamped depth
-__device__ __forceinline__ bool fragment(const SetupRec &t, const Edges &e, float inv_area, int32_t px, int32_t py,
-                                         float &l1, float &l2, float &z) {
-    int64_t e0 = edge_eval(e, 0, px, py), e1 = edge_eval(e, 1, px, py), e2 = edge_eval(e, 2, px, py);
-    if ((e0 + e.bias[0]) < 0 || (e1 + e.bias[1]) < 0 || (e2 + e.bias[2]) < 0) return false;
-    l1 = (float)e2 * inv_area;
-    l2 = (float)e0 * inv_area;
-    z = fmaf(l2, t.z[2] - t.z[0], fmaf(l1, t.z[1] - t.z[0], t.z[0]));
-    z = fminf(fmaxf(z, 0.0f), 1.0f);
-    return true;
-}
-
 // HLSL mul(M, v) with M column-major: row i = ((m0i*x + m1i*y) + m2i*z) + m3i*w
 __device__ __forceinline__ void mat_vec(const float *m, float x, float y, float z, float w, float *o) {
 #pragma unroll
@@ -294,16 +282,6 @@ __device__ __forceinline__ bool load_triangle(const ObjectRec &ob, uint32_t ti, 
     fetch(i0, a, 1.0f, 0.0f, 0.0f); fetch(i1, b, 0.0f, 1.0f, 0.0f); fetch(i2, c, 0.0f, 0.0f, 1.0f);
     return true;
 }
-__device__ __forceinline__ bool inside_all_planes(const CV &v) {
-    bool inside = true;
-#pragma unroll
-    for (int p = 0; p < 6; ++p) inside = inside && (plane_dist(v, p) >= 0.0f);
-    return inside;
-}
-
-// what a set-up triangle will put into the tables: its RasterRec and its work items.  Blocks of the bounding box no edge function
-// reaches are not emitted: as a bit mask for records of up to 64 blocks (nearly all), at emission for larger ones -- their slots
-// are taken before the wave looks at them, so those become ITEM_SKIP
 typedef int32_t i2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int32_t high_word(double v) { return __builtin_bit_cast(i2v, v).y; }   // sign and exponent: negative <=> the word is
 
