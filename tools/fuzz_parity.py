@@ -6,7 +6,7 @@ n.wo ~ 1e-6, low-roughness highlights): a pixel whose LITERAL fp32 evaluation (o
 move by one fp32 ulp of their vectors' magnitudes, is reported and must stay within 4x the larger of those two distances instead.
 usage: python tools/fuzz_parity.py [n_cases] [seed] [only] [size_factor] [jitter]   (size_factor 8: frames of 2-3 Mpx, where the
 rasteriser merges chunks of 32 work items per wave; the default small frames give every wave a single item.  jitter 1: odd frame
-and shadow-map sizes -- ragged tiles, scissored windows, a bounds table whose last blocks are cut -- and object transforms)"""
+and shadow-map sizes -- ragged tiles, scissored windows, a bounds table whose last blocks are cut --, object transforms, and the culling / light-loop options of the HIP side)"""
 import copy, sys, time
 import numpy as np
 import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..' if os.path.basename(os.path.dirname(os.path.abspath(__file__))) == 'tools' else os.path.join('..', '..')))
@@ -31,6 +31,7 @@ for case in range(n_cases):
         sc.width = max(9, int(sc.width * rng.uniform(0.8, 1.0)) | 1); sc.height = max(9, int(sc.height * rng.uniform(0.8, 1.0)) | 1)
         if sc.shadow_size: sc.shadow_size = int(sc.shadow_size * rng.uniform(0.6, 1.2)) | int(rng.integers(0, 2))
         desc.camera["aspect"] = sc.width / sc.height
+        hip_options = dict(culling=int(rng.integers(0, 2)), light_path=int(rng.integers(0, 3)))   # exact culling on / off; auto, scalar or packed light loop
         for ob in desc.objects[: 1 + int(rng.integers(0, 3))]:   # move / scale the first few objects (glm column-major trs)
             ob["trs"][12] += float(rng.uniform(-0.3, 0.3)); ob["trs"][13] += float(rng.uniform(0.0, 0.2)); ob["trs"][0] *= float(rng.uniform(0.9, 1.1))
     if cfg == 2:
@@ -52,6 +53,8 @@ for case in range(n_cases):
     o = sc.upload(O.Oracle(sc.width, sc.height, sc.shadow_size, sc.max_lights))
     r = sc.upload(pkg.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights))
     r.set_option("keep_float_output", 1)
+    if jitter:
+        for name, value in hip_options.items(): r.set_option(name, value)
     if env is not None:
         o.create_hdri(env); r.create_hdri(env)
     o.pass_shadow_map(desc); o.pass_gbuffer(desc)
@@ -98,6 +101,8 @@ for case in range(n_cases):
             rs = sc.upload(pkg.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights, band_rows=band, shard=(k, world)))
             if env is not None:
                 rs.create_hdri(env)
+            if jitter:
+                for name, value in hip_options.items(): rs.set_option(name, value)
             same = bool(np.array_equal(rs.render_frame(desc, settings), img[rows]))
             rs.close()
             ok = ok and same
