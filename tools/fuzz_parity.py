@@ -6,7 +6,7 @@ n.wo ~ 1e-6, low-roughness highlights): a pixel whose LITERAL fp32 evaluation (o
 move by one fp32 ulp of their vectors' magnitudes, is reported and must stay within 4x the larger of those two distances instead.
 usage: python tools/fuzz_parity.py [n_cases] [seed] [only] [size_factor] [jitter]   (size_factor 8: frames of 2-3 Mpx, where the
 rasteriser merges chunks of 32 work items per wave; the default small frames give every wave a single item.  jitter 1: odd frame
-and shadow-map sizes -- ragged tiles, scissored windows, a bounds table whose last blocks are cut --, object transforms, and the culling / light-loop options of the HIP side)"""
+and shadow-map sizes -- ragged tiles, scissored windows, a bounds table whose last blocks are cut --, object transforms, materials with unequal image sizes, and the culling / light-loop options of the HIP side)"""
 import copy, sys, time
 import numpy as np
 import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..' if os.path.basename(os.path.dirname(os.path.abspath(__file__))) == 'tools' else os.path.join('..', '..')))
@@ -31,6 +31,10 @@ for case in range(n_cases):
         sc.width = max(9, int(sc.width * rng.uniform(0.8, 1.0)) | 1); sc.height = max(9, int(sc.height * rng.uniform(0.8, 1.0)) | 1)
         if sc.shadow_size: sc.shadow_size = int(sc.shadow_size * rng.uniform(0.6, 1.2)) | int(rng.integers(0, 2))
         desc.camera["aspect"] = sc.width / sc.height
+        for _ in range(int(rng.integers(0, 3))):   # a few materials whose three images differ in size: the plain RGBA8 path, one material at a time
+            mi = int(rng.integers(0, len(sc.materials)))
+            d_, n_, m_ = sc.materials[mi]
+            sc.materials[mi] = (d_, np.ascontiguousarray(n_[::2, ::3]) if n_.shape[0] > 4 and n_.shape[1] > 6 else n_, np.ascontiguousarray(m_[::3, ::2]) if m_.shape[0] > 6 and m_.shape[1] > 4 else m_)
         hip_options = dict(culling=int(rng.integers(0, 2)), light_path=int(rng.integers(0, 3)))   # exact culling on / off; auto, scalar or packed light loop
         for ob in desc.objects[: 1 + int(rng.integers(0, 3))]:   # move / scale the first few objects (glm column-major trs)
             ob["trs"][12] += float(rng.uniform(-0.3, 0.3)); ob["trs"][13] += float(rng.uniform(0.0, 0.2)); ob["trs"][0] *= float(rng.uniform(0.9, 1.1))
