@@ -151,13 +151,19 @@ struct ArcticRenderer {
     // frame targets
     DevBuf d_vis, d_p0, d_p1, d_p2, d_p3, d_p4, d_rgba8, d_ldr, d_hdr, d_counter;
     bool have_gbuffer = false, have_output = false, have_vis = false;   // have_vis: d_vis holds the visibility of the current G-buffer
-    int geo_owner = 0;              // whose records d_recs / d_rec_of / d_xverts hold: 1 forward pass, 2 shadow pass
     int light_path = 0;             // ARCTIC_OPT_LIGHT_PATH: 0 automatic, 1 scalar light loop, 2 packed pairs
     bool visbuffer = true;          // arctic_render_frame shades straight from the visibility plane (no G-buffer)
     // per-frame geometry scratch
     PassTables tables[2];   // [0] forward pass, [1] shadow pass
-    DevBuf d_xverts, d_recs, d_rrecs, d_clip_list, d_rec_of, d_items, d_geo_counters, d_stage;
-    uint32_t item_cap = 0;          // entries of d_items (work-item table of the rasteriser)
+    // transformed vertices, records, work items: one set per pass ([0] forward, [1] shadow), so that the two prepasses of a frame
+    // can run side by side (arctic_render_frame) and the forward pass's records outlive a shadow pass (k_resolve, k_material_vis)
+    struct GeoSet {
+        DevBuf d_xverts, d_recs, d_rrecs, d_clip_list, d_rec_of, d_items;
+        uint32_t item_cap = 0;      // entries of d_items (work-item table of the rasteriser)
+    } geo[2];
+    DevBuf d_geo_counters, d_stage;
+    hipStream_t shadow_stream = nullptr;            // arctic_render_frame draws the shadow map here while the main stream runs the visibility prepass
+    hipEvent_t ev_fork = nullptr, ev_shadow = nullptr;
     bool recs_worst_case = false;   // record table at 7 per source triangle (after an overflow of the 2-per-triangle table)
     uint32_t item_cap_floor = 1u << 22;   // its smallest size (ARCTIC_OPT_ITEM_TABLE_FLOOR; tests shrink it to reach the overflow path)
     uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -240,7 +246,7 @@ int alloc_targets(ArcticRenderer *r) {
 
 // Scene.objects -> ObjectRec[] + block tables in one asynchronous upload, skipped while the list stays byte-identical (a
 // static scene under a moving camera: the frame constants travel as a kernel argument, so such frames copy nothing)
-int upload_pass_tables(ArcticRenderer *r, PassTables &T, const GeomParams &gp, const ArcticScene *sc, uint32_t &n_objs,
+int upload_pass_tables(ArcticRenderer *r, PassTables &T, DevBuf &d_xverts, hipStream_t stream, const GeomParams &gp, const ArcticScene *sc, uint32_t &n_objs,
                        uint32_t &n_xverts, uint32_t &n_src_tris, uint32_t &n_vblocks, uint32_t &n_tblocks) {
     std::vector<ObjectRec> objs;
     std::vector<uint32_t> vb_obj, vb_first, tb_obj, tb_first;
@@ -292,8 +298,8 @@ int upload_pass_tables(ArcticRenderer *r, PassTables &T, const GeomParams &gp, c
         T.last.clear();
         HIPCHECK(r, T.d.ensure(total));
         std::memcpy(T.h, h, total);
-        HIPCHECK(r, hipMemcpyAsync(T.d.p, T.h, total, hipMemcpyHostToDevice, r->stream));
-        HIPCHECK(r, hipEventRecord(T.copied, r->stream));
+        HIPCHECK(r, hipMemcpyAsync(T.d.p, T.h, total, hipMemcpyHostToDevice, stream));
+        HIPCHECK(r, hipEventRecord(T.copied, stream));
         T.pending = true;
         T.last.swap(stage);
     }
@@ -302,13 +308,14 @@ int upload_pass_tables(ArcticRenderer *r, PassTables &T, const GeomParams &gp, c
     T.vblock_obj = reinterpret_cast<const uint32_t *>(d + o_vo); T.vblock_first = reinterpret_cast<const uint32_t *>(d + o_vf);
     T.tblock_obj = reinterpret_cast<const uint32_t *>(d + o_to); T.tblock_first = reinterpret_cast<const uint32_t *>(d + o_tf);
     if (n_objs) {
-        HIPCHECK(r, r->d_xverts.ensure((size_t)n_xverts * sizeof(XVert)));
+        HIPCHECK(r, d_xverts.ensure((size_t)n_xverts * sizeof(XVert)));
     }
     return ARCTIC_OK;
 }
 
 // vertex -> clip/setup -> raster, shared by the forward prepass and the shadow pass
-int run_geometry(ArcticRenderer *r, const ArcticScene *sc, bool shadow_pass) {
+int run_geometry(ArcticRenderer *r, const ArcticScene *sc, bool shadow_pass, hipStream_t stream) {
+    ArcticRenderer::GeoSet &G = r->geo[shadow_pass ? 1 : 0];
     // the pass's target is cleared by the vertex kernel's launch (or by a fill when there is nothing to draw)
     unsigned long long *clear = shadow_pass ? r->d_shadow.as<unsigned long long>() : r->d_vis.as<unsigned long long>();
     const unsigned long long clear_value = shadow_pass ? 0x3F8000003F800000ull : ~0ull;   // depth 1.0 (shadow_map_pass.cpp:124-131) / no triangle
@@ -338,19 +345,18 @@ int run_geometry(ArcticRenderer *r, const ArcticScene *sc, bool shadow_pass) {
     }
     gp.raster_flags = (r->debug & 32) ? 1 : 0;
     PassTables &T = r->tables[shadow_pass ? 1 : 0];
-    r->geo_owner = shadow_pass ? 2 : 1;
     uint32_t n_objs, n_xverts, n_src, n_vblocks, n_tblocks;
-    int rc = upload_pass_tables(r, T, gp, sc, n_objs, n_xverts, n_src, n_vblocks, n_tblocks);
+    int rc = upload_pass_tables(r, T, G.d_xverts, stream, gp, sc, n_objs, n_xverts, n_src, n_vblocks, n_tblocks);
     if (rc != ARCTIC_OK) return rc;
     const GeomParams &d_gp = T.gp;
     if (n_objs == 0 || n_src == 0 || n_vblocks == 0) {
         r->h_counts[shadow_pass ? 2 : 0] = r->h_counts[shadow_pass ? 3 : 1] = 0;
-        HIPCHECK(r, launch_fill_u64(clear, clear_value, clear_count, r->stream));
+        HIPCHECK(r, launch_fill_u64(clear, clear_value, clear_count, stream));
         return ARCTIC_OK;
     }
     const ObjectRec *objs = T.objs;
-    HIPCHECK(r, launch_vertex(objs, T.vblock_obj, T.vblock_first, n_vblocks, d_gp, r->d_xverts.as<XVert>(), shadow_pass ? 1 : 0,
-                              r->d_geo_counters.as<uint32_t>() + (shadow_pass ? 4 : 0), clear, clear_value, clear_count, r->stream));
+    HIPCHECK(r, launch_vertex(objs, T.vblock_obj, T.vblock_first, n_vblocks, d_gp, G.d_xverts.as<XVert>(), shadow_pass ? 1 : 0,
+                              r->d_geo_counters.as<uint32_t>() + (shadow_pass ? 4 : 0), clear, clear_value, clear_count, stream));
     // Record slots: a triangle clipped against 6 planes yields at most 7 triangles, so 7 * n_src slots can never overflow.
     // Records and work items are allocated on the device from two counters (k_setup): no count pass, no scan, and neither
     // count has to come back to the host -- the frame stays asynchronous.
@@ -362,43 +368,55 @@ int run_geometry(ArcticRenderer *r, const ArcticScene *sc, bool shadow_pass) {
     // work-item table: explicit (record, 16x16 block) pairs.  Its size follows the largest count seen so far (pinned
     // h_counts, refreshed asynchronously each pass) with 4x headroom; an overflow drops work, is flagged by the kernel and
     // reported by the next call that synchronises (arctic_flush / read-backs) -- and the table has grown by then.
-    const uint64_t want = std::max<uint64_t>(r->item_cap_floor, 4ull * std::max(r->h_counts[1], r->h_counts[3]));
-    if (want > r->item_cap) {
-        HIPCHECK(r, r->d_items.ensure((size_t)want * 8));
-        r->item_cap = (uint32_t)std::min<uint64_t>(want, 0x7FFFFFF0ull);
+    const uint64_t want = std::max<uint64_t>(r->item_cap_floor, 4ull * r->h_counts[shadow_pass ? 3 : 1]);
+    if (want > G.item_cap) {
+        HIPCHECK(r, G.d_items.ensure((size_t)want * 8));
+        G.item_cap = (uint32_t)std::min<uint64_t>(want, 0x7FFFFFF0ull);
     }
-    HIPCHECK(r, r->d_recs.ensure((size_t)n_slots * sizeof(SetupRec)));
-    HIPCHECK(r, r->d_rrecs.ensure((size_t)n_slots * sizeof(RasterRec)));
-    HIPCHECK(r, r->d_rec_of.ensure((size_t)n_src * 8 * 4));
-    HIPCHECK(r, r->d_clip_list.ensure((size_t)n_src * 8));
+    HIPCHECK(r, G.d_recs.ensure((size_t)n_slots * sizeof(SetupRec)));
+    HIPCHECK(r, G.d_rrecs.ensure((size_t)n_slots * sizeof(RasterRec)));
+    HIPCHECK(r, G.d_rec_of.ensure((size_t)n_src * 8 * 4));
+    HIPCHECK(r, G.d_clip_list.ensure((size_t)n_src * 8));
     uint32_t *counters = r->d_geo_counters.as<uint32_t>() + (shadow_pass ? 4 : 0);   // zeroed by k_vertex
-    HIPCHECK(r, launch_setup(objs, T.tblock_obj, T.tblock_first, n_tblocks, d_gp, r->d_xverts.as<XVert>(), r->d_recs.as<SetupRec>(),
-                             r->d_rrecs.as<RasterRec>(), r->d_rec_of.as<uint32_t>(), r->d_items.as<uint2>(), r->item_cap, n_slots, counters,
-                             r->d_clip_list.as<uint2>(), r->stream));
+    HIPCHECK(r, launch_setup(objs, T.tblock_obj, T.tblock_first, n_tblocks, d_gp, G.d_xverts.as<XVert>(), G.d_recs.as<SetupRec>(),
+                             G.d_rrecs.as<RasterRec>(), G.d_rec_of.as<uint32_t>(), G.d_items.as<uint2>(), G.item_cap, n_slots, counters,
+                             G.d_clip_list.as<uint2>(), stream));
     // counts for arctic_stats() and the overflow flag: k_raster stores them into pinned, mapped memory (no copy launches between
     // the kernels); looked at only when the stream has been synchronised
     uint32_t *dh = r->dh_counts + (shadow_pass ? 2 : 0), *dh_overflow = r->dh_counts + 4 + (shadow_pass ? 1 : 0);
     if (shadow_pass)
-        HIPCHECK(r, launch_raster_depth(r->d_recs.as<SetupRec>(), r->d_rrecs.as<RasterRec>(), r->d_items.as<uint2>(), r->item_cap, counters, r->raster_blocks[1], d_gp,
-                                        r->d_shadow.as<uint32_t>(), dh, dh_overflow, r->stream));
+        HIPCHECK(r, launch_raster_depth(G.d_recs.as<SetupRec>(), G.d_rrecs.as<RasterRec>(), G.d_items.as<uint2>(), G.item_cap, counters, r->raster_blocks[1], d_gp,
+                                        r->d_shadow.as<uint32_t>(), dh, dh_overflow, stream));
     else
-        HIPCHECK(r, launch_raster_vis(r->d_recs.as<SetupRec>(), r->d_rrecs.as<RasterRec>(), r->d_items.as<uint2>(), r->item_cap, counters, r->raster_blocks[0], d_gp,
-                                      r->d_vis.as<unsigned long long>(), dh, dh_overflow, r->stream));
+        HIPCHECK(r, launch_raster_vis(G.d_recs.as<SetupRec>(), G.d_rrecs.as<RasterRec>(), G.d_items.as<uint2>(), G.item_cap, counters, r->raster_blocks[0], d_gp,
+                                      r->d_vis.as<unsigned long long>(), dh, dh_overflow, stream));
     return ARCTIC_OK;
 }
 
-int pass_shadow_map(ArcticRenderer *r, const ArcticScene *sc) {
+// the min/max table of the shadow map (shade.hip: the test that replaces the 25 PCF taps for most pixels): rebuilt, two small
+// launches, after the map was written
+int build_shadow_bounds(ArcticRenderer *r, hipStream_t stream) {
+    const uint32_t nb = shadow_bounds_pitch(r->shadow_size);
+    if (!nb || r->bounds_valid) return ARCTIC_OK;
+    HIPCHECK(r, r->d_shadow_blocks.ensure((size_t)nb * nb * 8));
+    HIPCHECK(r, r->d_shadow_bounds.ensure((size_t)nb * nb * 8));
+    HIPCHECK(r, launch_shadow_bounds(r->d_shadow.as<float>(), r->shadow_size, r->d_shadow_blocks.as<float2>(), r->d_shadow_bounds.as<float2>(), stream));
+    r->bounds_valid = true;
+    return ARCTIC_OK;
+}
+
+int pass_shadow_map(ArcticRenderer *r, const ArcticScene *sc, hipStream_t stream) {
     if (r->shadow_size == 0) return ARCTIC_OK;
     Range zone("Shadow Map Pass");
     r->bounds_valid = false;
-    int rc = run_geometry(r, sc, true);
+    int rc = run_geometry(r, sc, true, stream);
     if (rc != ARCTIC_OK) return rc;
     if (r->shadow_sharded && r->comm && r->comm_world > 1) {
         // every rank has drawn ceil(S / world) rows of the map: one in-place all-gather (the send buffer is this rank's slice of the
-        // receive buffer) completes it everywhere, on the main stream -- the shading pass needs it next
+        // receive buffer) completes it everywhere, on the pass's stream -- the shading pass needs it next
         const size_t per = (size_t)((r->shadow_size + (uint32_t)r->comm_world - 1) / (uint32_t)r->comm_world) * r->shadow_size;
         float *base = r->d_shadow.as<float>();
-        const int nrc = g_rccl.AllGather(base + per * (size_t)r->comm_rank, base, per, Rccl::Float32, r->comm, r->stream);
+        const int nrc = g_rccl.AllGather(base + per * (size_t)r->comm_rank, base, per, Rccl::Float32, r->comm, stream);
         if (nrc != 0) return r->fail(ARCTIC_E_DEVICE, "ncclAllGather(shadow map): %s", g_rccl.why(nrc));
     }
     return ARCTIC_OK;
@@ -408,7 +426,7 @@ int pass_shadow_map(ArcticRenderer *r, const ArcticScene *sc) {
 int pass_visibility(ArcticRenderer *r, const ArcticScene *sc) {
     Range zone("Forward Pass: visibility");
     r->have_gbuffer = false;
-    int rc = run_geometry(r, sc, false);
+    int rc = run_geometry(r, sc, false, r->stream);
     if (rc != ARCTIC_OK) return rc;
     r->have_vis = true;
     return ARCTIC_OK;
@@ -417,10 +435,10 @@ int pass_visibility(ArcticRenderer *r, const ArcticScene *sc) {
 // visibility -> the 76 B/pixel G-buffer.  Valid while the records of the forward pass are still in place.
 int resolve_gbuffer(ArcticRenderer *r) {
     Range zone("Forward Pass: G-buffer");
-    if (!r->have_vis || r->geo_owner != 1)
-        return r->fail(ARCTIC_E_STATE, "no G-buffer: the frame was shaded from the visibility plane and a later pass has replaced its records (run arctic_pass_gbuffer)");
-    HIPCHECK(r, launch_resolve(r->d_vis.as<unsigned long long>(), r->d_recs.as<SetupRec>(), r->d_rrecs.as<RasterRec>(), r->d_rec_of.as<uint32_t>(), r->tables[0].objs,
-                               r->d_xverts.as<XVert>(), r->tables[0].gp, (uint32_t)r->n_tiles(), r->gbuffer(),
+    if (!r->have_vis)
+        return r->fail(ARCTIC_E_STATE, "no G-buffer: no visibility plane to resolve it from (run arctic_pass_gbuffer)");
+    HIPCHECK(r, launch_resolve(r->d_vis.as<unsigned long long>(), r->geo[0].d_recs.as<SetupRec>(), r->geo[0].d_rrecs.as<RasterRec>(), r->geo[0].d_rec_of.as<uint32_t>(), r->tables[0].objs,
+                               r->geo[0].d_xverts.as<XVert>(), r->tables[0].gp, (uint32_t)r->n_tiles(), r->gbuffer(),
                                r->stream));
     r->have_gbuffer = true;
     return ARCTIC_OK;
@@ -433,15 +451,16 @@ int pass_gbuffer(ArcticRenderer *r, const ArcticScene *sc) {
 
 int fill_shade_params(ArcticRenderer *r, const ArcticScene *sc, const ArcticSettings *st, void *d_out, ShadeParams &sp, bool from_vis = false) {
     if (!from_vis && !r->have_gbuffer) {
-        if (r->have_vis && r->geo_owner == 1) { int rc = resolve_gbuffer(r); if (rc != ARCTIC_OK) return rc; }   // frame came from arctic_render_frame
+        if (r->have_vis) { int rc = resolve_gbuffer(r); if (rc != ARCTIC_OK) return rc; }   // frame came from arctic_render_frame
         else return r->fail(ARCTIC_E_STATE, "shade: no G-buffer (run arctic_pass_gbuffer or arctic_write_gbuffer first)");
     }
     std::memset(&sp, 0, sizeof sp);
     sp.g = r->gbuffer();
-    sp.compact_tables = (r->d_recs.cap < (1ull << 32) && r->d_rrecs.cap < (1ull << 32) && r->d_xverts.cap < (1ull << 32) && r->d_rec_of.cap < (1ull << 32) &&
+    const ArcticRenderer::GeoSet &G = r->geo[0];
+    sp.compact_tables = (G.d_recs.cap < (1ull << 32) && G.d_rrecs.cap < (1ull << 32) && G.d_xverts.cap < (1ull << 32) && G.d_rec_of.cap < (1ull << 32) &&
                          r->tables[0].d.cap < (1ull << 32) && !(r->debug & 64)) ? 1 : 0;
-    sp.vis = r->d_vis.as<unsigned long long>(); sp.recs = r->d_recs.as<SetupRec>(); sp.rrecs = r->d_rrecs.as<RasterRec>(); sp.rec_of = r->d_rec_of.as<uint32_t>();
-    sp.objs = r->tables[0].objs; sp.xv = r->d_xverts.as<XVert>();
+    sp.vis = r->d_vis.as<unsigned long long>(); sp.recs = G.d_recs.as<SetupRec>(); sp.rrecs = G.d_rrecs.as<RasterRec>(); sp.rec_of = G.d_rec_of.as<uint32_t>();
+    sp.objs = r->tables[0].objs; sp.xv = G.d_xverts.as<XVert>();
     sp.tex = r->d_tex.as<TexDesc>();
     sp.n_materials = (uint32_t)(r->tex.size() / 3);
     sp.srgb_lut = r->d_lut.as<float>();
@@ -475,13 +494,9 @@ int fill_shade_params(ArcticRenderer *r, const ArcticScene *sc, const ArcticSett
     sp.band_tiles = (int32_t)(r->band_rows / TILE); sp.shard_index = (int32_t)r->shard_index; sp.shard_count = (int32_t)r->shard_count;
     sp.tile_y0 = (int32_t)r->tile_y0;
     const uint32_t nb = shadow_bounds_pitch(r->shadow_size);
-    if (nb && !(r->debug & 8)) {   // the min/max table of the shadow map: rebuilt (two small launches) whenever the map was written
-        if (!r->bounds_valid) {
-            HIPCHECK(r, r->d_shadow_blocks.ensure((size_t)nb * nb * 8));
-            HIPCHECK(r, r->d_shadow_bounds.ensure((size_t)nb * nb * 8));
-            HIPCHECK(r, launch_shadow_bounds(r->d_shadow.as<float>(), r->shadow_size, r->d_shadow_blocks.as<float2>(), r->d_shadow_bounds.as<float2>(), r->stream));
-            r->bounds_valid = true;
-        }
+    if (nb && !(r->debug & 8)) {   // the min/max table of the shadow map: rebuilt whenever the map was written
+        int rc = build_shadow_bounds(r, r->stream);
+        if (rc != ARCTIC_OK) return rc;
         sp.shadow_bounds = r->d_shadow_bounds.as<float2>(); sp.bounds_pitch = nb;
     }
     return ARCTIC_OK;
@@ -543,7 +558,7 @@ int check_item_overflow(ArcticRenderer *r) {
     r->recs_worst_case = true;   // whichever table it was: the record table takes its worst-case size from now on
     r->have_gbuffer = false; r->have_output = false; r->have_vis = false; r->shadow_key.clear();
     return r->fail(ARCTIC_E_CAPACITY, "a rasteriser table overflowed (%u work items needed, %u slots; or more than 2 records per source triangle): the last frame "
-                   "is incomplete; the tables grow on the next pass -- render the frame again", need, r->item_cap);
+                   "is incomplete; the tables grow on the next pass -- render the frame again", need, std::max(r->geo[0].item_cap, r->geo[1].item_cap));
 }
 
 bool valid_scene(const ArcticScene *sc) { return sc && (sc->n_objects == 0 || sc->objects); }
@@ -588,6 +603,9 @@ ArcticRenderer *arctic_create(const ArcticCreateInfo *info, char *err, uint64_t 
     if ((e = hipSetDevice(r->device)) != hipSuccess) return bail("hipSetDevice", e);
     if ((e = hipStreamCreateWithFlags(&r->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     r->stream = r->own_stream;
+    if ((e = hipStreamCreateWithFlags(&r->shadow_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    if ((e = hipEventCreateWithFlags(&r->ev_fork, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreateWithFlags(&r->ev_shadow, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     {
         hipDeviceProp_t prop;
         if ((e = hipGetDeviceProperties(&prop, r->device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
@@ -621,12 +639,16 @@ void arctic_destroy(ArcticRenderer *r) {
     if (r->h_counts) (void)hipHostFree(r->h_counts);
     (void)hipStreamSynchronize(r->stream);
     (void)arctic_comm_destroy(r);
+    if (r->shadow_stream) { (void)hipStreamSynchronize(r->shadow_stream); (void)hipStreamDestroy(r->shadow_stream); }
+    if (r->ev_fork) (void)hipEventDestroy(r->ev_fork);
+    if (r->ev_shadow) (void)hipEventDestroy(r->ev_shadow);
     if (r->own_stream) { (void)hipStreamSynchronize(r->own_stream); (void)hipStreamDestroy(r->own_stream); }
     for (Mesh &m : r->meshes) { if (m.d_vertices) (void)hipFree(m.d_vertices); if (m.d_indices) (void)hipFree(m.d_indices); }
     for (void *p : r->tex_allocs) (void)hipFree(p);
     DevBuf *bufs[] = {&r->d_tex, &r->d_lut, &r->d_lights, &r->d_light_pairs, &r->d_shadow, &r->d_env, &r->d_vis, &r->d_p0, &r->d_p1, &r->d_p2, &r->d_p3, &r->d_p4,
-                      &r->d_rgba8, &r->d_ldr, &r->d_hdr, &r->d_counter, &r->d_shadow_blocks, &r->d_shadow_bounds, &r->d_staging, &r->d_layout, &r->d_xverts,
-                      &r->d_recs, &r->d_rrecs, &r->d_clip_list, &r->d_rec_of, &r->d_items, &r->d_geo_counters, &r->d_stage, &r->tables[0].d, &r->tables[1].d};
+                      &r->d_rgba8, &r->d_ldr, &r->d_hdr, &r->d_counter, &r->d_shadow_blocks, &r->d_shadow_bounds, &r->d_staging, &r->d_layout, &r->geo[0].d_xverts, &r->geo[1].d_xverts,
+                      &r->geo[0].d_recs, &r->geo[0].d_rrecs, &r->geo[0].d_clip_list, &r->geo[0].d_rec_of, &r->geo[0].d_items,
+                      &r->geo[1].d_recs, &r->geo[1].d_rrecs, &r->geo[1].d_clip_list, &r->geo[1].d_rec_of, &r->geo[1].d_items, &r->d_geo_counters, &r->d_stage, &r->tables[0].d, &r->tables[1].d};
     for (PassTables &T : r->tables) { if (T.h) (void)hipHostFree(T.h); if (T.copied) (void)hipEventDestroy(T.copied); }
     for (DevBuf *b : bufs) b->release();
     delete r;
@@ -777,7 +799,7 @@ int arctic_pass_shadow_map(ArcticRenderer *r, const ArcticScene *scene) {
     int rc = select_device(r);
     if (rc) return rc;
     r->shadow_key.clear();   // an explicit pass always renders; render_frame's cache starts over
-    return pass_shadow_map(r, scene);
+    return pass_shadow_map(r, scene, r->stream);
 }
 
 int arctic_pass_gbuffer(ArcticRenderer *r, const ArcticScene *scene) {
@@ -800,15 +822,30 @@ int arctic_render_frame_device(ArcticRenderer *r, const ArcticScene *scene, cons
     int rc = select_device(r);
     if (rc) return rc;
     std::vector<uint8_t> key = shadow_inputs(r, scene);
-    if (!r->shadow_cache || key != r->shadow_key) {
+    // The shadow pass and the visibility prepass of a frame are independent until the shading pass, and both are bound by latency
+    // and by the memory side's atomic rate, not by the ALUs: when the map has to be redrawn it is drawn on
+    // a second stream, forked after everything enqueued so far (the previous frame still reads the map) and joined before the
+    // shading pass.  (Not with a sharded map: its all-gather stays on the main stream.  ARCTIC_OPT_DEBUG bit 7: one after the other.)
+    const bool redraw = r->shadow_size != 0 && (!r->shadow_cache || key != r->shadow_key);
+    const bool beside = redraw && !(r->debug & 128) && !(r->shadow_sharded && r->comm && r->comm_world > 1);
+    if (redraw) {
         r->shadow_key.clear();
-        if ((rc = pass_shadow_map(r, scene)) != ARCTIC_OK) return rc;
+        if (beside) {
+            HIPCHECK(r, hipEventRecord(r->ev_fork, r->stream));
+            HIPCHECK(r, hipStreamWaitEvent(r->shadow_stream, r->ev_fork, 0));
+            rc = pass_shadow_map(r, scene, r->shadow_stream);
+            if (rc == ARCTIC_OK && !(r->debug & 8)) rc = build_shadow_bounds(r, r->shadow_stream);
+            HIPCHECK(r, hipEventRecord(r->ev_shadow, r->shadow_stream));
+        } else rc = pass_shadow_map(r, scene, r->stream);
+        if (rc != ARCTIC_OK) { if (beside) (void)hipStreamWaitEvent(r->stream, r->ev_shadow, 0); return rc; }
         r->shadow_key.swap(key);
     }
     // whole frames skip the G-buffer: the shading pass interpolates from the visibility plane (k_material_vis), bit-identical
     // to visibility -> G-buffer -> shading; arctic_read_gbuffer / arctic_pass_shade materialise the G-buffer afterwards if asked
     const bool vis_path = r->visbuffer;
-    if ((rc = vis_path ? pass_visibility(r, scene) : pass_gbuffer(r, scene)) != ARCTIC_OK) return rc;
+    rc = vis_path ? pass_visibility(r, scene) : pass_gbuffer(r, scene);
+    if (beside) HIPCHECK(r, hipStreamWaitEvent(r->stream, r->ev_shadow, 0));   // the map and its table are complete
+    if (rc != ARCTIC_OK) return rc;
     return pass_shade(r, scene, settings, d_out, vis_path);
 }
 
@@ -998,7 +1035,7 @@ int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value) {
         break;
     case ARCTIC_OPT_ITEM_TABLE_FLOOR:
         if (value < 64 || value > 0x7FFFFFF0ll) return r->fail(ARCTIC_E_INVALID, "set_option: item table floor out of range");
-        r->item_cap_floor = (uint32_t)value; r->item_cap = 0;
+        r->item_cap_floor = (uint32_t)value; r->geo[0].item_cap = r->geo[1].item_cap = 0;
         break;
     case ARCTIC_OPT_SHADOW_CACHE: r->shadow_cache = value != 0; r->shadow_key.clear(); break;
     case ARCTIC_OPT_SHADOW_SHARDED: r->shadow_sharded = value != 0; r->shadow_key.clear(); break;

@@ -333,6 +333,8 @@ def test_render_frame_redraws_the_shadow_map_only_when_its_inputs_change(pkg, or
     cached = sc.upload(hip.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights))
     plain = sc.upload(hip.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights))
     plain.set_option("shadow_cache", 0)
+    serial = sc.upload(hip.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights))   # debug bit 7: the shadow pass on the main stream, before
+    serial.set_option("shadow_cache", 0); serial.set_option("debug", 128)                  # the visibility prepass instead of beside it
     desc = copy.deepcopy(sc.desc)
     frames = []
     for step in range(6):
@@ -344,6 +346,7 @@ def test_render_frame_redraws_the_shadow_map_only_when_its_inputs_change(pkg, or
             desc.camera["eye"] = tuple(np.add(desc.camera["eye"], (0.2, 0.1, 0.0)))   # only the camera moves: map is reused
         a, b = cached.render_frame(desc, sc.settings), plain.render_frame(desc, sc.settings)
         np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(a, serial.render_frame(desc, sc.settings))
         np.testing.assert_array_equal(cached.read_shadow_map().view(np.uint32), plain.read_shadow_map().view(np.uint32))
         frames.append(a)
     assert (frames[0] == frames[1]).all() and (frames[1] != frames[2]).any() and (frames[3] != frames[4]).any()
@@ -351,7 +354,7 @@ def test_render_frame_redraws_the_shadow_map_only_when_its_inputs_change(pkg, or
     ref = o.render_frame(desc, sc.settings)
     d = np.abs(frames[-1].astype(np.int16) - ref.astype(np.int16))
     assert d.max() <= 1 and (d != 0).mean() < 2e-3
-    cached.close(); plain.close(); o.close()
+    cached.close(); plain.close(); serial.close(); o.close()
 
 
 def test_materials_with_unequal_texture_sizes(pkg, oracle, hip):
