@@ -88,7 +88,8 @@ static_assert(sizeof(RasterRec) == 128, "RasterRec layout");
 constexpr uint32_t RASTER_EXACT_F64 = 1u;
 // a work item = {record, block}: block = bx | by << 12 | ITEM_SCISSOR (the 16x16 block is cut by the scissor / the target's edge);
 // record ITEM_SKIP: an entry of a large record whose block no edge function reaches (its slot was taken before that was known)
-constexpr uint32_t SETUP_THREADS = 512;   // triangles per workgroup of k_setup (one pair of slot atomics per workgroup)
+constexpr uint32_t SETUP_THREADS = 256;   // triangles per workgroup of k_setup (one slot atomic per workgroup).  512 is 1 us faster alone, but a 512-thread
+                                          // workgroup finds no room beside a shading kernel of 256-thread workgroups (frames in flight): it starved until that ended
 constexpr uint32_t ITEM_SCISSOR = 1u << 24;
 constexpr uint32_t ITEM_SKIP = 0xFFFFFFFFu;
 
