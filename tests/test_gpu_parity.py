@@ -357,6 +357,51 @@ def test_render_frame_redraws_the_shadow_map_only_when_its_inputs_change(pkg, or
     cached.close(); plain.close(); serial.close(); o.close()
 
 
+def test_frames_in_flight_give_the_same_frames(pkg, oracle, hip):
+    """ARCTIC_OPT_FRAMES_IN_FLIGHT = 2 (default): the visibility prepass of a frame runs on its own stream, into the other set of
+    tables, beside the shading of the frame before.  A run of frames whose camera moves every frame and whose objects move now and
+    then -- each frame enqueued without waiting for the one before -- must equal the same run with one frame at a time, byte for
+    byte, also with pass-level calls (which see the latest frame's set) and G-buffer read-backs in between."""
+    import copy
+    import torch
+    sc = pkg.scenes.config3(scale=0.25)
+    two = sc.upload(hip.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights))
+    one = sc.upload(hip.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights))
+    one.set_option("frames_in_flight", 1)
+    n = 12
+    outs = [[torch.empty((sc.height, sc.width, 4), dtype=torch.uint8, device="cuda") for _ in range(n)] for _ in range(2)]
+    descs = []
+    desc = copy.deepcopy(sc.desc)
+    for k in range(n):
+        desc = copy.deepcopy(desc)
+        desc.camera["eye"] = (0.4 * k - 2.0, 5.0 + 0.1 * k, 0.3 * np.sin(k))
+        desc.camera["rotation"] = (-15.0 + k, 7.0 * k)
+        if k in (4, 9):
+            desc.objects["trs"][8 + k][12] += 0.5          # a column moves: its table set is uploaded again, the other one a frame later
+        descs.append(desc)
+    for k in range(n):                                      # no flush inside the loop: frames are in flight
+        for r, o in zip((two, one), outs):
+            r.render_frame_device(descs[k], sc.settings, o[k].data_ptr())
+        if k == 5:                                          # the lazily resolved G-buffer is the latest frame's
+            ga, gb = two.read_gbuffer(), one.read_gbuffer()
+            for x, y in zip(ga, gb):
+                np.testing.assert_array_equal(x.view(np.uint32), y.view(np.uint32))
+        if k == 7:                                          # pass-level calls between frames
+            for r in (two, one):
+                r.pass_gbuffer(descs[k]); r.pass_shade(descs[k], sc.settings)
+            np.testing.assert_array_equal(two.read_output(want=("rgba8",))[2], one.read_output(want=("rgba8",))[2])
+    two.flush(); one.flush()
+    for k in range(n):
+        np.testing.assert_array_equal(outs[0][k].cpu().numpy(), outs[1][k].cpu().numpy(), err_msg=f"frame {k}")
+    assert any((outs[0][k] != outs[0][k + 1]).any().item() for k in range(n - 1))
+    o = sc.upload(oracle.Oracle(sc.width, sc.height, sc.shadow_size, sc.max_lights))
+    for k in (0, n - 1):
+        ref = o.render_frame(descs[k], sc.settings)
+        d = np.abs(outs[0][k].cpu().numpy().astype(np.int16) - ref.astype(np.int16))
+        assert d.max() <= 1 and (d != 0).mean() < 2e-3, f"frame {k}"
+    two.close(); one.close(); o.close()
+
+
 def test_materials_with_unequal_texture_sizes(pkg, oracle, hip):
     """equal-size triples are stored interleaved; this exercises the other layout (and the fallback 16x16 textures)."""
     rng = np.random.default_rng(21)
