@@ -232,7 +232,7 @@ def main():
                 dist.barrier()
             whole[name + "_ms"] = round((time.perf_counter() - t0) / 20 * 1e3, 4)
         r.set_option("shadow_cache", 1)
-        whole["note"] = ("arctic_render_frame_device per rank" + (" + arctic_gather_frame; the shadow map is drawn in light-space row shards "
+        whole["note"] = ("arctic_render_frame_device per rank, 20 frames enqueued back to back (static sun: two frames in flight; moving sun: shadow pass beside the visibility prepass)" + (" + arctic_gather_frame; the shadow map is drawn in light-space row shards "
                          "and all-gathered when the sun moves" if cabi else "") + "; vertex transform and triangle setup of the whole scene are "
                          "redundant per rank (DESIGN.md section 5)")
     except Exception as exc:
