@@ -143,9 +143,19 @@ struct ArcticRenderer {
     std::vector<Mesh> meshes;
     std::vector<TexDesc> tex;        // 3 per material (device pointers)
     std::vector<void *> tex_allocs;
-    DevBuf d_tex, d_lut, d_lights, d_light_pairs, d_shadow, d_env;
-    DevBuf d_shadow_blocks, d_shadow_bounds;   // min/max of the shadow map per 4x4 texel block / per 4x4-aligned 8x8 block (k_shadow_bounds)
-    bool bounds_valid = false;      // false whenever d_shadow has been written since the table was built
+    DevBuf d_tex, d_lut, d_lights, d_light_pairs, d_env;
+    // the shadow map, and the min/max of it per 4x4 texel block / per 4x4-aligned 8x8 block (k_shadow_bounds).  Two sets: a frame in
+    // flight that redraws the map draws into the other one while the previous frame's shading still reads this one (the second set
+    // is allocated when that first happens); `scur` names the map of the latest frame, the one every other call sees
+    DevBuf d_shadow_set[2], d_shadow_blocks_set[2], d_shadow_bounds_set[2];
+    bool bounds_valid_set[2] = {false, false};   // false whenever the map has been written since its table was built
+    int scur = 0;
+    hipEvent_t ev_shadow_released[2] = {nullptr, nullptr};   // like ev_released, for the shadow-map sets
+    bool shadow_released_valid[2] = {false, false};
+    DevBuf &d_shadow() { return d_shadow_set[scur]; }
+    DevBuf &d_shadow_blocks() { return d_shadow_blocks_set[scur]; }
+    DevBuf &d_shadow_bounds() { return d_shadow_bounds_set[scur]; }
+    bool &bounds_valid() { return bounds_valid_set[scur]; }
     uint32_t env_w = 0, env_h = 0;
     uint32_t n_lights = 0;
     // frame targets
@@ -331,7 +341,7 @@ int run_geometry(ArcticRenderer *r, const ArcticScene *sc, bool shadow_pass, hip
     const int set = shadow_pass ? 1 : r->fwd();
     ArcticRenderer::GeoSet &G = r->geo[set];
     // the pass's target is cleared by the vertex kernel's launch (or by a fill when there is nothing to draw)
-    unsigned long long *clear = shadow_pass ? r->d_shadow.as<unsigned long long>() : r->d_vis().as<unsigned long long>();
+    unsigned long long *clear = shadow_pass ? r->d_shadow().as<unsigned long long>() : r->d_vis().as<unsigned long long>();
     const unsigned long long clear_value = shadow_pass ? 0x3F8000003F800000ull : ~0ull;   // depth 1.0 (shadow_map_pass.cpp:124-131) / no triangle
     const size_t clear_count = shadow_pass ? ((size_t)r->shadow_size * r->shadow_size + 1) / 2 : r->n_tiles() * TILE_PIXELS;
     GeomParams gp;
@@ -400,7 +410,7 @@ int run_geometry(ArcticRenderer *r, const ArcticScene *sc, bool shadow_pass, hip
     uint32_t *dh = r->dh_counts + (shadow_pass ? 2 : 0), *dh_overflow = r->dh_counts + 4 + (shadow_pass ? 1 : 0);
     if (shadow_pass)
         HIPCHECK(r, launch_raster_depth(G.d_recs.as<SetupRec>(), G.d_rrecs.as<RasterRec>(), G.d_items.as<uint2>(), G.item_cap, counters, r->raster_blocks[1], d_gp,
-                                        r->d_shadow.as<uint32_t>(), dh, dh_overflow, stream));
+                                        r->d_shadow().as<uint32_t>(), dh, dh_overflow, stream));
     else
         HIPCHECK(r, launch_raster_vis(G.d_recs.as<SetupRec>(), G.d_rrecs.as<RasterRec>(), G.d_items.as<uint2>(), G.item_cap, counters, r->raster_blocks[0], d_gp,
                                       r->d_vis().as<unsigned long long>(), dh, dh_overflow, stream));
@@ -411,25 +421,25 @@ int run_geometry(ArcticRenderer *r, const ArcticScene *sc, bool shadow_pass, hip
 // launches, after the map was written
 int build_shadow_bounds(ArcticRenderer *r, hipStream_t stream) {
     const uint32_t nb = shadow_bounds_pitch(r->shadow_size);
-    if (!nb || r->bounds_valid) return ARCTIC_OK;
-    HIPCHECK(r, r->d_shadow_blocks.ensure((size_t)nb * nb * 8));
-    HIPCHECK(r, r->d_shadow_bounds.ensure((size_t)nb * nb * 8));
-    HIPCHECK(r, launch_shadow_bounds(r->d_shadow.as<float>(), r->shadow_size, r->d_shadow_blocks.as<float2>(), r->d_shadow_bounds.as<float2>(), stream));
-    r->bounds_valid = true;
+    if (!nb || r->bounds_valid()) return ARCTIC_OK;
+    HIPCHECK(r, r->d_shadow_blocks().ensure((size_t)nb * nb * 8));
+    HIPCHECK(r, r->d_shadow_bounds().ensure((size_t)nb * nb * 8));
+    HIPCHECK(r, launch_shadow_bounds(r->d_shadow().as<float>(), r->shadow_size, r->d_shadow_blocks().as<float2>(), r->d_shadow_bounds().as<float2>(), stream));
+    r->bounds_valid() = true;
     return ARCTIC_OK;
 }
 
 int pass_shadow_map(ArcticRenderer *r, const ArcticScene *sc, hipStream_t stream) {
     if (r->shadow_size == 0) return ARCTIC_OK;
     Range zone("Shadow Map Pass");
-    r->bounds_valid = false;
+    r->bounds_valid() = false;
     int rc = run_geometry(r, sc, true, stream);
     if (rc != ARCTIC_OK) return rc;
     if (r->shadow_sharded && r->comm && r->comm_world > 1) {
         // every rank has drawn ceil(S / world) rows of the map: one in-place all-gather (the send buffer is this rank's slice of the
         // receive buffer) completes it everywhere, on the pass's stream -- the shading pass needs it next
         const size_t per = (size_t)((r->shadow_size + (uint32_t)r->comm_world - 1) / (uint32_t)r->comm_world) * r->shadow_size;
-        float *base = r->d_shadow.as<float>();
+        float *base = r->d_shadow().as<float>();
         const int nrc = g_rccl.AllGather(base + per * (size_t)r->comm_rank, base, per, Rccl::Float32, r->comm, stream);
         if (nrc != 0) return r->fail(ARCTIC_E_DEVICE, "ncclAllGather(shadow map): %s", g_rccl.why(nrc));
     }
@@ -478,7 +488,7 @@ int fill_shade_params(ArcticRenderer *r, const ArcticScene *sc, const ArcticSett
     sp.tex = r->d_tex.as<TexDesc>();
     sp.n_materials = (uint32_t)(r->tex.size() / 3);
     sp.srgb_lut = r->d_lut.as<float>();
-    sp.shadow_map = r->shadow_size ? r->d_shadow.as<float>() : nullptr;
+    sp.shadow_map = r->shadow_size ? r->d_shadow().as<float>() : nullptr;
     sp.shadow_size = r->shadow_size;
     sp.lights = r->d_lights.as<float4>(); sp.light_pairs = r->d_light_pairs.as<float4>();
     sp.n_lights = r->n_lights;
@@ -511,7 +521,7 @@ int fill_shade_params(ArcticRenderer *r, const ArcticScene *sc, const ArcticSett
     if (nb && !(r->debug & 8)) {   // the min/max table of the shadow map: rebuilt whenever the map was written
         int rc = build_shadow_bounds(r, r->stream);
         if (rc != ARCTIC_OK) return rc;
-        sp.shadow_bounds = r->d_shadow_bounds.as<float2>(); sp.bounds_pitch = nb;
+        sp.shadow_bounds = r->d_shadow_bounds().as<float2>(); sp.bounds_pitch = nb;
     }
     return ARCTIC_OK;
 }
@@ -624,6 +634,8 @@ ArcticRenderer *arctic_create(const ArcticCreateInfo *info, char *err, uint64_t 
     if ((e = hipEventCreateWithFlags(&r->ev_prepass, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     for (hipEvent_t &ev : r->ev_released)
         if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    for (hipEvent_t &ev : r->ev_shadow_released)
+        if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     {
         hipDeviceProp_t prop;
         if ((e = hipGetDeviceProperties(&prop, r->device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
@@ -643,8 +655,8 @@ ArcticRenderer *arctic_create(const ArcticCreateInfo *info, char *err, uint64_t 
     if ((e = r->d_tex.ensure(48)) != hipSuccess) return bail("hipMalloc tex table", e);
     if (r->shadow_size) {
         size_t n = (size_t)r->shadow_size * r->shadow_size;
-        if ((e = r->d_shadow.ensure(n * 4 + 8)) != hipSuccess) return bail("hipMalloc shadow map", e);   // + 8: cleared in 8-byte words
-        if ((e = launch_fill_u32(r->d_shadow.as<uint32_t>(), 0x3F800000u, n, r->stream)) != hipSuccess) return bail("clear shadow map", e);
+        if ((e = r->d_shadow().ensure(n * 4 + 8)) != hipSuccess) return bail("hipMalloc shadow map", e);   // + 8: cleared in 8-byte words
+        if ((e = launch_fill_u32(r->d_shadow().as<uint32_t>(), 0x3F800000u, n, r->stream)) != hipSuccess) return bail("clear shadow map", e);
     }
     if (alloc_targets(r) != ARCTIC_OK) { say(r->err.c_str()); arctic_destroy(r); return nullptr; }
     if ((e = hipStreamSynchronize(r->stream)) != hipSuccess) return bail("sync", e);
@@ -661,13 +673,14 @@ void arctic_destroy(ArcticRenderer *r) {
     if (r->prepass_stream) { (void)hipStreamSynchronize(r->prepass_stream); (void)hipStreamDestroy(r->prepass_stream); }
     if (r->ev_prepass) (void)hipEventDestroy(r->ev_prepass);
     for (hipEvent_t ev : r->ev_released) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : r->ev_shadow_released) if (ev) (void)hipEventDestroy(ev);
     if (r->ev_fork) (void)hipEventDestroy(r->ev_fork);
     if (r->ev_shadow) (void)hipEventDestroy(r->ev_shadow);
     if (r->own_stream) { (void)hipStreamSynchronize(r->own_stream); (void)hipStreamDestroy(r->own_stream); }
     for (Mesh &m : r->meshes) { if (m.d_vertices) (void)hipFree(m.d_vertices); if (m.d_indices) (void)hipFree(m.d_indices); }
     for (void *p : r->tex_allocs) (void)hipFree(p);
-    DevBuf *bufs[] = {&r->d_tex, &r->d_lut, &r->d_lights, &r->d_light_pairs, &r->d_shadow, &r->d_env, &r->d_vis_set[0], &r->d_vis_set[1], &r->d_p0, &r->d_p1, &r->d_p2, &r->d_p3, &r->d_p4,
-                      &r->d_rgba8, &r->d_ldr, &r->d_hdr, &r->d_counter, &r->d_shadow_blocks, &r->d_shadow_bounds, &r->d_staging, &r->d_layout, &r->geo[0].d_xverts, &r->geo[1].d_xverts, &r->geo[2].d_xverts,
+    DevBuf *bufs[] = {&r->d_tex, &r->d_lut, &r->d_lights, &r->d_light_pairs, &r->d_shadow_set[0], &r->d_shadow_set[1], &r->d_env, &r->d_vis_set[0], &r->d_vis_set[1], &r->d_p0, &r->d_p1, &r->d_p2, &r->d_p3, &r->d_p4,
+                      &r->d_rgba8, &r->d_ldr, &r->d_hdr, &r->d_counter, &r->d_shadow_blocks_set[0], &r->d_shadow_blocks_set[1], &r->d_shadow_bounds_set[0], &r->d_shadow_bounds_set[1], &r->d_staging, &r->d_layout, &r->geo[0].d_xverts, &r->geo[1].d_xverts, &r->geo[2].d_xverts,
                       &r->geo[2].d_recs, &r->geo[2].d_rrecs, &r->geo[2].d_clip_list, &r->geo[2].d_rec_of, &r->geo[2].d_items, &r->tables[2].d,
                       &r->geo[0].d_recs, &r->geo[0].d_rrecs, &r->geo[0].d_clip_list, &r->geo[0].d_rec_of, &r->geo[0].d_items,
                       &r->geo[1].d_recs, &r->geo[1].d_rrecs, &r->geo[1].d_clip_list, &r->geo[1].d_rec_of, &r->geo[1].d_items, &r->d_geo_counters, &r->d_stage, &r->tables[0].d, &r->tables[1].d};
@@ -852,11 +865,22 @@ int arctic_render_frame_device(ArcticRenderer *r, const ArcticScene *scene, cons
     // shading pass.  (Not with a sharded map: its all-gather stays on the main stream.  ARCTIC_OPT_DEBUG bit 7: one after the other.)
     const bool redraw = r->shadow_size != 0 && (!r->shadow_cache || key != r->shadow_key);
     const bool beside = redraw && !(r->debug & 128) && !(r->shadow_sharded && r->comm && r->comm_world > 1);
+    // ... and with frames in flight into the OTHER shadow map, ordered only after what had been enqueued when that one was last
+    // left: the pass then runs beside the previous frame's shading too
+    const bool shadow_in_flight = beside && r->frames_in_flight > 1;
     if (redraw) {
         r->shadow_key.clear();
         if (beside) {
-            HIPCHECK(r, hipEventRecord(r->ev_fork, r->stream));
-            HIPCHECK(r, hipStreamWaitEvent(r->shadow_stream, r->ev_fork, 0));
+            if (shadow_in_flight) {
+                HIPCHECK(r, hipEventRecord(r->ev_shadow_released[r->scur], r->stream));
+                r->shadow_released_valid[r->scur] = true;
+                r->scur ^= 1;
+                HIPCHECK(r, r->d_shadow().ensure((size_t)r->shadow_size * r->shadow_size * 4 + 8));   // first use of the second map (cleared by the pass itself)
+                if (r->shadow_released_valid[r->scur]) HIPCHECK(r, hipStreamWaitEvent(r->shadow_stream, r->ev_shadow_released[r->scur], 0));
+            } else {
+                HIPCHECK(r, hipEventRecord(r->ev_fork, r->stream));
+                HIPCHECK(r, hipStreamWaitEvent(r->shadow_stream, r->ev_fork, 0));
+            }
             rc = pass_shadow_map(r, scene, r->shadow_stream);
             if (rc == ARCTIC_OK && !(r->debug & 8)) rc = build_shadow_bounds(r, r->shadow_stream);
             HIPCHECK(r, hipEventRecord(r->ev_shadow, r->shadow_stream));
@@ -869,9 +893,9 @@ int arctic_render_frame_device(ArcticRenderer *r, const ArcticScene *scene, cons
     const bool vis_path = r->visbuffer;
     // frames in flight: this frame's visibility prepass goes to the other table set, on prepass_stream, ordered only after what
     // the main stream had enqueued when that set was last left -- so it runs beside the shading of the previous frame
-    // (not in a frame that redraws the shadow map: the map exists once, so its pass has to follow the previous frame's shading and
-    // precede this one's -- a prepass running ahead would only compete with it: 0.50 against 0.46 ms at 4K)
-    const bool in_flight = vis_path && r->frames_in_flight > 1 && !redraw;
+    // (not in a frame that redraws the shadow map on the main stream -- sharded map, debug bit 7 --: that pass has to follow the previous
+    // frame's shading and precede this one's, a prepass running ahead would only compete with it)
+    const bool in_flight = vis_path && r->frames_in_flight > 1 && (!redraw || shadow_in_flight);
     if (in_flight) {
         HIPCHECK(r, hipEventRecord(r->ev_released[r->cur], r->stream));   // everything that reads or writes the set being left is enqueued by now
         r->released_valid[r->cur] = true;
@@ -1007,7 +1031,7 @@ int arctic_read_shadow_map(ArcticRenderer *r, float *depth) {
     if (rc) return rc;
     HIPCHECK(r, hipStreamSynchronize(r->stream));
     if (int ov = check_item_overflow(r)) return ov;
-    HIPCHECK(r, hipMemcpy(depth, r->d_shadow.p, (size_t)r->shadow_size * r->shadow_size * 4, hipMemcpyDeviceToHost));
+    HIPCHECK(r, hipMemcpy(depth, r->d_shadow().p, (size_t)r->shadow_size * r->shadow_size * 4, hipMemcpyDeviceToHost));
     return ARCTIC_OK;
 }
 
@@ -1017,8 +1041,8 @@ int arctic_write_shadow_map(ArcticRenderer *r, const float *depth) {
     int rc = select_device(r);
     if (rc) return rc;
     HIPCHECK(r, hipStreamSynchronize(r->stream));
-    HIPCHECK(r, hipMemcpy(r->d_shadow.p, depth, (size_t)r->shadow_size * r->shadow_size * 4, hipMemcpyHostToDevice));
-    r->shadow_key.clear(); r->bounds_valid = false;
+    HIPCHECK(r, hipMemcpy(r->d_shadow().p, depth, (size_t)r->shadow_size * r->shadow_size * 4, hipMemcpyHostToDevice));
+    r->shadow_key.clear(); r->bounds_valid() = false;
     return ARCTIC_OK;
 }
 
@@ -1170,10 +1194,10 @@ int arctic_comm_init(ArcticRenderer *r, const void *id_bytes, int rank, int worl
         const uint32_t per = (r->shadow_size + (uint32_t)world - 1) / (uint32_t)world;
         if ((size_t)per * world > r->shadow_size) {
             const size_t n = (size_t)per * world * r->shadow_size;
-            if (r->d_shadow.cap < n * 4) {
-                HIPCHECK(r, r->d_shadow.ensure(n * 4 + 8));
-                HIPCHECK(r, launch_fill_u32(r->d_shadow.as<uint32_t>(), 0x3F800000u, n, r->stream));
-                r->shadow_key.clear(); r->bounds_valid = false;
+            if (r->d_shadow().cap < n * 4) {
+                HIPCHECK(r, r->d_shadow().ensure(n * 4 + 8));
+                HIPCHECK(r, launch_fill_u32(r->d_shadow().as<uint32_t>(), 0x3F800000u, n, r->stream));
+                r->shadow_key.clear(); r->bounds_valid() = false;
             }
         }
     }

@@ -270,7 +270,8 @@ int arctic_stats(ArcticRenderer *r, uint64_t *out, uint32_t n);
 #define ARCTIC_OPT_SHADOW_CACHE      9 /* 1 (default) = arctic_render_frame redraws the shadow map only when the sun, the objects or the mesh list changed
                                           (byte-compared); 0 = every frame like the reference (renderer.cpp:300-337).  Same image either way. */
 #define ARCTIC_OPT_FRAMES_IN_FLIGHT  15 /* 2 (default) = arctic_render_frame runs the visibility prepass of a frame on a second stream, into a second set of
-                                          tables, beside the shading of the frame before it (the reference keeps 3 frames in flight, rhi.hpp:25); every call
+                                          tables (and, when the shadow map is redrawn, into a second map), beside the shading of the frame before it (the reference keeps
+                                          3 frames in flight, rhi.hpp:25); every call
                                           still enqueues one whole frame and the output is complete after arctic_flush / in stream order on the main
                                           stream.  1 = one frame at a time on one stream.  Same images. */
 #define ARCTIC_OPT_VISBUFFER        10 /* 1 (default) = arctic_render_frame shades straight from the visibility plane, no 76 B/px G-buffer round trip

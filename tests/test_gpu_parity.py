@@ -359,8 +359,8 @@ def test_render_frame_redraws_the_shadow_map_only_when_its_inputs_change(pkg, or
 
 def test_frames_in_flight_give_the_same_frames(pkg, oracle, hip):
     """ARCTIC_OPT_FRAMES_IN_FLIGHT = 2 (default): the visibility prepass of a frame runs on its own stream, into the other set of
-    tables, beside the shading of the frame before.  A run of frames whose camera moves every frame and whose objects move now and
-    then -- each frame enqueued without waiting for the one before -- must equal the same run with one frame at a time, byte for
+    tables (and, when the map is redrawn, the other shadow map), beside the shading of the frame before.  A run of frames whose camera
+    moves every frame and whose objects and sun move now and then -- each frame enqueued without waiting for the one before -- must equal the same run with one frame at a time, byte for
     byte, also with pass-level calls (which see the latest frame's set) and G-buffer read-backs in between."""
     import copy
     import torch
@@ -378,6 +378,8 @@ def test_frames_in_flight_give_the_same_frames(pkg, oracle, hip):
         desc.camera["rotation"] = (-15.0 + k, 7.0 * k)
         if k in (4, 9):
             desc.objects["trs"][8 + k][12] += 0.5          # a column moves: its table set is uploaded again, the other one a frame later
+        if k in (2, 3, 6, 10):
+            desc.sun = dict(desc.sun, rotation=(desc.sun["rotation"][0] - 1.5, desc.sun["rotation"][1] + 4.0))   # the sun moves: the map is redrawn, into the other shadow map
         descs.append(desc)
     for k in range(n):                                      # no flush inside the loop: frames are in flight
         for r, o in zip((two, one), outs):

@@ -20,7 +20,9 @@ for cfg, scale in ((3, 1.0), (2, 1.0), (4, 0.5)):
         if k % 5 == 3: desc.objects["trs"][int(rng.integers(0, len(desc.objects)))][12] += 0.25
         if k % 7 == 6: desc.sun["rotation"] = (float(desc.sun["rotation"][0] + 1.0), float(desc.sun["rotation"][1]))   # a shadow redraw in between
         descs.append(desc)
-    for rep in range(3):
+    for rep in range(4):
+        if rep == 3:   # the last repetition redraws the shadow map in every frame: both shadow maps in flight all the time
+            two.set_option("shadow_cache", 0); one.set_option("shadow_cache", 0)
         for k in range(n):
             for r, o in zip((two, one), outs): r.render_frame_device(descs[k], sc.settings, o[k].data_ptr())
         two.flush(); one.flush()
