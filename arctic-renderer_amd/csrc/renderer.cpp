@@ -174,6 +174,12 @@ struct ArcticRenderer {
     DevBuf d_geo_counters, d_stage;
     hipStream_t shadow_stream = nullptr;            // arctic_render_frame draws the shadow map here while the main stream runs the visibility prepass
     hipEvent_t ev_fork = nullptr, ev_shadow = nullptr;
+    // The shadow pass has ONE set of scratch (geo[1], tables[1], its four counters) whichever stream it runs on -- the main stream
+    // (arctic_pass_shadow_map, a sharded map, debug bit 7) or shadow_stream (whole frames).  ev_shadow_scratch marks the end of the
+    // last shadow pass on shadow_scratch_stream; a pass on another stream waits for it first, so two never share the scratch.
+    hipEvent_t ev_shadow_scratch = nullptr;
+    hipStream_t shadow_scratch_stream = nullptr;
+    bool shadow_scratch_valid = false;
     // Frames in flight (arctic_render_frame, ARCTIC_OPT_FRAMES_IN_FLIGHT = 2): the visibility prepass of frame k + 1 runs on
     // prepass_stream while the main stream still shades frame k, so there are two sets of what the prepass writes and the
     // shading reads -- visibility plane, vertex / record / item tables, object tables -- and `cur` names the set of the latest frame
@@ -433,7 +439,11 @@ int pass_shadow_map(ArcticRenderer *r, const ArcticScene *sc, hipStream_t stream
     if (r->shadow_size == 0) return ARCTIC_OK;
     Range zone("Shadow Map Pass");
     r->bounds_valid() = false;
+    if (r->shadow_scratch_valid && r->shadow_scratch_stream != stream)   // the previous shadow pass ran on another stream: it owns the scratch until it ends
+        HIPCHECK(r, hipStreamWaitEvent(stream, r->ev_shadow_scratch, 0));
     int rc = run_geometry(r, sc, true, stream);
+    HIPCHECK(r, hipEventRecord(r->ev_shadow_scratch, stream));
+    r->shadow_scratch_stream = stream; r->shadow_scratch_valid = true;
     if (rc != ARCTIC_OK) return rc;
     if (r->shadow_sharded && r->comm && r->comm_world > 1) {
         // every rank has drawn ceil(S / world) rows of the map: one in-place all-gather (the send buffer is this rank's slice of the
@@ -630,6 +640,7 @@ ArcticRenderer *arctic_create(const ArcticCreateInfo *info, char *err, uint64_t 
     if ((e = hipStreamCreateWithFlags(&r->shadow_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     if ((e = hipEventCreateWithFlags(&r->ev_fork, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&r->ev_shadow, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreateWithFlags(&r->ev_shadow_scratch, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipStreamCreateWithFlags(&r->prepass_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     if ((e = hipEventCreateWithFlags(&r->ev_prepass, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     for (hipEvent_t &ev : r->ev_released)
@@ -676,6 +687,7 @@ void arctic_destroy(ArcticRenderer *r) {
     for (hipEvent_t ev : r->ev_shadow_released) if (ev) (void)hipEventDestroy(ev);
     if (r->ev_fork) (void)hipEventDestroy(r->ev_fork);
     if (r->ev_shadow) (void)hipEventDestroy(r->ev_shadow);
+    if (r->ev_shadow_scratch) (void)hipEventDestroy(r->ev_shadow_scratch);
     if (r->own_stream) { (void)hipStreamSynchronize(r->own_stream); (void)hipStreamDestroy(r->own_stream); }
     for (Mesh &m : r->meshes) { if (m.d_vertices) (void)hipFree(m.d_vertices); if (m.d_indices) (void)hipFree(m.d_indices); }
     for (void *p : r->tex_allocs) (void)hipFree(p);

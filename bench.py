@@ -4,6 +4,10 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
+Both forms run N ranks, one per GPU: under a launcher (WORLD_SIZE in the environment) this process is one of them; without one
+and N > 1 it starts the N ranks itself (launch_ranks: child processes, before any GPU call), relays rank 0's JSON line and exits
+non-zero if any rank fails.  The first multi-rank step is compared byte for byte with a single-device frame before anything is timed.
+
 A "step" is ONE pass of the hot path (ps_main + post_process: G-buffer -> BRDF + PCF shadow +
 point lights -> tonemap + gamma -> RGBA8) over one 4K frame's G-buffer, resident in HBM.  The
 workload is BASELINE.json configs[2] (the config the metric is quoted on): the Sponza stand-in
@@ -58,6 +62,63 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment): start the N ranks here -- one child
+    process per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set the way torch.distributed.run sets them --
+    BEFORE this process has made any GPU call (it never makes one: a process that has initialised the GPU must not fork + exec
+    on this pool).  Rank 0's stdout (the one JSON line) is relayed; the exit code is non-zero when any rank fails, and the
+    other ranks are then stopped by their exact pids (they may be blocked in a collective)."""
+    import socket
+    import subprocess
+    import threading
+    share = os.environ.get("ARCTIC_BENCH_SHARE_GPU") == "1"
+    if not share:
+        import torch
+        have = torch.cuda.device_count()      # counts devices without initialising them (no HIP context in this process)
+        if have < n:
+            raise SystemExit(f"bench.py --gpus {n}: this node shows {have} HIP device(s); the multi-GPU leg needs one GPU per rank "
+                             f"(a rehearsal of the N-rank code path on one GPU: ARCTIC_BENCH_BACKEND=gloo ARCTIC_BENCH_SHARE_GPU=1)")
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = str(s.getsockname()[1])
+        s.close()
+    procs, lines = [], []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, ARCTIC_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this pool
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if rank == 0 else sys.stderr, text=(rank == 0)))
+    reader = threading.Thread(target=lambda: lines.extend(procs[0].stdout), daemon=True)
+    reader.start()
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        time.sleep(0.1)
+        failed = next((k for k, p in enumerate(procs) if p.poll() not in (None, 0)), None)
+    if failed is None:
+        failed = next((k for k, p in enumerate(procs) if p.returncode != 0), None)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.time() + 10
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+        log(f"[bench] rank {failed} exited with code {procs[failed].returncode}; the other ranks were stopped")
+        raise SystemExit(procs[failed].returncode or 1)
+    reader.join(timeout=10)
+    out = [l for l in lines if l.strip()]
+    if not out:
+        raise SystemExit("[bench] rank 0 printed no result line")
+    sys.stdout.write(out[-1] if out[-1].endswith("\n") else out[-1] + "\n")
+    sys.stdout.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -71,6 +132,9 @@ def main():
                     "for a rocprofv3 --stats run of this command, whose kernel average should be the timed launches'")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus, sys.argv[1:])      # no launcher around us: be the launcher (no GPU call in this process)
+
     import torch
     import torch.distributed as dist
 
@@ -78,7 +142,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+        log(f"warning: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}; running {world} ranks (n_gpus in the line is {world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product has no CPU path")
     backend = os.environ.get("ARCTIC_BENCH_BACKEND", "nccl")    # "gloo" + ARCTIC_BENCH_SHARE_GPU=1: rehearse N ranks on one GPU
@@ -103,17 +167,36 @@ def main():
         r = sc.upload(pkg.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights, device=local))
     cabi = False
     if world > 1 and backend == "nccl" and os.environ.get("ARCTIC_BENCH_EXCHANGE", "cabi") == "cabi":
-        try:   # the exchange below Python: an RCCL communicator owned by the handle; the id travels over torch.distributed
-            box = [pkg.Renderer.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            r.comm_init(box[0], rank, world)
-            r.set_option("shadow_sharded", 1)
-            cabi = True
-        except Exception as exc:
-            log(f"[bench] rank {rank}: C-ABI exchange unavailable ({exc}); falling back to torch.distributed")
-        flag = torch.tensor([1 if cabi else 0], device="cuda")
+        # The exchange below Python: an RCCL communicator owned by the handle; the 128-byte id travels over torch.distributed.
+        # Every step here is a collective that EVERY rank executes whatever happened before it on that rank (a rank that skipped
+        # one would leave the others blocked in it): broadcast (None when rank 0 could not make an id) -> init -> vote.
+        uid = None
+        if rank == 0:
+            try:
+                uid = pkg.Renderer.comm_unique_id()
+            except Exception as exc:
+                log(f"[bench] rank 0: no RCCL unique id ({exc})")
+        box = [uid]
+        dist.broadcast_object_list(box, src=0)
+        mine = 0
+        if box[0] is not None:
+            try:
+                r.comm_init(box[0], rank, world)
+                mine = 1
+            except Exception as exc:
+                log(f"[bench] rank {rank}: arctic_comm_init failed ({exc})")
+        flag = torch.tensor([mine], device="cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         cabi = bool(flag.item())
+        if cabi:
+            r.set_option("shadow_sharded", 1)
+        else:       # lost vote: no rank keeps a communicator (a sharded shadow pass would all-gather with ranks that have none)
+            log(f"[bench] rank {rank}: C-ABI exchange not available on every rank; falling back to torch.distributed")
+            try:
+                r.comm_destroy()
+            except Exception:
+                pass
+            r.set_option("shadow_sharded", 0)
     r.pass_shadow_map(sc.desc)      # untimed: the producers of the hot path's inputs
     r.pass_gbuffer(sc.desc)
     r.flush()
@@ -167,6 +250,26 @@ def main():
             if pending[b] is not None:
                 finish(b)
 
+    verified = None
+    if world > 1 and os.environ.get("ARCTIC_BENCH_VERIFY", "1") != "0":
+        # The multi-rank invariant, end to end, on the FIRST multi-rank step and before anything is timed: the gathered,
+        # de-interleaved frame == a single-device frame, byte for byte.  A mismatch ends the run on every rank (non-zero exit):
+        # an unverified exchange path is never timed.  (ARCTIC_BENCH_VERIFY=0 skips it.)
+        step(); drain(); r.flush(); torch.cuda.synchronize()
+        same = 1
+        if rank == 0:
+            full = sc.upload(pkg.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights, device=local))
+            ref = full.render_frame(sc.desc, sc.settings)
+            full.close()
+            same = int(bool((frame.cpu().numpy() == ref).all()))
+            log(f"[bench] verify: {world}-rank frame identical to the single-device frame: {bool(same)}")
+        t = torch.tensor([same], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if not int(t.item()):
+            r.close()
+            raise SystemExit("multi-rank frame differs from the single-device frame")
+        verified = True
+
     # isolated launches, each between its own pair of HIP events (p10/p50/p90 in the line; also brings clocks and caches to
     # their steady state before the W warm-up steps)
     iters = max(10, min(args.steps, 50))
@@ -192,6 +295,10 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t_start
     kernel_ms = ev0.elapsed_time(ev1) / args.steps   # HIP events on the launch stream around the K timed launches
+    kernel_ms_source = "HIP events on the launch stream around the K timed steps / K"
+    if world > 1:   # there the span between the events includes the waits for the gathers that free the shard buffers: not kernel time
+        kernel_ms = float(np.median(ms))
+        kernel_ms_source = "median of this rank's isolated launches (its own shard), each between its own pair of HIP events"
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -238,15 +345,6 @@ def main():
     except Exception as exc:
         log(f"[bench] whole-frame timing skipped: {exc}")
     r.set_stream(None)
-    if world > 1 and rank == 0 and os.environ.get("ARCTIC_BENCH_VERIFY") == "1":
-        # the multi-rank invariant, end to end: the gathered, de-interleaved frame == a single-device frame, byte for byte
-        full = sc.upload(pkg.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights, device=local))
-        ref = full.render_frame(sc.desc, sc.settings)
-        full.close()
-        same = bool((frame.cpu().numpy() == ref).all())
-        log(f"[bench] verify: {world}-rank frame identical to the single-device frame: {same}")
-        if not same:
-            raise SystemExit("multi-rank frame differs from the single-device frame")
     # shaded pixels = pixels with geometry (100 % in this scene); counted, not assumed
     _, mat, _, _ = r.read_gbuffer(want=("material",))
     shaded_local = int((mat != 0xFFFFFFFF).sum())
@@ -302,7 +400,7 @@ def main():
                 "kernel": f"k_material<{2 if n_lights > 16 else 1}> (the whole pass in one launch: material fetch, shadow test, "
                           f"{'packed' if n_lights > 16 else 'scalar'} light loop, tonemap, store)",
                 "kernel_ms": round(kernel_ms, 4),
-                "kernel_ms_source": "HIP events on the launch stream around the K timed steps / K",
+                "kernel_ms_source": kernel_ms_source,
                 "isolated_launch_ms_p10_p50_p90": [round(float(np.percentile(ms, q)), 4) for q in (10, 50, 90)],
                 "bytes_per_pixel": BYTES_PER_PIXEL}
         if lit_px is not None:
@@ -334,6 +432,7 @@ def main():
                                    f"shadow {sc.shadow_size}^2 PCF 5x5, tonemap {sc.settings[0]}, {len(sc.materials)} materials; shading pass over a resident G-buffer",
                        "triangles": sc.n_triangles, "shaded_pixels": shaded, "sharding": f"{BAND}-row bands round-robin over {world} ranks, RCCL gather to rank 0" if world > 1 else "none",
                        "scale": args.scale, "whole_frame": whole or None,
+                       "verified_against_single_device_frame": verified,
                        "exchange_path": ("C-ABI arctic_gather_frame (RCCL send/recv + placement kernel)" if cabi else "torch.distributed gather + index_copy_") if world > 1 else None,
                        "exchange": None if gather_ms is None else {
                            "gather_ms": round(gather_ms, 4), "bytes_per_sender": int(pad) * sc.width * 4,

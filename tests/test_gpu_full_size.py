@@ -87,6 +87,49 @@ def test_config2_1080p_2048_shadow_against_oracle(pkg, oracle, hip):
     r.close(); o.close()
 
 
+def test_config4_4k_256_lights(pkg, oracle, hip):
+    """config 4 at its real size: 3840x2160, 256 point lights (forward.hlsl:224-231 far beyond renderer.hpp:22's cap of 16), the
+    4000^2 map.  Prepass bit for bit over the whole frame; three 64-row stripes against the float64 oracle (the whole frame at 257
+    light evaluations per pixel is minutes of CPU time); exact culling on == off; and the sharding config 4 is defined with: the
+    frame rendered as 2 / 4 / 8 interleaved 16-row-band shards (one handle each, all on this device) and put together by
+    arctic_assemble_frame -- the root's half of arctic_gather_frame -- must be the single-device frame byte for byte."""
+    import torch
+    sc = pkg.scenes.config4(scale=1.0)
+    assert (sc.width, sc.height, sc.shadow_size, len(sc.lights)) == (3840, 2160, 4000, 256)
+    o, r = prepass_pair(pkg, oracle, hip, sc)
+    attrs, mat = assert_prepass_bit_exact(sc, o, r)
+    r.pass_shade(sc.desc, sc.settings)
+    h_ldr, _, h_rgba = (x.copy() for x in r.read_output())
+    assert np.isfinite(h_ldr).all() and (h_rgba[..., 3] == 255).all()
+    for y0 in (300, 1050, 1850):   # ceiling / far wall, the middle of the atrium, the sunlit floor
+        ref = o.shade_gbuffer(sc.desc, sc.settings, attrs[y0:y0 + 64], mat[y0:y0 + 64], threads=oracle.hardware_threads(), want=("ldr", "rgba8"))
+        worst = assert_image_parity(ref["ldr"], ref["rgba8"], h_ldr[y0:y0 + 64], h_rgba[y0:y0 + 64])
+        print(f"config 4 at 4K, rows {y0}..{y0 + 64}: max |ldr - oracle| = {worst:.2e}")
+    del attrs, mat
+    o.close()
+    r.set_option("culling", 0)     # every pixel through the 256-light loop: same image
+    r.pass_shade(sc.desc, sc.settings)
+    assert np.abs(r.read_output()[0] - h_ldr).max() <= 2e-6
+    r.set_option("culling", 1)
+    frame = r.render_frame(sc.desc, sc.settings)   # the frame path from the visibility plane: same bytes
+    np.testing.assert_array_equal(frame, h_rgba)
+    for world in (2, 4, 8):
+        parts = []
+        for k in range(world):
+            s = sc.upload(hip.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights, band_rows=16, shard=(k, world)))
+            parts.append(torch.as_tensor(s.render_frame(sc.desc, sc.settings).reshape(-1), device="cuda"))
+            s.close()
+        assert sum(p.numel() for p in parts) == sc.width * sc.height * 4     # 135 bands: unequal shards at 2, 4 and 8 ranks
+        staging = torch.cat(parts)
+        out = torch.zeros((sc.height, sc.width, 4), dtype=torch.uint8, device="cuda")
+        a = sc.upload(hip.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights, band_rows=16, shard=(world - 1, world)))
+        a.assemble_frame(staging.data_ptr(), out.data_ptr(), world)
+        a.flush()
+        a.close()
+        np.testing.assert_array_equal(out.cpu().numpy(), h_rgba)
+    r.close()
+
+
 def test_config5_8k_prepass_bitwise_and_oracle_stripes(pkg, oracle, hip):
     """config 5 at 7680x4320 with 1024 point lights and the 4096^2 map: shadow map and G-buffer bit for bit over all 33 M
     pixels; the shaded image against the oracle on stripes (64 rows each) through lit and shadowed regions -- the whole 8K

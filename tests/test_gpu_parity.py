@@ -404,6 +404,33 @@ def test_frames_in_flight_give_the_same_frames(pkg, oracle, hip):
     two.close(); one.close(); o.close()
 
 
+def test_shadow_passes_on_two_streams_never_share_their_scratch(pkg, hip):
+    """arctic_pass_shadow_map runs on the main stream, a frame in flight redraws the map on the handle's shadow stream -- and both use
+    the ONE set of shadow-pass scratch (transformed vertices, records, work items, counters).  Pass-level shadow passes still queued on
+    the main stream followed at once, without a flush, by a frame with another sun must give the frame one-frame-at-a-time gives."""
+    import copy
+    import torch
+    sc = pkg.scenes.config3(scale=0.25)
+    two = sc.upload(hip.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights))
+    one = sc.upload(hip.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights))
+    one.set_option("frames_in_flight", 1)
+    n = 6
+    outs = [[torch.zeros((sc.height, sc.width, 4), dtype=torch.uint8, device="cuda") for _ in range(n)] for _ in range(2)]
+    for k in range(n):
+        a, b = copy.deepcopy(sc.desc), copy.deepcopy(sc.desc)
+        a.sun = dict(a.sun, rotation=(a.sun["rotation"][0] + 2.0 * k, a.sun["rotation"][1] - 9.0 * k))
+        b.sun = dict(b.sun, rotation=(b.sun["rotation"][0] - 1.0 - k, b.sun["rotation"][1] + 5.0 * k + 3.0))
+        for r, o in zip((two, one), outs):
+            for _ in range(3):
+                r.pass_shadow_map(a)                      # main stream, still queued when ...
+            r.render_frame_device(b, sc.settings, o[k].data_ptr())   # ... this frame's shadow pass starts on the shadow stream
+    two.flush(); one.flush()
+    for k in range(n):
+        np.testing.assert_array_equal(outs[0][k].cpu().numpy(), outs[1][k].cpu().numpy(), err_msg=f"frame {k}")
+    assert any((outs[0][k] != outs[0][k + 1]).any().item() for k in range(n - 1))
+    two.close(); one.close()
+
+
 def test_materials_with_unequal_texture_sizes(pkg, oracle, hip):
     """equal-size triples are stored interleaved; this exercises the other layout (and the fallback 16x16 textures)."""
     rng = np.random.default_rng(21)
