@@ -55,7 +55,16 @@ SIGNATURES = {
     "arctic_comm_destroy": (_i32, [_vp]),
     "arctic_gather_frame": (_i32, [_vp, _vp, _vp, _i32]),
     "arctic_assemble_frame": (_i32, [_vp, _vp, _vp, _u32, _vp]),
+    # ... and their plan as pure host functions (no device needed)
+    "arctic_exchange_plan": (_i32, [_u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp]),
+    "arctic_exchange_row_source": (_i32, [_u32, _u32, _u32, _u32, _vp, _vp, _vp]),
+    "arctic_exchange_transfers": (_i32, [_u32, _u32, _i32, _i32, _vp, _vp, _vp, _u32]),
 }
+
+
+class CTransfer(C.Structure):
+    """ArcticTransfer (include/arctic_dist.h)"""
+    _fields_ = [("peer", C.c_int32), ("is_send", C.c_int32), ("staging_offset", C.c_uint64), ("bytes", C.c_uint64)]
 
 
 def header_symbols():

@@ -113,6 +113,23 @@ __host__ __device__ inline bool row_owned(int ty_rel, int band_tiles, int n, int
 __host__ __device__ inline int row_local(int ty_rel, int band_tiles, int n) { return band_tiles == 0 ? ty_rel : ((ty_rel / band_tiles) / n) * band_tiles + ty_rel % band_tiles; }
 __host__ __device__ inline int row_global(int lt, int band_tiles, int n, int r) { return band_tiles == 0 ? lt : ((lt / band_tiles) * n + r) * band_tiles + lt % band_tiles; }
 
+// Which shard holds frame row y, and as which of its rows (the exchange step, include/arctic_dist.h).  Interleaved sharding
+// (band_rows > 0): row y belongs to band y / band_rows, the band to rank band % world, and is that rank's local row
+// (band / world) * band_rows + y % band_rows (all its earlier bands are full).  Row ranges (band_rows == 0): ranges[2k],
+// ranges[2k+1] = rank k's [begin, end); false for a row outside every range.  One definition for the placement kernel
+// (exchange.hip) and the host-side plan (arctic_exchange_plan / arctic_exchange_row_source).
+__host__ __device__ inline bool shard_row_source(uint32_t y, uint32_t band_rows, uint32_t world, const uint32_t *ranges, uint32_t &owner, uint32_t &local) {
+    if (band_rows) {
+        const uint32_t band = y / band_rows;
+        owner = band % world;
+        local = (band / world) * band_rows + y % band_rows;
+        return true;
+    }
+    for (uint32_t k = 0; k < world; ++k)
+        if (y >= ranges[2 * k] && y < ranges[2 * k + 1]) { owner = k; local = y - ranges[2 * k]; return true; }
+    return false;
+}
+
 // texture descriptor, 16 B; three consecutive per material: diffuse (sRGB), normal, metal-rough
 // When a material's three images have equal size they are stored PACKED: one image of 8-byte texels holding exactly the
 // eight channels ps_main reads (diffuse rgb, normal rgb, metal-rough gb; layout in shade.hip), so one bilinear footprint =

@@ -6,24 +6,14 @@ namespace arctic {
 
 namespace {
 
-// one workgroup per frame row.  Interleaved sharding (band_rows > 0): row y belongs to band y / band_rows, the band to rank
-// band % world, and is that rank's local row (band / world) * band_rows + y % band_rows (all earlier bands are full).
-// Row ranges (band_rows == 0): ranges[2k], ranges[2k+1] = rank k's [begin, end); rows outside every range are left alone.
+// one workgroup per frame row; shard_row_source (common.h) names the shard and the row inside it -- the same function the host-side
+// plan (arctic_exchange_plan) is made of; rows outside every range are left alone.
 __global__ __launch_bounds__(256) void k_place_rows(const uint8_t *__restrict__ staging, uint8_t *__restrict__ frame, uint32_t width, uint32_t height,
                                                     uint32_t band_rows, uint32_t world, const uint32_t *__restrict__ ranges,
                                                     const unsigned long long *__restrict__ shard_offset /* world entries: byte offset of rank k's shard */) {
     const uint32_t y = blockIdx.x;
     uint32_t owner = 0, local = 0;
-    if (band_rows) {
-        const uint32_t band = y / band_rows;
-        owner = band % world;
-        local = (band / world) * band_rows + y % band_rows;
-    } else {
-        bool found = false;
-        for (uint32_t k = 0; k < world; ++k)
-            if (y >= ranges[2 * k] && y < ranges[2 * k + 1]) { owner = k; local = y - ranges[2 * k]; found = true; break; }
-        if (!found) return;
-    }
+    if (!shard_row_source(y, band_rows, world, ranges, owner, local)) return;
     const size_t row_bytes = (size_t)width * 4;
     const uint8_t *src = staging + shard_offset[owner] + (size_t)local * row_bytes;
     uint8_t *dst = frame + (size_t)y * row_bytes;

@@ -209,10 +209,11 @@ struct ArcticRenderer {
     hipEvent_t ev_main = nullptr;
     struct InFlight { const void *ptr = nullptr; hipEvent_t done = nullptr; } inflight[4];   // gathers that still read a shard buffer
     std::vector<uint32_t> peer_rows, peer_ranges;    // rows of every rank's shard; [begin, end) of every rank (row-range shards)
+    std::vector<uint64_t> peer_offset;               // byte offset of every rank's shard in the root's staging buffer (arctic_exchange_plan)
+    uint64_t staging_bytes = 0;
     DevBuf d_staging, d_layout;                       // root: all shards back to back; ranges (2 u32 per rank) + byte offsets (u64 per rank)
     uint32_t layout_world = 0; bool layout_from_comm = false;
     bool shadow_sharded = false;                      // ARCTIC_OPT_SHADOW_SHARDED
-    uint32_t shadow_rows_alloc = 0;                   // rows the shadow buffer holds (>= shadow_size: padded to world * ceil(S / world))
     uint32_t *dh_counts = nullptr;  // the device's address of h_counts
     uint32_t *h_counts = nullptr;   // pinned, mapped: [0] records, [1] work items (forward), [2], [3] the same for the shadow pass, [4], [5] item-table overflow flags
     std::string err;
@@ -238,6 +239,15 @@ struct ArcticRenderer {
     } while (0)
 
 namespace {
+
+// bytes of a shadow-map buffer: S rows, or -- with a communicator -- world * ceil(S / world) rows, the room the in-place all-gather
+// of a sharded map writes (ARCTIC_OPT_SHADOW_SHARDED); + 8: the map is cleared in 8-byte words.  ONE definition for every place
+// that allocates a map (arctic_create, the second map of frames in flight, arctic_comm_init).
+size_t shadow_alloc_bytes(const ArcticRenderer *r) {
+    const uint32_t S = r->shadow_size, w = (uint32_t)std::max(1, r->comm_world);
+    const uint32_t rows = std::max(S, w * ((S + w - 1) / w));
+    return (size_t)rows * S * 4 + 8;
+}
 
 int select_device(ArcticRenderer *r) {
     HIPCHECK(r, hipSetDevice(r->device));
@@ -450,6 +460,8 @@ int pass_shadow_map(ArcticRenderer *r, const ArcticScene *sc, hipStream_t stream
         // receive buffer) completes it everywhere, on the pass's stream -- the shading pass needs it next
         const size_t per = (size_t)((r->shadow_size + (uint32_t)r->comm_world - 1) / (uint32_t)r->comm_world) * r->shadow_size;
         float *base = r->d_shadow().as<float>();
+        if (r->d_shadow().cap < per * (size_t)r->comm_world * 4)   // (cannot happen through this API: every map is sized by shadow_alloc_bytes)
+            return r->fail(ARCTIC_E_STATE, "sharded shadow map: the map buffer has no room for %d x %zu texels", r->comm_world, per);
         const int nrc = g_rccl.AllGather(base + per * (size_t)r->comm_rank, base, per, Rccl::Float32, r->comm, stream);
         if (nrc != 0) return r->fail(ARCTIC_E_DEVICE, "ncclAllGather(shadow map): %s", g_rccl.why(nrc));
     }
@@ -666,7 +678,7 @@ ArcticRenderer *arctic_create(const ArcticCreateInfo *info, char *err, uint64_t 
     if ((e = r->d_tex.ensure(48)) != hipSuccess) return bail("hipMalloc tex table", e);
     if (r->shadow_size) {
         size_t n = (size_t)r->shadow_size * r->shadow_size;
-        if ((e = r->d_shadow().ensure(n * 4 + 8)) != hipSuccess) return bail("hipMalloc shadow map", e);   // + 8: cleared in 8-byte words
+        if ((e = r->d_shadow().ensure(shadow_alloc_bytes(r))) != hipSuccess) return bail("hipMalloc shadow map", e);
         if ((e = launch_fill_u32(r->d_shadow().as<uint32_t>(), 0x3F800000u, n, r->stream)) != hipSuccess) return bail("clear shadow map", e);
     }
     if (alloc_targets(r) != ARCTIC_OK) { say(r->err.c_str()); arctic_destroy(r); return nullptr; }
@@ -887,7 +899,7 @@ int arctic_render_frame_device(ArcticRenderer *r, const ArcticScene *scene, cons
                 HIPCHECK(r, hipEventRecord(r->ev_shadow_released[r->scur], r->stream));
                 r->shadow_released_valid[r->scur] = true;
                 r->scur ^= 1;
-                HIPCHECK(r, r->d_shadow().ensure((size_t)r->shadow_size * r->shadow_size * 4 + 8));   // first use of the second map (cleared by the pass itself)
+                HIPCHECK(r, r->d_shadow().ensure(shadow_alloc_bytes(r)));   // first use of the second map (cleared by the pass itself)
                 if (r->shadow_released_valid[r->scur]) HIPCHECK(r, hipStreamWaitEvent(r->shadow_stream, r->ev_shadow_released[r->scur], 0));
             } else {
                 HIPCHECK(r, hipEventRecord(r->ev_fork, r->stream));
@@ -1123,34 +1135,104 @@ int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value) {
 }
 
 // ---- multi-GPU exchange steps (include/arctic_dist.h) ------------------------------------------------------------------------
+// the plan, as pure host functions (no device, no handle): everything below is built on them
+int arctic_exchange_plan(uint32_t width, uint32_t height, uint32_t band_rows, uint32_t world, const uint32_t *row_ranges,
+                         uint32_t *rows, uint64_t *offset, uint64_t *total_bytes) {
+    if (!rows || !offset || world == 0 || width == 0 || height == 0) return ARCTIC_E_INVALID;
+    if (row_ranges) {
+        if (band_rows) return ARCTIC_E_INVALID;
+        for (uint32_t k = 0; k < world; ++k) {
+            if (row_ranges[2 * k] > row_ranges[2 * k + 1] || row_ranges[2 * k + 1] > height) return ARCTIC_E_INVALID;
+            rows[k] = row_ranges[2 * k + 1] - row_ranges[2 * k];
+        }
+    } else {
+        if (!band_rows) return ARCTIC_E_INVALID;
+        // band b -> rank b % world: full bands each, and the frame's last (possibly short) band to whoever it falls to
+        const uint32_t n_bands = (height + band_rows - 1) / band_rows, last_rows = height - (n_bands - 1) * band_rows;
+        for (uint32_t k = 0; k < world; ++k) {
+            const uint32_t mine = n_bands / world + (k < n_bands % world ? 1u : 0u);
+            rows[k] = mine * band_rows;
+            if (mine && (n_bands - 1) % world == k) rows[k] -= band_rows - last_rows;
+        }
+    }
+    uint64_t off = 0;
+    for (uint32_t k = 0; k < world; ++k) { offset[k] = off; off += (uint64_t)rows[k] * width * 4; }
+    if (total_bytes) *total_bytes = off;
+    return ARCTIC_OK;
+}
+
+int arctic_exchange_row_source(uint32_t y, uint32_t height, uint32_t band_rows, uint32_t world, const uint32_t *row_ranges,
+                               uint32_t *owner, uint32_t *local_row) {
+    if (!owner || !local_row || world == 0 || y >= height || (!row_ranges && !band_rows) || (row_ranges && band_rows)) return ARCTIC_E_INVALID;
+    return shard_row_source(y, band_rows, world, row_ranges, *owner, *local_row) ? 0 : 1;
+}
+
+int arctic_exchange_transfers(uint32_t width, uint32_t world, int32_t rank, int32_t root, const uint32_t *rows, const uint64_t *offset,
+                              ArcticTransfer *out, uint32_t cap) {
+    if (!rows || !offset || !out || world == 0 || rank < 0 || root < 0 || (uint32_t)rank >= world || (uint32_t)root >= world) return ARCTIC_E_INVALID;
+    uint32_t n = 0;
+    const uint64_t row_bytes = (uint64_t)width * 4;
+    if (rank != root) {
+        if (rows[rank]) { if (n >= cap) return ARCTIC_E_CAPACITY; out[n++] = ArcticTransfer{root, 1, 0, rows[rank] * row_bytes}; }
+        return (int)n;
+    }
+    for (uint32_t k = 0; k < world; ++k) {
+        if ((int32_t)k == root || !rows[k]) continue;
+        if (n >= cap) return ARCTIC_E_CAPACITY;
+        out[n++] = ArcticTransfer{(int32_t)k, 0, offset[k], rows[k] * row_bytes};
+    }
+    return (int)n;
+}
+
 namespace {
 
 // rows of every rank's shard and where each shard starts in a staging buffer that holds them back to back; uploaded to d_layout
 int upload_layout(ArcticRenderer *r, uint32_t world, const uint32_t *ranges /* 2 * world, or null: interleaved bands */, bool from_comm) {
     std::vector<uint32_t> rows(world, 0), rg(2 * (size_t)world, 0);
-    if (ranges) {
-        for (uint32_t k = 0; k < world; ++k) {
-            if (ranges[2 * k] > ranges[2 * k + 1] || ranges[2 * k + 1] > r->height) return r->fail(ARCTIC_E_INVALID, "frame layout: bad row range of rank %u", k);
-            rg[2 * k] = ranges[2 * k]; rg[2 * k + 1] = ranges[2 * k + 1]; rows[k] = ranges[2 * k + 1] - ranges[2 * k];
-        }
-    } else {
-        if (!r->band_rows || r->shard_count != world) return r->fail(ARCTIC_E_INVALID, "frame layout: interleaved bands need band_rows > 0 and shard_count == world");
-        for (uint32_t y = 0; y < r->height; ++y) rows[(y / r->band_rows) % world]++;
-    }
-    std::vector<unsigned long long> off(world, 0);
-    for (uint32_t k = 1; k < world; ++k) off[k] = off[k - 1] + (unsigned long long)rows[k - 1] * r->width * 4;
+    std::vector<uint64_t> off(world, 0);
+    uint64_t total = 0;
+    if (ranges) std::memcpy(rg.data(), ranges, (size_t)world * 8);
+    else if (!r->band_rows || r->shard_count != world) return r->fail(ARCTIC_E_INVALID, "frame layout: interleaved bands need band_rows > 0 and shard_count == world");
+    if (arctic_exchange_plan(r->width, r->height, ranges ? 0u : r->band_rows, world, ranges, rows.data(), off.data(), &total) != ARCTIC_OK)
+        return r->fail(ARCTIC_E_INVALID, "frame layout: bad row ranges");
     const size_t ranges_bytes = (((size_t)world * 8) + 15) / 16 * 16;
     HIPCHECK(r, r->d_layout.ensure(ranges_bytes + (size_t)world * 8));
     HIPCHECK(r, hipMemcpyAsync(r->d_layout.p, rg.data(), (size_t)world * 8, hipMemcpyHostToDevice, r->stream));
     HIPCHECK(r, hipMemcpyAsync(r->d_layout.as<char>() + ranges_bytes, off.data(), (size_t)world * 8, hipMemcpyHostToDevice, r->stream));
     HIPCHECK(r, hipStreamSynchronize(r->stream));   // the host vectors go out of scope
-    r->peer_rows = rows; r->peer_ranges = ranges ? rg : std::vector<uint32_t>();
+    r->peer_rows = rows; r->peer_offset = off; r->staging_bytes = total; r->peer_ranges = ranges ? rg : std::vector<uint32_t>();
     r->layout_world = world; r->layout_from_comm = from_comm;
     return ARCTIC_OK;
 }
 const uint32_t *layout_ranges(const ArcticRenderer *r) { return r->d_layout.as<uint32_t>(); }
 const unsigned long long *layout_offsets(const ArcticRenderer *r) {
     return reinterpret_cast<const unsigned long long *>(r->d_layout.as<char>() + (((size_t)r->layout_world * 8) + 15) / 16 * 16);
+}
+
+// the second half of arctic_comm_init, free of RCCL calls (unit-testable through arctic_comm_init's error paths): `all` holds every
+// rank's {row_begin, row_end, rows, band_rows}; checks them against this handle's sharding, uploads the layout, grows the shadow maps
+int comm_adopt_layout(ArcticRenderer *r, const uint32_t *all, int world) {
+    std::vector<uint32_t> ranges(2 * (size_t)world);
+    for (int k = 0; k < world; ++k) {
+        if (all[4 * k + 3] != r->band_rows) return r->fail(ARCTIC_E_INVALID, "comm_init: rank %d shards the frame differently (band_rows %u vs %u)", k, all[4 * k + 3], r->band_rows);
+        ranges[2 * k] = all[4 * k]; ranges[2 * k + 1] = all[4 * k + 1];
+    }
+    int rc = upload_layout(r, (uint32_t)world, r->band_rows ? nullptr : ranges.data(), true);
+    if (rc != ARCTIC_OK) return rc;
+    for (int k = 0; k < world; ++k)
+        if (r->peer_rows[(size_t)k] != all[4 * k + 2]) return r->fail(ARCTIC_E_INVALID, "comm_init: rank %d reports %u rows, the layout gives it %u", k, all[4 * k + 2], r->peer_rows[(size_t)k]);
+    if (r->shadow_size) {   // room for the in-place all-gather of a sharded shadow map, in BOTH map sets (frames in flight flip between them)
+        const size_t need = shadow_alloc_bytes(r);
+        for (int s = 0; s < 2; ++s) {
+            DevBuf &b = r->d_shadow_set[s];
+            if (!b.p || b.cap >= need) continue;   // (the second set is allocated, at this size, when first used)
+            HIPCHECK(r, hipStreamSynchronize(r->stream));
+            HIPCHECK(r, b.ensure(need));
+            HIPCHECK(r, launch_fill_u32(b.as<uint32_t>(), 0x3F800000u, (need - 8) / 4, r->stream));
+            r->shadow_key.clear(); r->bounds_valid_set[s] = false;
+        }
+    }
+    return ARCTIC_OK;
 }
 
 }  // namespace
@@ -1180,38 +1262,31 @@ int arctic_comm_init(ArcticRenderer *r, const void *id_bytes, int rank, int worl
     int nrc = g_rccl.CommInitRank(&r->comm, world, id, rank);
     if (nrc != 0) { r->comm = nullptr; return r->fail(ARCTIC_E_DEVICE, "ncclCommInitRank: %s", g_rccl.why(nrc)); }
     r->comm_rank = rank; r->comm_world = world;
-    if (!r->comm_stream) HIPCHECK(r, hipStreamCreateWithFlags(&r->comm_stream, hipStreamNonBlocking));
-    if (!r->ev_main) HIPCHECK(r, hipEventCreateWithFlags(&r->ev_main, hipEventDisableTiming));
-    for (auto &f : r->inflight) if (!f.done) HIPCHECK(r, hipEventCreateWithFlags(&f.done, hipEventDisableTiming));
-    // every rank's shard layout: {row_begin, row_end, rows, band_rows} all-gathered once (the root places shards of unequal size)
+    // From here on the handle owns a communicator: any failure below gives it back (arctic_comm_destroy) before returning, so the
+    // handle is never left half initialised (comm set, no layout) and arctic_comm_init can be called again.
     DevBuf tmp;
-    HIPCHECK(r, tmp.ensure((size_t)world * 16));
-    const uint32_t mine[4] = {r->band_rows ? 0u : r->row_begin, r->band_rows ? 0u : r->row_end, r->rows(), r->band_rows};
-    HIPCHECK(r, hipMemcpyAsync(tmp.as<char>() + (size_t)rank * 16, mine, 16, hipMemcpyHostToDevice, r->comm_stream));
-    nrc = g_rccl.AllGather(tmp.as<char>() + (size_t)rank * 16, tmp.p, 4, Rccl::Uint32, r->comm, r->comm_stream);
-    if (nrc != 0) { tmp.release(); return r->fail(ARCTIC_E_DEVICE, "ncclAllGather(layout): %s", g_rccl.why(nrc)); }
-    std::vector<uint32_t> all((size_t)world * 4);
-    HIPCHECK(r, hipMemcpyAsync(all.data(), tmp.p, (size_t)world * 16, hipMemcpyDeviceToHost, r->comm_stream));
-    HIPCHECK(r, hipStreamSynchronize(r->comm_stream));
+    const auto finish = [&]() -> int {
+        if (!r->comm_stream) HIPCHECK(r, hipStreamCreateWithFlags(&r->comm_stream, hipStreamNonBlocking));
+        if (!r->ev_main) HIPCHECK(r, hipEventCreateWithFlags(&r->ev_main, hipEventDisableTiming));
+        for (auto &f : r->inflight) if (!f.done) HIPCHECK(r, hipEventCreateWithFlags(&f.done, hipEventDisableTiming));
+        // every rank's shard layout: {row_begin, row_end, rows, band_rows} all-gathered once (the root places shards of unequal size)
+        HIPCHECK(r, tmp.ensure((size_t)world * 16));
+        const uint32_t mine[4] = {r->band_rows ? 0u : r->row_begin, r->band_rows ? 0u : r->row_end, r->rows(), r->band_rows};
+        HIPCHECK(r, hipMemcpyAsync(tmp.as<char>() + (size_t)rank * 16, mine, 16, hipMemcpyHostToDevice, r->comm_stream));
+        const int arc = g_rccl.AllGather(tmp.as<char>() + (size_t)rank * 16, tmp.p, 4, Rccl::Uint32, r->comm, r->comm_stream);
+        if (arc != 0) return r->fail(ARCTIC_E_DEVICE, "ncclAllGather(layout): %s", g_rccl.why(arc));
+        std::vector<uint32_t> all((size_t)world * 4);
+        HIPCHECK(r, hipMemcpyAsync(all.data(), tmp.p, (size_t)world * 16, hipMemcpyDeviceToHost, r->comm_stream));
+        HIPCHECK(r, hipStreamSynchronize(r->comm_stream));
+        return comm_adopt_layout(r, all.data(), world);
+    };
+    rc = finish();
     tmp.release();
-    std::vector<uint32_t> ranges(2 * (size_t)world);
-    for (int k = 0; k < world; ++k) {
-        if (all[4 * k + 3] != r->band_rows) return r->fail(ARCTIC_E_INVALID, "comm_init: rank %d shards the frame differently (band_rows %u vs %u)", k, all[4 * k + 3], r->band_rows);
-        ranges[2 * k] = all[4 * k]; ranges[2 * k + 1] = all[4 * k + 1];
-    }
-    if ((rc = upload_layout(r, (uint32_t)world, r->band_rows ? nullptr : ranges.data(), true)) != ARCTIC_OK) return rc;
-    for (int k = 0; k < world; ++k)
-        if (r->peer_rows[k] != all[4 * k + 2]) return r->fail(ARCTIC_E_INVALID, "comm_init: rank %d reports %u rows, the layout gives it %u", k, all[4 * k + 2], r->peer_rows[k]);
-    if (r->shadow_size) {   // room for the in-place all-gather of a sharded shadow map: world * ceil(S / world) rows
-        const uint32_t per = (r->shadow_size + (uint32_t)world - 1) / (uint32_t)world;
-        if ((size_t)per * world > r->shadow_size) {
-            const size_t n = (size_t)per * world * r->shadow_size;
-            if (r->d_shadow().cap < n * 4) {
-                HIPCHECK(r, r->d_shadow().ensure(n * 4 + 8));
-                HIPCHECK(r, launch_fill_u32(r->d_shadow().as<uint32_t>(), 0x3F800000u, n, r->stream));
-                r->shadow_key.clear(); r->bounds_valid() = false;
-            }
-        }
+    if (rc != ARCTIC_OK) {
+        const std::string why = r->err;
+        (void)arctic_comm_destroy(r);
+        r->err = why;
+        return rc;
     }
     return ARCTIC_OK;
 }
@@ -1245,24 +1320,23 @@ int arctic_gather_frame(ArcticRenderer *r, const void *d_shard, void *d_frame, i
     HIPCHECK(r, hipStreamWaitEvent(r->comm_stream, r->ev_main, 0));   // ... on the communication stream, beside the next frame
     const uint8_t *src = static_cast<const uint8_t *>(d_shard);
     if (r->comm_world > 1) {
-        size_t total = 0;
-        for (uint32_t k = 0; k < (uint32_t)r->comm_world; ++k) total += (size_t)r->peer_rows[k] * row_bytes;
-        if (is_root) HIPCHECK(r, r->d_staging.ensure(total));
+        // the transfers of this rank, straight from the plan (arctic_exchange_transfers: what the CPU tests check for worlds 2..8)
+        std::vector<ArcticTransfer> xfers((size_t)r->comm_world);
+        const int n_x = arctic_exchange_transfers(r->width, (uint32_t)r->comm_world, r->comm_rank, root, r->peer_rows.data(), r->peer_offset.data(),
+                                                  xfers.data(), (uint32_t)xfers.size());
+        if (n_x < 0) return r->fail(ARCTIC_E_STATE, "gather_frame: no transfer plan");
+        if (is_root) HIPCHECK(r, r->d_staging.ensure((size_t)r->staging_bytes));
         int nrc = g_rccl.GroupStart();
         if (nrc != 0) return r->fail(ARCTIC_E_DEVICE, "ncclGroupStart: %s", g_rccl.why(nrc));
-        size_t off = 0;
-        for (int k = 0; k < r->comm_world && nrc == 0; ++k) {
-            const size_t bytes = (size_t)r->peer_rows[k] * row_bytes;
-            if (is_root && k != root && bytes) nrc = g_rccl.Recv(r->d_staging.as<char>() + off, bytes, Rccl::Uint8, k, r->comm, r->comm_stream);
-            off += bytes;
+        for (int i = 0; i < n_x && nrc == 0; ++i) {
+            const ArcticTransfer &t = xfers[(size_t)i];
+            nrc = t.is_send ? g_rccl.Send(src, (size_t)t.bytes, Rccl::Uint8, t.peer, r->comm, r->comm_stream)
+                            : g_rccl.Recv(r->d_staging.as<char>() + t.staging_offset, (size_t)t.bytes, Rccl::Uint8, t.peer, r->comm, r->comm_stream);
         }
-        if (!is_root && nrc == 0 && r->rows()) nrc = g_rccl.Send(src, (size_t)r->rows() * row_bytes, Rccl::Uint8, root, r->comm, r->comm_stream);
         const int erc = g_rccl.GroupEnd();
         if (nrc != 0 || erc != 0) return r->fail(ARCTIC_E_DEVICE, "ncclSend/ncclRecv(frame shards): %s", g_rccl.why(nrc ? nrc : erc));
         if (is_root) {
-            size_t mine = 0;
-            for (int k = 0; k < root; ++k) mine += (size_t)r->peer_rows[k] * row_bytes;
-            HIPCHECK(r, hipMemcpyAsync(r->d_staging.as<char>() + mine, src, (size_t)r->rows() * row_bytes, hipMemcpyDeviceToDevice, r->comm_stream));
+            HIPCHECK(r, hipMemcpyAsync(r->d_staging.as<char>() + r->peer_offset[(size_t)root], src, (size_t)r->rows() * row_bytes, hipMemcpyDeviceToDevice, r->comm_stream));
             src = r->d_staging.as<uint8_t>();
         }
     }

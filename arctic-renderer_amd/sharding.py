@@ -33,6 +33,50 @@ def owned_rows(height, rank, world, band_rows=16):
     return y[(y // band_rows) % world == rank]
 
 
+def exchange_plan(width, height, world, band_rows=0, row_ranges=None):
+    """arctic_exchange_plan (include/arctic_dist.h; a pure host function of libarctic_hip.so, no device needed): rows of every
+    rank's shard, the byte offset of every shard in the root's staging buffer, and that buffer's size."""
+    import ctypes as C
+    import numpy as np
+    from . import binding
+    rows, off, total = np.zeros(world, np.uint32), np.zeros(world, np.uint64), C.c_uint64(0)
+    rr = None if row_ranges is None else np.ascontiguousarray(row_ranges, dtype=np.uint32).reshape(-1)
+    rc = binding.lib().arctic_exchange_plan(width, height, band_rows, world, None if rr is None else rr.ctypes.data_as(C.c_void_p),
+                                            rows.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), C.byref(total))
+    if rc != 0:
+        raise ValueError(f"arctic_exchange_plan: {binding.ERRORS.get(rc, rc)}")
+    return rows, off, int(total.value)
+
+
+def exchange_transfers(width, world, rank, root, rows, offset):
+    """arctic_exchange_transfers: the point-to-point transfers `rank` posts in one arctic_gather_frame, as (peer, is_send,
+    staging_offset, bytes) tuples."""
+    import ctypes as C
+    import numpy as np
+    from . import binding
+    out = (binding.CTransfer * world)()
+    rows, offset = np.ascontiguousarray(rows, np.uint32), np.ascontiguousarray(offset, np.uint64)
+    n = binding.lib().arctic_exchange_transfers(width, world, rank, root, rows.ctypes.data_as(C.c_void_p), offset.ctypes.data_as(C.c_void_p),
+                                                C.cast(out, C.c_void_p), world)
+    if n < 0:
+        raise ValueError(f"arctic_exchange_transfers: {binding.ERRORS.get(n, n)}")
+    return [(t.peer, t.is_send, t.staging_offset, t.bytes) for t in out[:n]]
+
+
+def exchange_row_source(y, height, world, band_rows=0, row_ranges=None):
+    """arctic_exchange_row_source: (owner, local_row) of frame row y, or None when no rank owns it."""
+    import ctypes as C
+    import numpy as np
+    from . import binding
+    rr = None if row_ranges is None else np.ascontiguousarray(row_ranges, dtype=np.uint32).reshape(-1)
+    owner, local = C.c_uint32(0), C.c_uint32(0)
+    rc = binding.lib().arctic_exchange_row_source(y, height, band_rows, world, None if rr is None else rr.ctypes.data_as(C.c_void_p),
+                                                  C.byref(owner), C.byref(local))
+    if rc < 0:
+        raise ValueError(f"arctic_exchange_row_source: {binding.ERRORS.get(rc, rc)}")
+    return None if rc == 1 else (owner.value, local.value)
+
+
 def padded_gather_plan(height, world, band_rows=16):
     """equal-size exchange for interleaved shards: every rank sends `pad` rows (its own rows first, the rest unused), so
     the gather is ONE collective (ncclGather) whatever the band count.  Returns (pad, dest) where dest[k * pad + j] is the

@@ -55,6 +55,35 @@ int arctic_gather_frame(ArcticRenderer *r, const void *d_shard, void *d_frame, i
  * No communicator needed: this is what the root does after the transfers, callable by tests and by hosts with another transport. */
 int arctic_assemble_frame(ArcticRenderer *r, const void *d_staging, void *d_frame, uint32_t world, const uint32_t *row_ranges);
 
+/* ---- the plan of the exchange step as plain numbers: pure host functions, no device, no communicator, no handle ------------------
+ * arctic_comm_init, arctic_gather_frame, arctic_assemble_frame and the placement kernel are all built on these three, so what they
+ * will do on R GPUs can be checked on any machine (tests/test_exchange_plan.py: worlds 2..8, heights that no band count divides).
+ *
+ * arctic_exchange_plan: a frame of `height` rows sharded over `world` ranks -- interleaved bands of `band_rows` rows dealt
+ * round-robin (row_ranges == NULL), or the row ranges row_ranges[2k], row_ranges[2k+1] = rank k's [begin, end) (band_rows == 0).
+ * Fills rows[k] = rows of rank k's shard and offset[k] = byte offset of that shard in the root's staging buffer (shards back to
+ * back in rank order, rows of width * 4 bytes); *total_bytes = size of the staging buffer. */
+int arctic_exchange_plan(uint32_t width, uint32_t height, uint32_t band_rows, uint32_t world, const uint32_t *row_ranges,
+                         uint32_t *rows /* world */, uint64_t *offset /* world */, uint64_t *total_bytes);
+
+/* Where frame row y comes from: *owner = the rank whose shard holds it, *local_row = its index inside that shard.  Returns 0, or
+ * 1 when no rank owns the row (row ranges with a gap), < 0 for bad arguments.  The placement kernel evaluates the same function. */
+int arctic_exchange_row_source(uint32_t y, uint32_t height, uint32_t band_rows, uint32_t world, const uint32_t *row_ranges,
+                               uint32_t *owner, uint32_t *local_row);
+
+/* The point-to-point transfers rank `rank` posts inside one ncclGroupStart / ncclGroupEnd of arctic_gather_frame with root `root`:
+ * a non-root rank sends its whole shard to the root (one entry, is_send = 1, staging_offset unused = 0); the root receives every
+ * other rank's shard at staging_offset (is_send = 0) -- its own shard is a local copy to offset[root].  Empty shards post nothing.
+ * Returns the number of entries written (<= world), < 0 for bad arguments. */
+typedef struct ArcticTransfer {
+    int32_t peer;            /* the other rank */
+    int32_t is_send;
+    uint64_t staging_offset; /* receives: byte offset in the root's staging buffer */
+    uint64_t bytes;
+} ArcticTransfer;
+int arctic_exchange_transfers(uint32_t width, uint32_t world, int32_t rank, int32_t root, const uint32_t *rows /* world */,
+                              const uint64_t *offset /* world */, ArcticTransfer *out, uint32_t cap);
+
 #define ARCTIC_OPT_SHADOW_SHARDED 14 /* 1 = with a communicator of world > 1 attached, arctic_pass_shadow_map / arctic_render_frame rasterise
                                         only this rank's ceil(S / world) light-space rows and complete the map with one in-place ncclAllGather
                                         (same map bit for bit: shadow raster results do not depend on the scissor); 0 (default) = every

@@ -117,3 +117,54 @@ def test_gloo_gather_reassembles_the_single_process_frame(pkg, oracle, tmp_path,
     ref = sc.upload(oracle.Oracle(sc.width, height, sc.shadow_size, sc.max_lights)).render_frame(sc.desc, sc.settings, threads=4)
     assert got.shape == ref.shape
     np.testing.assert_array_equal(got, ref)      # sharding must not change a single byte
+
+
+def _band_worker(rank, world, port, band, padded, out_path):
+    """interleaved bands (what bench.py shards with): every rank shades the rows it owns -- here the oracle's frame cut to those
+    rows -- and the root puts the frame together, either bench.py's way (every shard padded to the largest: ONE equal-count gather,
+    one indexed copy through padded_gather_plan) or shard by shard (unequal send/recv + assemble_banded).  The row bookkeeping of both
+    is cross-checked against the C-ABI plan (arctic_exchange_plan), which is what the RCCL path places rows by."""
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as entry
+    from importlib import import_module
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pkg = entry.load_package()
+        sh = import_module("arctic_renderer_amd.sharding")
+        sc = pkg.scenes.config3(scale=0.04, tex=64)
+        o = sc.upload(O.Oracle(sc.width, sc.height, sc.shadow_size, sc.max_lights))
+        mine = sh.owned_rows(sc.height, rank, world, band)
+        shard = torch.from_numpy(o.render_frame(sc.desc, sc.settings, threads=2)[mine])
+        rows, off, total = sh.exchange_plan(sc.width, sc.height, world, band_rows=band)
+        assert rows[rank] == len(mine) and total == sc.height * sc.width * 4
+        if padded:
+            pad, dest = sh.padded_gather_plan(sc.height, world, band)
+            out = torch.zeros((pad, sc.width, 4), dtype=torch.uint8)
+            out[:len(mine)] = shard
+            staging = torch.zeros((world * pad, sc.width, 4), dtype=torch.uint8) if rank == 0 else None
+            gathered = [staging[k * pad:(k + 1) * pad] for k in range(world)] if rank == 0 else None
+            w = sh.gather_rows(out, gathered, rank, world, async_op=True, equal_rows=True)
+            w.wait()
+            if rank == 0:
+                ext = torch.zeros((world * pad, sc.width, 4), dtype=torch.uint8)
+                ext.index_copy_(0, torch.as_tensor(dest), staging)
+                np.save(out_path, ext[:sc.height].numpy())
+        else:
+            gathered = [torch.empty((int(rows[k]), sc.width, 4), dtype=torch.uint8) for k in range(world)] if rank == 0 else None
+            sh.gather_rows(shard, gathered, rank, world)        # unequal shards: decided by one all_reduce, then send/recv
+            if rank == 0:
+                np.save(out_path, sh.assemble_banded(gathered, sc.height, band).numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,band,padded", [(2, 16, True), (3, 8, True), (3, 8, False), (2, 8, False)],
+                         ids=["2x16-padded", "3x8-padded", "3x8-sendrecv", "2x8-sendrecv"])
+def test_gloo_interleaved_bands_reassemble_the_frame(pkg, oracle, tmp_path, world, band, padded):
+    out = str(tmp_path / "frame.npy")
+    mp.spawn(_band_worker, args=(world, _free_port(), band, padded, out), nprocs=world, join=True)
+    sc = pkg.scenes.config3(scale=0.04, tex=64)
+    ref = sc.upload(oracle.Oracle(sc.width, sc.height, sc.shadow_size, sc.max_lights)).render_frame(sc.desc, sc.settings, threads=4)
+    np.testing.assert_array_equal(np.load(out), ref)
