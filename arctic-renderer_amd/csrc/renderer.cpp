@@ -195,7 +195,7 @@ struct ArcticRenderer {
     uint32_t item_cap_floor = 1u << 22;   // its smallest size (ARCTIC_OPT_ITEM_TABLE_FLOOR; tests shrink it to reach the overflow path)
     uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t light_stats[2] = {0, 0};   // stats[8], [9]: (tile, light) pairs with n.wi <= 0 in every lit lane; tiles with a lit pixel
-    int keep_float = 0, count_evals = 0, culling = 1, debug = 0, hdr16 = 0;
+    int keep_float = 0, count_evals = 0, culling = 1, debug = 0, hdr16 = 0, row_order = 0;
     uint32_t raster_blocks[2] = {2048, 2048};  // persistent grid of k_raster: [0] forward pass, [1] shadow pass
     // render_frame re-renders the shadow map only when its inputs changed (sun, objects, meshes): the reference redraws it
     // every frame (renderer.cpp:300-337), but a depth map of unchanged geometry from an unchanged light is the same map
@@ -539,6 +539,12 @@ int fill_shade_params(ArcticRenderer *r, const ArcticScene *sc, const ArcticSett
     sp.ndc_sx = 2.0f / (float)r->width; sp.ndc_sy = 2.0f / (float)r->height;
     sp.band_tiles = (int32_t)(r->band_rows / TILE); sp.shard_index = (int32_t)r->shard_index; sp.shard_count = (int32_t)r->shard_count;
     sp.tile_y0 = (int32_t)r->tile_y0;
+    {   // dispatch order of the row groups (shade.hip: row_group)
+        const uint32_t groups = (r->tiles_y + 7) / 8;
+        uint32_t sh = (uint32_t)r->row_order;
+        while (sh && (1u << sh) > groups) --sh;
+        sp.group_shift = sh; sp.group_q = (groups + (1u << sh) - 1) >> sh;
+    }
     const uint32_t nb = shadow_bounds_pitch(r->shadow_size);
     if (nb && !(r->debug & 8)) {   // the min/max table of the shadow map: rebuilt whenever the map was written
         int rc = build_shadow_bounds(r, r->stream);
@@ -1126,6 +1132,10 @@ int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value) {
     case ARCTIC_OPT_ITEM_TABLE_FLOOR:
         if (value < 64 || value > 0x7FFFFFF0ll) return r->fail(ARCTIC_E_INVALID, "set_option: item table floor out of range");
         r->item_cap_floor = (uint32_t)value; r->geo[0].item_cap = r->geo[1].item_cap = r->geo[2].item_cap = 0;
+        break;
+    case ARCTIC_OPT_ROW_ORDER:
+        if (value < 0 || value > 5) return r->fail(ARCTIC_E_INVALID, "set_option: row order must be 0..5");
+        r->row_order = (int)value;
         break;
     case ARCTIC_OPT_SHADOW_CACHE: r->shadow_cache = value != 0; r->shadow_key.clear(); break;
     case ARCTIC_OPT_SHADOW_SHARDED: r->shadow_sharded = value != 0; r->shadow_key.clear(); break;

@@ -802,6 +802,9 @@ __device__ __forceinline__ void shade_tile(const ShadeParams &sp, const float *l
     if (in_frame) store_pixel(sp, o, color);
 }
 
+// the group of 8 tile rows a workgroup works on: block row g -> (g mod Q) * ceil(groups / Q) + g / Q (scalar shifts; the grid is padded to Q * ceil(groups / Q))
+__device__ __forceinline__ uint32_t row_group(const ShadeParams &sp) { return (blockIdx.y & ((1u << sp.group_shift) - 1u)) * sp.group_q + (blockIdx.y >> sp.group_shift); }
+
 // LDS: the sRGB LUT
 __device__ __forceinline__ void stage_lds(const ShadeParams &sp, float *lut) { lut[threadIdx.x] = sp.srgb_lut[threadIdx.x]; }
 
@@ -818,7 +821,10 @@ __global__ __launch_bounds__(256) void k_material(const ShadeParams sp) {
     // same L2, while all eight XCDs stay within 8 tile rows of each other in the G-buffer stream.  (Placement is a speed
     // matter only; the grid is padded to whole groups of 8 rows and surplus blocks exit.)
     // grid = (8 x workgroups per tile row, groups of 8 tile rows): the linear block id advances along x first, so id % 8 = x % 8
-    const uint32_t ty = blockIdx.y * 8 + (blockIdx.x & 7u), tx = (blockIdx.x >> 3) * 4 + wave;
+    // ... and the row groups themselves are visited Q-way interleaved (ARCTIC_OPT_ROW_ORDER): the ~1800 workgroups resident at one time
+    // then come from Q distant bands of the frame, so a SIMD holds waves of lit tiles (ALU-bound) next to waves of shadowed ones
+    // (latency-bound) and each kind hides behind the other.
+    const uint32_t ty = row_group(sp) * 8 + (blockIdx.x & 7u), tx = (blockIdx.x >> 3) * 4 + wave;
     const bool tile_ok = ty < sp.tiles_y && tx < sp.tiles_x;
     const size_t tile = (size_t)ty * sp.tiles_x + tx;   // wave-uniform
     TileHead cur;
@@ -844,7 +850,7 @@ __global__ __launch_bounds__(256) void k_material_vis(const ShadeParams sp) {
     __shared__ float shadow_tiles[LDS_SHADOW ? 4 : 1][LDS_SHADOW ? SHADOW_TILE * SHADOW_TILE : 1];   // one per wave (the LDS variant of the PCF slow path)
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t ty = blockIdx.y * 8 + (blockIdx.x & 7u), tx = (blockIdx.x >> 3) * 4 + wave;   // XCD-aware order: see k_material
+    const uint32_t ty = row_group(sp) * 8 + (blockIdx.x & 7u), tx = (blockIdx.x >> 3) * 4 + wave;   // XCD-aware, interleaved order: see k_material
     const bool tile_ok = ty < sp.tiles_y && tx < sp.tiles_x;
     const size_t gi = ((size_t)ty * sp.tiles_x + tx) * 64 + lane;
     unsigned long long key = ~0ull;
@@ -993,8 +999,8 @@ hipError_t launch_variant(const ShadeParams &sp, const ShadeLaunch &L, dim3 grid
 hipError_t launch_shade(const ShadeParams &sp, const ShadeLaunch &L) {
     const uint32_t n_tiles = sp.tiles_x * sp.tiles_y;
     if (n_tiles == 0) return hipSuccess;
-    const uint32_t bpr = (sp.tiles_x + 3) / 4, row_groups = (sp.tiles_y + 7) / 8;
-    const dim3 grid(8 * bpr, row_groups);
+    const uint32_t bpr = (sp.tiles_x + 3) / 4;
+    const dim3 grid(8 * bpr, sp.group_q << sp.group_shift);   // Q * ceil(row groups / Q) block rows: surplus groups exit
     if (sp.debug & 16)   // A/B only: the 25-tap path staged through LDS (a separate instantiation: it costs the default kernels nothing)
         return L.loop == 2 ? launch_variant<2, false, true>(sp, L, grid) : launch_variant<1, false, true>(sp, L, grid);
     if (L.loop == 2) return L.stats ? launch_variant<2, true, false>(sp, L, grid) : launch_variant<2, false, false>(sp, L, grid);
