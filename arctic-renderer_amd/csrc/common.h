@@ -130,14 +130,21 @@ __host__ __device__ inline bool shard_row_source(uint32_t y, uint32_t band_rows,
     return false;
 }
 
-// texture descriptor, 16 B; three consecutive per material: diffuse (sRGB), normal, metal-rough
+// texture descriptor, 32 B (one s_load_dwordx8); three consecutive per material: diffuse (sRGB), normal, metal-rough
 // When a material's three images have equal size they are stored PACKED: one image of 8-byte texels holding exactly the
-// eight channels ps_main reads (diffuse rgb, normal rgb, metal-rough gb; layout in shade.hip), so one bilinear footprint =
-// four aligned 8-byte loads instead of twelve 4-byte ones.  Bit 31 of w marks it; descriptors 1 and 2 are then unused.
+// eight channels ps_main reads (diffuse rgb, normal rgb, metal-rough gb; layout in shade.hip) WITH A ONE-TEXEL WRAP BORDER:
+// (w + 2) x (h + 2) texels, padded texel (X, Y) = image texel ((X - 1) mod w, (Y - 1) mod h).  A bilinear footprint under
+// WRAP addressing starts at image texel (i0, j0) in [-1, w - 1] x [-1, h - 1] and ends one further, i.e. it is padded texels
+// (i0 + 1 .. i0 + 2, j0 + 1 .. j0 + 2): never a wrap test, and the two texels of a row are adjacent -- one footprint = two
+// 16-byte loads instead of twelve 4-byte ones.  Bit 31 of w marks it; descriptors 1 and 2 are then unused.
 struct TexDesc {
-    const uint32_t *texels;  // RGBA8 little endian (r = low byte), row-major, tightly packed -- or the packed image
-    uint32_t w, h;           // w bit 31: packed
+    const uint32_t *texels;  // RGBA8 little endian (r = low byte), row-major, tightly packed -- or the packed, bordered image
+    uint32_t w, h;           // image size (without the border); w bit 31: packed
+    float wf, hf;            // (float)w, (float)h: exact (sides are below 65536)
+    uint32_t pitch;          // packed: texels per row of the bordered image = w + 2
+    uint32_t pad;
 };
+static_assert(sizeof(TexDesc) == 32, "TexDesc layout (tex_desc loads it with one s_load_dwordx8)");
 constexpr uint32_t TEX_INTERLEAVED = 0x80000000u;
 
 // point light as uploaded (scene.hpp:88-94): float3 pos, pad, float3 color, pad = 2 x float4

@@ -773,20 +773,29 @@ int arctic_create_material(ArcticRenderer *r, const void *diffuse, uint32_t dw, 
     const void *src[3] = {diffuse, normal, mr};
     const uint32_t w[3] = {dw, nw, mw}, h[3] = {dh, nh, mh};
     TexDesc td[3];
+    // byte offsets into an image are 32-bit in the kernels (shade.hip: saddr loads)
+    if ((uint64_t)(dw + 2) * (dh + 2) > (1ull << 29) || (uint64_t)nw * nh > (1ull << 30) || (uint64_t)mw * mh > (1ull << 30))
+        return r->fail(ARCTIC_E_CAPACITY, "create_material: image above 2^29 texels");
     if (dw == nw && dw == mw && dh == nh && dh == mh) {
-        // equal sizes (the usual glTF case): pack the eight channels ps_main reads into 8-byte texels (layout: shade.hip)
-        size_t n = (size_t)dw * dh;
+        // equal sizes (the usual glTF case): pack the eight channels ps_main reads into 8-byte texels, with a one-texel WRAP
+        // border around the image (layout: common.h TexDesc, shade.hip)
+        const uint32_t pw = dw + 2, ph = dh + 2;
+        size_t n = (size_t)pw * ph;
         std::vector<uint32_t> packed(n * 2);
         const uint8_t *a = static_cast<const uint8_t *>(diffuse), *b = static_cast<const uint8_t *>(normal), *c = static_cast<const uint8_t *>(mr);
-        for (size_t i = 0; i < n; ++i) {
-            packed[2 * i] = (uint32_t)a[4 * i] | ((uint32_t)a[4 * i + 1] << 8) | ((uint32_t)a[4 * i + 2] << 16) | ((uint32_t)b[4 * i] << 24);
-            packed[2 * i + 1] = (uint32_t)b[4 * i + 1] | ((uint32_t)b[4 * i + 2] << 8) | ((uint32_t)c[4 * i + 1] << 16) | ((uint32_t)c[4 * i + 2] << 24);
+        for (uint32_t Y = 0; Y < ph; ++Y) {
+            const size_t sy = (size_t)((Y + dh - 1) % dh) * dw;
+            for (uint32_t X = 0; X < pw; ++X) {
+                const size_t i = sy + (X + dw - 1) % dw, o = (size_t)Y * pw + X;
+                packed[2 * o] = (uint32_t)a[4 * i] | ((uint32_t)a[4 * i + 1] << 8) | ((uint32_t)a[4 * i + 2] << 16) | ((uint32_t)b[4 * i] << 24);
+                packed[2 * o + 1] = (uint32_t)b[4 * i + 1] | ((uint32_t)b[4 * i + 2] << 8) | ((uint32_t)c[4 * i + 1] << 16) | ((uint32_t)c[4 * i + 2] << 24);
+            }
         }
         void *p = nullptr;
         HIPCHECK(r, hipMalloc(&p, n * 8));
         r->tex_allocs.push_back(p);
         HIPCHECK(r, hipMemcpy(p, packed.data(), n * 8, hipMemcpyHostToDevice));   // synchronous like rhi.cpp:480-519
-        for (int i = 0; i < 3; ++i) { td[i].texels = static_cast<const uint32_t *>(p); td[i].w = dw | TEX_INTERLEAVED; td[i].h = dh; }
+        for (int i = 0; i < 3; ++i) { td[i] = TexDesc{static_cast<const uint32_t *>(p), dw | TEX_INTERLEAVED, dh, (float)dw, (float)dh, pw, 0u}; }
     } else {
         for (int i = 0; i < 3; ++i) {
             void *p = nullptr;
@@ -794,7 +803,7 @@ int arctic_create_material(ArcticRenderer *r, const void *diffuse, uint32_t dw, 
             HIPCHECK(r, hipMalloc(&p, bytes));
             r->tex_allocs.push_back(p);
             HIPCHECK(r, hipMemcpy(p, src[i], bytes, hipMemcpyHostToDevice));
-            td[i].texels = static_cast<const uint32_t *>(p); td[i].w = w[i]; td[i].h = h[i];
+            td[i] = TexDesc{static_cast<const uint32_t *>(p), w[i], h[i], (float)w[i], (float)h[i], w[i], 0u};
         }
     }
     r->tex.insert(r->tex.end(), td, td + 3);

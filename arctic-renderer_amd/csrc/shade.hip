@@ -73,20 +73,22 @@ __device__ __forceinline__ void wrap_axis(float u, uint32_t n, int &i0, int &i1,
 
 // one texture of a material, WAVE-UNIFORM (the descriptor lives in SGPRs).  packed = 0: plain RGBA8 image.  packed = 1: the
 // material's three equally sized images are stored as ONE image of 8-byte texels holding exactly the eight channels ps_main
-// reads (forward.hlsl:98-124):
+// reads (forward.hlsl:98-124), with a one-texel WRAP border around it (common.h TexDesc):
 //   word 0 = diffuse.r | diffuse.g << 8 | diffuse.b << 16 | normal.r << 24
 //   word 1 = normal.g | normal.b << 8 | metal_rough.g << 16 | metal_rough.b << 24
-struct TexS { const uint8_t *texels; uint32_t w, h, packed; };
+struct TexS { const uint8_t *texels; uint32_t w, h, packed; float wf, hf; uint32_t pitch; };
 // The descriptor is fetched with an explicit s_load: written as a plain load the compiler sinks it into the `mat == m` branch
 // of the waterfall loop, replaces the uniform m by the per-lane mat it equals there, and issues a vector load per lane.
 typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+typedef uint32_t u8v __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ TexS tex_desc(const TexDesc *tex, uint32_t i /* wave-uniform */) {
-    u4v v;
-    asm("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(tex + i));   // not volatile: a side-effecting asm would stop the compiler from using scalar loads for the lights
+    u8v v;
+    asm("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(tex + i));   // not volatile: a side-effecting asm would stop the compiler from using scalar loads for the lights
     TexS t;
-    t.texels = reinterpret_cast<const uint8_t *>(((unsigned long long)v.y << 32) | v.x);
-    t.w = v.z & 0x7FFFFFFFu; t.h = v.w;
-    t.packed = v.z >> 31;   // TexDesc::w bit 31
+    t.texels = reinterpret_cast<const uint8_t *>(((unsigned long long)v[1] << 32) | v[0]);
+    t.w = v[2] & 0x7FFFFFFFu; t.h = v[3];
+    t.packed = v[2] >> 31;   // TexDesc::w bit 31
+    t.wf = __uint_as_float(v[4]); t.hf = __uint_as_float(v[5]); t.pitch = v[6];
     return t;
 }
 
@@ -94,41 +96,62 @@ __device__ __forceinline__ TexS tex_desc(const TexDesc *tex, uint32_t i /* wave-
 // form, no 64-bit address arithmetic per lane.  (Pointers rebuilt from descriptor words would otherwise be generic: flat_load.)
 typedef const char __attribute__((address_space(1))) *gchar;
 typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+typedef uint32_t u4u __attribute__((ext_vector_type(4), aligned(8)));    // 16 bytes at an 8-byte aligned address: gfx950 runs in unaligned-access mode
 typedef float f2v __attribute__((ext_vector_type(2)));
-typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));   // 16 bytes at a 4-byte aligned address: gfx950 runs in unaligned-access mode
+typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));   // 16 bytes at a 4-byte aligned address
 __device__ __forceinline__ uint32_t gload_u32(const void *base, uint32_t o) { return *(const uint32_t __attribute__((address_space(1))) *)((gchar)base + o); }
 __device__ __forceinline__ uint2 gload_u2(const void *base, uint32_t o) { const u2v v = *(const u2v __attribute__((address_space(1))) *)((gchar)base + o); return make_uint2(v.x, v.y); }
+__device__ __forceinline__ u4v gload_u4u(const void *base, uint32_t o) { const u4u v = *(const u4u __attribute__((address_space(1))) *)((gchar)base + o); return (u4v){v.x, v.y, v.z, v.w}; }
 __device__ __forceinline__ float2 gload_f2(const void *base, uint32_t o) { const f2v v = *(const f2v __attribute__((address_space(1))) *)((gchar)base + o); return make_float2(v.x, v.y); }
 __device__ __forceinline__ float4u gload_f4u(const void *base, uint32_t o) { return *(const float4u __attribute__((address_space(1))) *)((gchar)base + o); }
 
+// texel coordinate along one axis WITHOUT the wrap (the bordered packed images never need it): the oracle's operations in the
+// oracle's order, i0 = first texel of the footprint in [-1, n - 1], f = weight of the second
+__device__ __forceinline__ void axis_nowrap(float u, float nf, int &i0, float &f) {
+#pragma clang fp contract(off)
+    const float uw = u - floorf(u);
+    const float x = uw * nf - 0.5f;
+    const float xf = floorf(x);
+    f = x - xf;
+    i0 = (int)xf;
+}
+
 // bilinear footprint of a lane: four texels (8 bytes each when packed, else 4) + weights.  Byte offsets are 32-bit (images
-// are at most 16384^2 texels of 8 bytes), so a load is one global_load with the descriptor's base in SGPRs.
-struct Taps { uint2 q00, q10, q01, q11; float w00, w10, w01, w11; };
-template <int TEXEL_BYTES>
-__device__ __forceinline__ void fetch_taps(const TexS &d, float u, float v, Taps &t) {
+// hold at most 2^29 texels), so a load is one global_load with the descriptor's base in SGPRs.
+// r0 = {texel (x0, y0) word 0, word 1, texel (x1, y0) word 0, word 1}, r1 = the same of row y1 (plain images: words 0 only)
+struct Taps { u4v r0, r1; float w00, w10, w01, w11; };
+__device__ __forceinline__ void tap_weights(float fx, float fy, Taps &t) {
+    const float gx = 1.0f - fx, gy = 1.0f - fy;
+    t.w00 = gx * gy; t.w10 = fx * gy; t.w01 = gx * fy; t.w11 = fx * fy;
+}
+// packed + bordered image: the footprint is two 16-byte loads, their address one multiply-add and one shifted add
+__device__ __forceinline__ void fetch_taps_packed(const TexS &d, float u, float v, Taps &t) {
+    int x0, y0;
+    float fx, fy;
+    axis_nowrap(u, d.wf, x0, fx);
+    axis_nowrap(v, d.hf, y0, fy);
+    // padded texel (x0 + 1, y0 + 1): (y0 * pitch + x0) + (pitch + 1) >= 0
+    const uint32_t o = ((uint32_t)(__mul24(y0, (int)d.pitch) + x0) + (d.pitch + 1u)) << 3;
+    t.r0 = gload_u4u(d.texels, o);
+    t.r1 = gload_u4u(d.texels + (size_t)d.pitch * 8u, o);
+    tap_weights(fx, fy, t);
+}
+__device__ __forceinline__ void fetch_taps_plain(const TexS &d, float u, float v, Taps &t) {
     int x0, x1, y0, y1;
     float fx, fy;
     wrap_axis(u, d.w, x0, x1, fx);
     wrap_axis(v, d.h, y0, y1, fy);
     const uint32_t r0 = (uint32_t)y0 * d.w, r1 = (uint32_t)y1 * d.w;
-    const uint32_t o00 = (r0 + (uint32_t)x0) * TEXEL_BYTES, o10 = (r0 + (uint32_t)x1) * TEXEL_BYTES;
-    const uint32_t o01 = (r1 + (uint32_t)x0) * TEXEL_BYTES, o11 = (r1 + (uint32_t)x1) * TEXEL_BYTES;
-    if (TEXEL_BYTES == 8) {
-        t.q00 = gload_u2(d.texels, o00); t.q10 = gload_u2(d.texels, o10);
-        t.q01 = gload_u2(d.texels, o01); t.q11 = gload_u2(d.texels, o11);
-    } else {
-        t.q00.x = gload_u32(d.texels, o00); t.q10.x = gload_u32(d.texels, o10);
-        t.q01.x = gload_u32(d.texels, o01); t.q11.x = gload_u32(d.texels, o11);
-        t.q00.y = t.q10.y = t.q01.y = t.q11.y = 0u;
-    }
-    const float gx = 1.0f - fx, gy = 1.0f - fy;
-    t.w00 = gx * gy; t.w10 = fx * gy; t.w01 = gx * fy; t.w11 = fx * fy;
+    t.r0.x = gload_u32(d.texels, (r0 + (uint32_t)x0) * 4u); t.r0.z = gload_u32(d.texels, (r0 + (uint32_t)x1) * 4u);
+    t.r1.x = gload_u32(d.texels, (r1 + (uint32_t)x0) * 4u); t.r1.z = gload_u32(d.texels, (r1 + (uint32_t)x1) * 4u);
+    t.r0.y = t.r0.w = t.r1.y = t.r1.w = 0u;
+    tap_weights(fx, fy, t);
 }
 // byte k of a word as float: v_cvt_f32_ubyteK, one instruction
 template <int K> __device__ __forceinline__ float ubyte(uint32_t w) { return (float)((w >> (8 * K)) & 0xFFu); }
-// UNORM8 channel (byte K of word W of the texel: 0 = .x, 1 = .y), bilinear, scaled to [0,1]
+// UNORM8 channel (byte K of word W of the texel), bilinear, scaled to [0,1]
 template <int W, int K> __device__ __forceinline__ float filt_bytes(const Taps &t) {   // the filtered channel on the 0..255 scale
-    const uint32_t a = W ? t.q00.y : t.q00.x, b = W ? t.q10.y : t.q10.x, c = W ? t.q01.y : t.q01.x, d = W ? t.q11.y : t.q11.x;
+    const uint32_t a = W ? t.r0.y : t.r0.x, b = W ? t.r0.w : t.r0.z, c = W ? t.r1.y : t.r1.x, d = W ? t.r1.w : t.r1.z;
     return fm(t.w11, ubyte<K>(d), fm(t.w01, ubyte<K>(c), fm(t.w10, ubyte<K>(b), t.w00 * ubyte<K>(a))));
 }
 template <int W, int K> __device__ __forceinline__ float filt_unorm(const Taps &t) { return filt_bytes<W, K>(t) * (1.0f / 255.0f); }
@@ -141,8 +164,8 @@ __device__ __forceinline__ float snorm_of_bytes(float s) {
 }
 // sRGB8 channel (byte K of word 0), decoded per texel BEFORE filtering through the 256-entry LDS table
 template <int K> __device__ __forceinline__ float filt_srgb(const Taps &t, const float *lut) {
-    return fm(t.w11, lut[(t.q11.x >> (8 * K)) & 0xFFu], fm(t.w01, lut[(t.q01.x >> (8 * K)) & 0xFFu],
-              fm(t.w10, lut[(t.q10.x >> (8 * K)) & 0xFFu], t.w00 * lut[(t.q00.x >> (8 * K)) & 0xFFu])));
+    return fm(t.w11, lut[(t.r1.z >> (8 * K)) & 0xFFu], fm(t.w01, lut[(t.r1.x >> (8 * K)) & 0xFFu],
+              fm(t.w10, lut[(t.r0.z >> (8 * K)) & 0xFFu], t.w00 * lut[(t.r0.x >> (8 * K)) & 0xFFu])));
 }
 
 // ---- forward.hlsl:68-96 calculate_shadow: 5x5 taps, each a bilinear fetch of the R32 map, WRAP -----
@@ -347,6 +370,7 @@ __device__ __forceinline__ void make_pix(f3 n, f3 wo, f3 world, f3 base, float m
     const float r1 = rough + 1.0f;
     const float k = r1 * r1 * 0.125f, omk = 1.0f - k;
     t.num = a2 * INV_PI * ndwo * rcp(fm(ndwo, omk, k));
+    asm volatile("" : "+v"(t.num));   // one register through the light loop instead of the four it is made of (the compiler would sink the division behind the loop)
     const float four_ndwo = 4.0f * ndwo;
     p.q2 = omk * four_ndwo; p.q1 = fm(k, four_ndwo, 0.0001f * omk); p.q0 = 0.0001f * k;
 }
@@ -500,7 +524,11 @@ __device__ __forceinline__ float rrt_odt(float c) {
     float b = fm(c, fm(0.983729f, c, 0.4329510f), 0.238081f);
     return a * rcp(b);
 }
-__device__ __forceinline__ f3 post_process(f3 c, int tm, float inv_gamma, float exposure) {
+// the last multiply-add of the ACES output matrix with the saturate (:24) in the instruction's clamp bit
+__device__ __forceinline__ v2 pk_fma_sat(v2 k /* SGPR pair */, v2 a, v2 c) { v2 r; asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "s"(k), "v"(a), "v"(c)); return r; }
+__device__ __forceinline__ float fma_sat(float k /* SGPR */, float a, float c) { float r; asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "s"(k), "v"(a), "v"(c)); return r; }
+// the tonemappers, post_process.hlsl:39-57 (what correct_gamma is applied to)
+__device__ __forceinline__ f3 tonemap(f3 c, int tm, float exposure) {
     f3 t;
     if (tm == 1) {          // tm_exposure :44-47: 1 - exp(-c * exposure); for tiny arguments the subtraction cancels in
                             // fp32 (1 - exp(-1e-8) = 0), so the series x - x^2/2 + x^3/6 takes over below 1/64
@@ -513,29 +541,51 @@ __device__ __forceinline__ f3 post_process(f3 c, int tm, float inv_gamma, float 
         };
         t = mk(one_minus_exp(x.x), one_minus_exp(x.y), one_minus_exp(x.z));
     } else if (tm == 2) {   // tm_aces :15-25, :50-57; channels x and y as a packed pair (same operations lane for lane), z plain
-        typedef float p2 __attribute__((ext_vector_type(2)));
-        auto pfm = [](p2 a, p2 b, p2 c2) { return __builtin_elementwise_fma(a, b, c2); };
-        const p2 cx = {c.x, c.x}, cy = {c.y, c.y}, cz = {c.z, c.z};
-        p2 ixy = pfm((p2){0.04823f, 0.01566f}, cz, pfm((p2){0.35458f, 0.90834f}, cy, (p2){0.59719f, 0.07600f} * cx));
+        auto pfm = [](v2 a, v2 b, v2 c2) { return __builtin_elementwise_fma(a, b, c2); };
+        const v2 cx = {c.x, c.x}, cy = {c.y, c.y}, cz = {c.z, c.z};
+        v2 ixy = pfm((v2){0.04823f, 0.01566f}, cz, pfm((v2){0.35458f, 0.90834f}, cy, (v2){0.59719f, 0.07600f} * cx));
         float iz = fm(0.837f, c.z, fm(0.13383f, c.y, 0.02840f * c.x));
         {   // rrt_and_odt_fit
-            const p2 a = pfm(ixy, ixy + (p2){0.0245786f, 0.0245786f}, (p2){-0.000090537f, -0.000090537f});
-            const p2 b = pfm(ixy, pfm((p2){0.983729f, 0.983729f}, ixy, (p2){0.4329510f, 0.4329510f}), (p2){0.238081f, 0.238081f});
-            ixy = a * (p2){rcp(b.x), rcp(b.y)};
+            const v2 a = pfm(ixy, ixy + (v2){0.0245786f, 0.0245786f}, (v2){-0.000090537f, -0.000090537f});
+            const v2 b = pfm(ixy, pfm((v2){0.983729f, 0.983729f}, ixy, (v2){0.4329510f, 0.4329510f}), (v2){0.238081f, 0.238081f});
+            ixy = a * (v2){rcp(b.x), rcp(b.y)};
             iz = rrt_odt(iz);
         }
-        const p2 ix = {ixy.x, ixy.x}, iy = {ixy.y, ixy.y}, izz = {iz, iz};
-        const p2 oxy = pfm((p2){-0.07367f, -0.00605f}, izz, pfm((p2){-0.53108f, 1.10813f}, iy, (p2){1.60475f, -0.10208f} * ix));
-        t = mk(sat(oxy.x), sat(oxy.y), sat(fm(1.07f, iz, fm(-0.07276f, ixy.y, -0.00327f * ixy.x))));
+        const v2 ix = {ixy.x, ixy.x}, iy = {ixy.y, ixy.y}, izz = {iz, iz};
+        const v2 oxy = pk_fma_sat((v2){-0.07367f, -0.00605f}, izz, pfm((v2){-0.53108f, 1.10813f}, iy, (v2){1.60475f, -0.10208f} * ix));
+        t = mk(oxy.x, oxy.y, fma_sat(1.07f, iz, fm(-0.07276f, ixy.y, -0.00327f * ixy.x)));
     } else {                // tm_reinhard :39-42 (and `default:`)
         t = mk(c.x * rcp(c.x + 1.0f), c.y * rcp(c.y + 1.0f), c.z * rcp(c.z + 1.0f));
     }
-    // correct_gamma :34-37: pow(abs(c), 1/gamma)
-    return mk(pow_fast(fabsf(t.x), inv_gamma), pow_fast(fabsf(t.y), inv_gamma), pow_fast(fabsf(t.z), inv_gamma));
+    return t;
+}
+// correct_gamma :34-37: pow(abs(t), 1/gamma) = exp2(g), g = log2|t| / gamma
+__device__ __forceinline__ f3 gamma_exponent(f3 t, float inv_gamma) {
+    return mk(inv_gamma * __builtin_amdgcn_logf(fabsf(t.x)), inv_gamma * __builtin_amdgcn_logf(fabsf(t.y)), inv_gamma * __builtin_amdgcn_logf(fabsf(t.z)));
+}
+__device__ __forceinline__ f3 post_process(f3 c, int tm, float inv_gamma, float exposure) {
+    const f3 g = gamma_exponent(tonemap(c, tm, exposure), inv_gamma);
+    return mk(__builtin_amdgcn_exp2f(g.x), __builtin_amdgcn_exp2f(g.y), __builtin_amdgcn_exp2f(g.z));
 }
 // store to the R8G8B8A8_UNORM target (renderer.cpp:161-175): saturate (NaN -> 0), *255, +0.5, truncate
 // (v_med3_f32 of (NaN, 0, 1) is 0; v_cvt_u32_f32 truncates)
 __device__ __forceinline__ uint32_t unorm8(float x) { return (uint32_t)__builtin_fmaf(sat(x), 255.0f, 0.5f); }
+__device__ __forceinline__ uint32_t rgba8_word(f3 l) { return unorm8(l.x) | (unorm8(l.y) << 8) | (unorm8(l.z) << 16) | 0xFF000000u; }
+// the same store for a colour given as its gamma exponents (LDR = exp2(g)): the saturate is the clamp bit of v_exp_f32, and the
+// three multiply-adds follow the three transcendentals in ONE asm statement, so each reads its exponential two instructions
+// after it was issued (gfx950 needs one wait state between a transcendental and the VALU instruction reading its result; the
+// compiler does not look inside asm statements).  Bit for bit unorm8 of exp2(g): the clamp of a NaN is 0 (DX10_CLAMP).
+__device__ __forceinline__ uint32_t rgba8_word_of_exponents(f3 g) {
+    float e0, e1, e2, q0, q1, q2;
+    asm("v_exp_f32_e64 %0, %6 clamp\n\tv_exp_f32_e64 %1, %7 clamp\n\tv_exp_f32_e64 %2, %8 clamp\n\t"
+        "v_fma_f32 %3, %0, %9, 0.5\n\tv_fma_f32 %4, %1, %9, 0.5\n\tv_fma_f32 %5, %2, %9, 0.5"
+        : "=&v"(e0), "=&v"(e1), "=&v"(e2), "=&v"(q0), "=&v"(q1), "=&v"(q2) : "v"(g.x), "v"(g.y), "v"(g.z), "s"(255.0f));
+#if ARCTIC_CVT_PK_U8
+    return __builtin_amdgcn_cvt_pk_u8_f32(q2, 2u, __builtin_amdgcn_cvt_pk_u8_f32(q1, 1u, __builtin_amdgcn_cvt_pk_u8_f32(q0, 0u, 0xFF000000u)));
+#else
+    return (uint32_t)q0 | ((uint32_t)q1 << 8) | ((uint32_t)q2 << 16) | 0xFF000000u;
+#endif
+}
 
 // first wave of G-buffer loads: what every pixel needs (28 B)
 struct TileHead { float4 a; float b0, b1, b2; };   // a = uv.xy, ls.xy; b = ls.z, ls.w, material id
@@ -555,14 +605,26 @@ __device__ __forceinline__ TileHead load_head(const GBuffer &g, size_t tile /* w
 // hdr16 reproduces that rounding (round-to-nearest-even to binary16, finite overflow to +inf like the ROP's conversion)
 __device__ __forceinline__ float through_half(float x) { return (float)(_Float16)x; }
 
-__device__ __forceinline__ void store_pixel(const ShadeParams &sp, uint32_t o, f3 color) {
-    if (sp.hdr16) color = mk(through_half(color.x), through_half(color.y), through_half(color.z));
-    const f3 l = (sp.debug & 4) ? color : post_process(color, sp.tm_method, sp.inv_gamma, sp.exposure);   // bit 2: timing only
-    // uniform base + 32-bit byte offset (targets are at most 16384^2 pixels): no 64-bit address arithmetic per lane
-    *(uint32_t __attribute__((address_space(1))) *)((char __attribute__((address_space(1))) *)sp.out_rgba8 + o * 4u) =
-        unorm8(l.x) | (unorm8(l.y) << 8) | (unorm8(l.z) << 16) | 0xFF000000u;
-    if (sp.out_ldr) { sp.out_ldr[(size_t)o * 3] = l.x; sp.out_ldr[(size_t)o * 3 + 1] = l.y; sp.out_ldr[(size_t)o * 3 + 2] = l.z; }
-    if (sp.out_hdr) { sp.out_hdr[(size_t)o * 3] = color.x; sp.out_hdr[(size_t)o * 3 + 1] = color.y; sp.out_hdr[(size_t)o * 3 + 2] = color.z; }
+// post_process + the store of one pixel.  `out` = the RGBA8 target advanced to the tile's first pixel by the caller (wave-uniform,
+// or the target itself), o = the pixel's index behind it (32-bit: targets are at most 16384^2 pixels); po = the pixel's index
+// in the whole target, for the optional float planes of the tests.  The uniform options are real branches (an empty volatile asm
+// keeps the compiler from turning them into conversions + selects executed by every pixel).
+__device__ __forceinline__ void store_pixel(const ShadeParams &sp, const uint8_t *out, uint32_t o, uint32_t po, f3 color) {
+    if (sp.hdr16) { asm volatile(""); color = mk(through_half(color.x), through_half(color.y), through_half(color.z)); }
+    uint32_t word;
+    f3 g = mk(0.0f, 0.0f, 0.0f);
+    if (sp.debug & 4) { asm volatile(""); word = rgba8_word(color); }   // bit 2: timing only, no post_process
+    else {
+        g = gamma_exponent(tonemap(color, sp.tm_method, sp.exposure), sp.inv_gamma);
+        word = rgba8_word_of_exponents(g);
+    }
+    *(uint32_t __attribute__((address_space(1))) *)((char __attribute__((address_space(1))) *)out + o * 4u) = word;
+    if (sp.out_ldr) {
+        asm volatile("");
+        const f3 l = (sp.debug & 4) ? color : mk(__builtin_amdgcn_exp2f(g.x), __builtin_amdgcn_exp2f(g.y), __builtin_amdgcn_exp2f(g.z));
+        sp.out_ldr[(size_t)po * 3] = l.x; sp.out_ldr[(size_t)po * 3 + 1] = l.y; sp.out_ldr[(size_t)po * 3 + 2] = l.z;
+    }
+    if (sp.out_hdr) { asm volatile(""); sp.out_hdr[(size_t)po * 3] = color.x; sp.out_hdr[(size_t)po * 3 + 1] = color.y; sp.out_hdr[(size_t)po * 3 + 2] = color.z; }
 }
 
 // ---- skybox.hlsl:61-90: pixels without geometry take the environment map along their view ray --------------------------
@@ -596,11 +658,165 @@ __device__ __noinline__ f3 sample_environment(const float4 *__restrict__ env, ui
               fm(w11, d.z, fm(w01, c.z, fm(w10, b.z, w00 * a.z))));
 }
 
-// ---- ps_main + post_process for one 8x8 tile (one wave) --------------------------------------------------------------
-// `second(gc, gd, ge)` delivers the lit pixels' remaining attributes (world position + tangent frame, packed like the
-// G-buffer planes c, d, e): loaded from the G-buffer, or interpolated on the spot by the visibility-buffer kernel.
+// ---- the lights of one lit pixel: get_normal (forward.hlsl:104-111), the sun (:221-222) and the point-light loop (:224-231) ----
+// nr, ng, nb: the filtered normal-map channels on the 0..255 scale; gc, gd, ge: world position + tangent frame packed like the
+// G-buffer planes c, d, e.  Returns Lo without the (1 - shadow) factor.  Shared by the fast and the general tile below, so a pixel
+// gets the same bits whichever of them shades it.
 // LOOP 1: scalar loop.  LOOP 2: two lights at a time in packed fp32.  Both read the lights through the scalar cache.
 // STATS: count lit pixels, evaluated lights, contributing (n.wi > 0) evaluations and wave-wide zero evaluations into sp.stats.
+template <int LOOP, bool STATS>
+__device__ __forceinline__ f3 lit_radiance(const ShadeParams &sp, uint32_t lane, float nr, float ng, float nb, float rough, float metal, f3 base,
+                                           const float4 &gc, const float4 &gd, const float4 &ge) {
+    // get_normal :104-111: rgb with g -> 1 - g, * 2 - 1, then mul(tbn, v), tbn columns t, b, n
+    const float r = snorm_of_bytes(nr), g = -snorm_of_bytes(ng), b = snorm_of_bytes(nb);   // (1 - g) * 2 - 1 = -(2 g - 1); nr, ng, nb on the 0..255 scale
+    const f3 n = normalize(mk(fm(ge.y, b, fm(gd.z, g, gc.w * r)), fm(ge.z, b, fm(gd.w, g, gd.x * r)), fm(ge.w, b, fm(ge.x, g, gd.y * r))));
+    const f3 world = mk(gc.x, gc.y, gc.z);
+    const f3 wo = normalize(mk(sp.eye[0], sp.eye[1], sp.eye[2]) - world);
+    // metalness is only needed after the light loop; left alone the compiler filters it there, and keeps the footprint's texels and
+    // weights (12 registers) alive through the loop for it.  The empty asm pins the filtered value in front of the loop.
+    asm volatile("" : "+v"(metal));
+    LoopPix px;
+    TailPix tp;
+    make_pix(n, wo, world, base, metal, rough, px, tp);
+    unsigned long long contributing = 0ull, wave_zero = 0ull;   // STATS
+    f3 Lo;
+    if (LOOP == 1) {
+        Sums S;
+        {   // the sun: wi = -sun_dir, radiance = sun_color (forward.hlsl:221-222)
+            const f3 d = mk(-sp.sun_dir[0], -sp.sun_dir[1], -sp.sun_dir[2]);
+            float s1, s2, s3;
+            light_scalars<false>(px, d, dot(n, d), s1, s2, s3);
+            for (int k = 0; k < 3; ++k) { S.a[k] = sp.sun_color[k] * s1; S.b[k] = sp.sun_color[k] * s2; S.c[k] = sp.sun_color[k] * s3; }
+        }
+        for (uint32_t i = 0; i < sp.n_lights; ++i) {
+            // wave-uniform, read through the CONSTANT address space: scalar loads whatever the compiler thinks may have written
+            // to global memory before (the volatile asm statements above count as writes, and a plain load would then be a vector load)
+            typedef const f4v __attribute__((address_space(4))) *const_f4;
+            const f4v lp = ((const_f4)sp.lights)[2 * i], lc = ((const_f4)sp.lights)[2 * i + 1];
+            const f3 dl = mk(lp.x, lp.y, lp.z) - world;
+            const float ndl = dot(n, dl);
+            if (STATS) { const unsigned long long mk_ = __ballot(ndl > 0.0f); contributing += __popcll(mk_); wave_zero += mk_ == 0ull ? 1 : 0; }
+            if (sp.culling && ndl <= 0.0f) continue;      // n.wi <= 0: the term is multiplied by max(n.wi, 0) = 0 (:191-192)
+            float s1, s2, s3;
+            light_scalars<true>(px, dl, ndl, s1, s2, s3);
+            S.a[0] = __builtin_fmaf(lc.x, s1, S.a[0]); S.a[1] = __builtin_fmaf(lc.y, s1, S.a[1]); S.a[2] = __builtin_fmaf(lc.z, s1, S.a[2]);
+            S.b[0] = __builtin_fmaf(lc.x, s2, S.b[0]); S.b[1] = __builtin_fmaf(lc.y, s2, S.b[1]); S.b[2] = __builtin_fmaf(lc.z, s2, S.b[2]);
+            S.c[0] = __builtin_fmaf(lc.x, s3, S.c[0]); S.c[1] = __builtin_fmaf(lc.y, s3, S.c[1]); S.c[2] = __builtin_fmaf(lc.z, s3, S.c[2]);
+        }
+        Lo = resolve_sums(tp, S.a, S.b, S.c);
+    } else {
+        Sums2 S;
+        for (int k = 0; k < 3; ++k) { S.a[k] = (v2){0.0f, 0.0f}; S.b[k] = (v2){0.0f, 0.0f}; S.c[k] = (v2){0.0f, 0.0f}; }
+        const uint32_t n_pairs = (sp.n_lights + 1) >> 1;
+        const PackedPix pk = pack_pix(px);
+        // The light pairs (3 x 16 bytes per pair: {x0,x1,y0,y1} {z0,z1,r0,r1} {g0,g1,b0,b1}) come through the scalar cache into two
+        // sets of SGPRs used alternately: the loads of pair p + 1 are issued before pair p is evaluated (one s_waitcnt per pair,
+        // hundreds of cycles after its loads).  Written as asm because the compiler's own version addresses every dword separately
+        // (40 scalar instructions per trip) and waits right after issuing.
+        const char *lp = reinterpret_cast<const char *>(sp.light_pairs);
+        auto finish = [&](v2 dx, v2 dy, v2 dz, const f4v &Bq, const f4v &C, uint32_t p) {
+            const v2 nd = accumulate_pair(pk, dx, dy, dz, (v2){Bq.z, Bq.w}, (v2){C.x, C.y}, (v2){C.z, C.w}, S);
+            if (STATS) {
+                const bool second = 2 * p + 1 < sp.n_lights;
+                const unsigned long long m0 = __ballot(nd.x > 0.0f), m1 = second ? __ballot(nd.y > 0.0f) : ~0ull;
+                contributing += __popcll(m0) + (second ? __popcll(m1) : 0);
+                wave_zero += (m0 == 0ull ? 1 : 0) + (m1 == 0ull ? 1 : 0);
+            }
+        };
+        if (n_pairs) {
+            f4v A0, B0, C0, A1, B1, C1;
+            v2 dx, dy, dz;
+            load_light_pair(lp, A0, B0, C0);
+            for (uint32_t p = 0;;) {
+                wait_and_sub((v2){A0.x, A0.y}, (v2){A0.z, A0.w}, (v2){B0.x, B0.y}, pk.w_xy, pk.wz_a2, dx, dy, dz);   // set 0 has landed
+                if (p + 1 < n_pairs) load_light_pair(lp + 48 * (p + 1), A1, B1, C1);                                  // set 1 in flight
+                finish(dx, dy, dz, B0, C0, p);
+                if (++p == n_pairs) break;
+                wait_and_sub((v2){A1.x, A1.y}, (v2){A1.z, A1.w}, (v2){B1.x, B1.y}, pk.w_xy, pk.wz_a2, dx, dy, dz);
+                if (p + 1 < n_pairs) load_light_pair(lp + 48 * (p + 1), A0, B0, C0);
+                finish(dx, dy, dz, B1, C1, p);
+                if (++p == n_pairs) break;
+            }
+        }
+        float A[3], Bs[3], Cs[3];
+        {   // the sun joins the sums
+            const f3 d = mk(-sp.sun_dir[0], -sp.sun_dir[1], -sp.sun_dir[2]);
+            float s1, s2, s3;
+            light_scalars<false>(px, d, dot(n, d), s1, s2, s3);
+            for (int k = 0; k < 3; ++k) {
+                A[k] = __builtin_fmaf(sp.sun_color[k], s1, S.a[k].x + S.a[k].y);
+                Bs[k] = __builtin_fmaf(sp.sun_color[k], s2, S.b[k].x + S.b[k].y);
+                Cs[k] = __builtin_fmaf(sp.sun_color[k], s3, S.c[k].x + S.c[k].y);
+            }
+        }
+        Lo = resolve_sums(tp, A, Bs, Cs);
+    }
+    if (STATS) {
+        const unsigned long long active = __ballot(1);
+        if (lane == (uint32_t)__ffsll((long long)active) - 1) {
+            atomicAdd(sp.stats, (unsigned long long)__popcll(active) * sp.n_lights);   // point-light evaluations of lit pixels
+            atomicAdd(sp.stats + 1, (unsigned long long)__popcll(active));            // lit pixels
+            atomicAdd(sp.stats + 2, contributing);                                     // ... of which n.wi > 0
+            atomicAdd(sp.stats + 3, wave_zero);                                        // (tile, light) pairs with n.wi <= 0 in every lit lane
+            atomicAdd(sp.stats + 4, 1ull);                                             // tiles with a lit pixel
+        }
+    }
+    return Lo;
+}
+
+// ---- ps_main + post_process for one 8x8 tile (one wave): the FAST tile ---------------------------------------------------
+// What nearly every tile of a frame is: wholly inside the target, every pixel covered by ONE material stored packed, and the
+// shadow test of every pixel decided by the bounds table (or no shadow map at all).  For such a tile the wave runs straight-line
+// code with wave-uniform branches only -- material descriptor in SGPRs, the footprint as two 16-byte loads, the RGBA8 target
+// addressed from a scalar base -- except for the lit pixels' part.  Returns false, having stored nothing, when the tile is not of
+// that kind (decided wave-wide; the texel loads already issued are then dropped): the caller shades it with shade_tile.
+// `second(gc, gd, ge)` delivers the lit pixels' remaining attributes (world position + tangent frame, packed like the
+// G-buffer planes c, d, e): loaded from the G-buffer, or interpolated on the spot by the visibility-buffer kernel.
+template <int LOOP, bool STATS, class Second>
+__device__ __forceinline__ bool shade_tile_fast(const ShadeParams &sp, const float *lut, uint32_t ty, uint32_t tx, uint32_t lane, const TileHead &cur, Second second) {
+    const int32_t row0 = (int32_t)(ty * 8) - (int32_t)sp.row0_in_tile;   // the tile's first pixel row in the target (wave-uniform)
+    if ((sp.debug & (1 | 2 | 4 | 256)) != 0 || tx * 8 + 8 > sp.width || row0 < 0 || row0 + 8 > (int32_t)sp.rows) return false;
+    if (sp.shadow_map != nullptr && sp.shadow_bounds == nullptr) return false;
+    const uint32_t mat = __float_as_uint(cur.b2);
+    const uint32_t m0 = __builtin_amdgcn_readfirstlane(mat);
+    if (m0 >= sp.n_materials || __ballot(mat != m0) != 0ull) return false;
+    const TexS d0 = tex_desc(sp.tex, m0 * 3);
+    if (!d0.packed) return false;
+    // ---- A: material fetch, forward.hlsl:98-124: the two 16-byte texel loads stay in flight over the shadow test
+    Taps pt;
+    fetch_taps_packed(d0, cur.a.x, cur.a.y, pt);
+    // ---- B: shadow test, forward.hlsl:68-96, from the bounds table alone
+    float lit = 1.0f;
+    {
+        ShadowPos spos;
+        const bool decided = shadow_quick(sp, cur.a.z, cur.a.w, cur.b0, cur.b1, spos, lit);
+        if (__ballot(!decided) != 0ull) return false;   // a tile on a shadow edge (or at the map's border)
+    }
+    // exact culling: Lo of ps_main is a sum of terms each multiplied by (1 - shadow) (point lights too: forward.hlsl:222,
+    // 230), so a fully shadowed pixel is ambient * base and needs neither the sun, nor any point light, nor its normal,
+    // tangent frame, position, metalness or roughness.
+    const bool live = sp.culling ? lit != 0.0f : true;
+    float4 gc, gd, ge;
+    if (live) second(gc, gd, ge);   // second wave of loads: lit pixels only (48 B / pixel, whole 128-byte tile rows)
+    // ---- C: base colour
+    const f3 base = mk(filt_srgb<0>(pt, lut), filt_srgb<1>(pt, lut), filt_srgb<2>(pt, lut));
+    f3 color = base * sp.ambient;
+    // ---- D: the lights
+    if (live) {
+        const f3 Lo = lit_radiance<LOOP, STATS>(sp, lane, filt_bytes<0, 3>(pt), filt_bytes<1, 0>(pt), filt_bytes<1, 1>(pt),
+                                                filt_unorm<1, 2>(pt), filt_unorm<1, 3>(pt),   // metal-rough .g, .b (forward.hlsl:117,123)
+                                                base, gc, gd, ge);
+        color = mk(__builtin_fmaf(Lo.x, lit, color.x), __builtin_fmaf(Lo.y, lit, color.y), __builtin_fmaf(Lo.z, lit, color.z));
+    }
+    // ---- E: post_process + store: the tile's first pixel is a scalar address, the lane adds (lane >> 3) rows + (lane & 7)
+    const uint32_t tile_px = (uint32_t)row0 * sp.width + tx * 8;
+    const uint32_t o = __umul24(lane >> 3, sp.width) + (lane & 7u);   // (width <= 16384)
+    store_pixel(sp, sp.out_rgba8 + (size_t)tile_px * 4u, o, tile_px + o, color);
+    return true;
+}
+
+// ---- the GENERAL tile: ragged tiles at the target's edge, pixels without geometry (skybox), several materials in one tile,
+// materials with images of unequal sizes, the 25-tap shadow test, the debug / timing options --------------------------------
 template <int LOOP, bool STATS, bool LDS_SHADOW, class Second>
 __device__ __forceinline__ void shade_tile(const ShadeParams &sp, const float *lut, float *shadow_tile, uint32_t ty, uint32_t tx,
                                            uint32_t lane, const TileHead &cur, Second second) {
@@ -618,19 +834,19 @@ __device__ __forceinline__ void shade_tile(const ShadeParams &sp, const float *l
     bool plain = false;   // lane's material is stored as three plain RGBA8 images (unequal sizes): the cold path
     auto fetch_material = [&]() {
         // an empty asm "writes" every component: nothing of an earlier fetch stays live across the shadow test's slow path
-        asm("" : "=v"(pt.q00.x), "=v"(pt.q00.y), "=v"(pt.q10.x), "=v"(pt.q10.y), "=v"(pt.q01.x), "=v"(pt.q01.y), "=v"(pt.q11.x), "=v"(pt.q11.y));
+        asm("" : "=v"(pt.r0.x), "=v"(pt.r0.y), "=v"(pt.r0.z), "=v"(pt.r0.w), "=v"(pt.r1.x), "=v"(pt.r1.y), "=v"(pt.r1.z), "=v"(pt.r1.w));
         asm("" : "=v"(pt.w00), "=v"(pt.w10), "=v"(pt.w01), "=v"(pt.w11));
         if (sp.debug & 1) {   // timing only: no texture traffic
-            pt.q00 = pt.q10 = pt.q01 = pt.q11 = make_uint2(0x808080u, 0u); pt.w00 = pt.w10 = pt.w01 = pt.w11 = 0.25f;
+            pt.r0 = pt.r1 = (u4v){0x808080u, 0u, 0x808080u, 0u}; pt.w00 = pt.w10 = pt.w01 = pt.w11 = 0.25f;
             return;
         }
         auto fetch = [&](uint32_t m, bool mine) {   // m wave-uniform: the descriptor comes through the scalar unit
             const TexS d0 = tex_desc(sp.tex, m * 3);
             if (mine) {
-                if (d0.packed) fetch_taps<8>(d0, u, v, pt);
+                if (d0.packed) fetch_taps_packed(d0, u, v, pt);
                 else {
                     Taps t0;
-                    fetch_taps<4>(d0, u, v, t0);
+                    fetch_taps_plain(d0, u, v, t0);
                     base = mk(filt_srgb<0>(t0, lut), filt_srgb<1>(t0, lut), filt_srgb<2>(t0, lut));
                     plain = true;
                 }
@@ -639,7 +855,7 @@ __device__ __forceinline__ void shade_tile(const ShadeParams &sp, const float *l
         unsigned long long todo = __ballot(covered);
         if (todo == 0ull) return;
         const uint32_t m0 = __builtin_amdgcn_readlane(mat, __ffsll((long long)todo) - 1);
-        if (__ballot(covered && mat != m0) == 0ull) {   // one material in the tile (almost always): straight-line code, the texel
+        if (__ballot(covered && mat != m0) == 0ull) {   // one material in the tile: straight-line code, the texel
             fetch(m0, covered);                        // loads go straight into their registers
             return;
         }
@@ -665,9 +881,7 @@ __device__ __forceinline__ void shade_tile(const ShadeParams &sp, const float *l
             fetch_material();
         }
     }
-    // exact culling: Lo of ps_main is a sum of terms each multiplied by (1 - shadow) (point lights too: forward.hlsl:222,
-    // 230), so a fully shadowed pixel is ambient * base and needs neither the sun, nor any point light, nor its normal,
-    // tangent frame, position, metalness or roughness.
+    // exact culling: see shade_tile_fast
     const bool live = covered && (sp.culling ? lit != 0.0f : true);
     float4 gc, gd, ge;
     if (live) second(gc, gd, ge);   // second wave of loads: lit pixels only (48 B / pixel, whole 128-byte tile rows)
@@ -699,107 +913,20 @@ __device__ __forceinline__ void shade_tile(const ShadeParams &sp, const float *l
                 const TexS d1 = tex_desc(sp.tex, m * 3 + 1), d2 = tex_desc(sp.tex, m * 3 + 2);
                 if (mine) {
                     Taps t1, t2;
-                    fetch_taps<4>(d1, u, v, t1);
-                    fetch_taps<4>(d2, u, v, t2);
+                    fetch_taps_plain(d1, u, v, t1);
+                    fetch_taps_plain(d2, u, v, t2);
                     nr = filt_bytes<0, 0>(t1); ng = filt_bytes<0, 1>(t1); nb = filt_bytes<0, 2>(t1);
                     rough = filt_unorm<0, 1>(t2); metal = filt_unorm<0, 2>(t2);
                 }
                 todo &= ~__ballot(mine);
             }
         }
-        // get_normal :104-111: rgb with g -> 1 - g, * 2 - 1, then mul(tbn, v), tbn columns t, b, n
-        const float r = snorm_of_bytes(nr), g = -snorm_of_bytes(ng), b = snorm_of_bytes(nb);   // (1 - g) * 2 - 1 = -(2 g - 1); nr, ng, nb on the 0..255 scale
-        const f3 n = normalize(mk(fm(ge.y, b, fm(gd.z, g, gc.w * r)), fm(ge.z, b, fm(gd.w, g, gd.x * r)), fm(ge.w, b, fm(ge.x, g, gd.y * r))));
-        const f3 world = mk(gc.x, gc.y, gc.z);
-        const f3 wo = normalize(mk(sp.eye[0], sp.eye[1], sp.eye[2]) - world);
-        LoopPix px;
-        TailPix tp;
-        make_pix(n, wo, world, base, metal, rough, px, tp);
-        unsigned long long contributing = 0ull, wave_zero = 0ull;   // STATS
-        f3 Lo;
-        if (LOOP == 1) {
-            Sums S;
-            {   // the sun: wi = -sun_dir, radiance = sun_color (forward.hlsl:221-222)
-                const f3 d = mk(-sp.sun_dir[0], -sp.sun_dir[1], -sp.sun_dir[2]);
-                float s1, s2, s3;
-                light_scalars<false>(px, d, dot(n, d), s1, s2, s3);
-                for (int k = 0; k < 3; ++k) { S.a[k] = sp.sun_color[k] * s1; S.b[k] = sp.sun_color[k] * s2; S.c[k] = sp.sun_color[k] * s3; }
-            }
-            for (uint32_t i = 0; i < sp.n_lights; ++i) {
-                const float4 lp = sp.lights[2 * i], lc = sp.lights[2 * i + 1];   // wave-uniform: scalar loads
-                const f3 dl = mk(lp.x, lp.y, lp.z) - world;
-                const float ndl = dot(n, dl);
-                if (STATS) { const unsigned long long mk_ = __ballot(ndl > 0.0f); contributing += __popcll(mk_); wave_zero += mk_ == 0ull ? 1 : 0; }
-                if (sp.culling && ndl <= 0.0f) continue;      // n.wi <= 0: the term is multiplied by max(n.wi, 0) = 0 (:191-192)
-                float s1, s2, s3;
-                light_scalars<true>(px, dl, ndl, s1, s2, s3);
-                S.a[0] = __builtin_fmaf(lc.x, s1, S.a[0]); S.a[1] = __builtin_fmaf(lc.y, s1, S.a[1]); S.a[2] = __builtin_fmaf(lc.z, s1, S.a[2]);
-                S.b[0] = __builtin_fmaf(lc.x, s2, S.b[0]); S.b[1] = __builtin_fmaf(lc.y, s2, S.b[1]); S.b[2] = __builtin_fmaf(lc.z, s2, S.b[2]);
-                S.c[0] = __builtin_fmaf(lc.x, s3, S.c[0]); S.c[1] = __builtin_fmaf(lc.y, s3, S.c[1]); S.c[2] = __builtin_fmaf(lc.z, s3, S.c[2]);
-            }
-            Lo = resolve_sums(tp, S.a, S.b, S.c);
-        } else {
-            Sums2 S;
-            for (int k = 0; k < 3; ++k) { S.a[k] = (v2){0.0f, 0.0f}; S.b[k] = (v2){0.0f, 0.0f}; S.c[k] = (v2){0.0f, 0.0f}; }
-            const uint32_t n_pairs = (sp.n_lights + 1) >> 1;
-            const PackedPix pk = pack_pix(px);
-            // The light pairs (3 x 16 bytes per pair: {x0,x1,y0,y1} {z0,z1,r0,r1} {g0,g1,b0,b1}) come through the scalar cache into two
-            // sets of SGPRs used alternately: the loads of pair p + 1 are issued before pair p is evaluated (one s_waitcnt per pair,
-            // hundreds of cycles after its loads).  Written as asm because the compiler's own version addresses every dword separately
-            // (40 scalar instructions per trip) and waits right after issuing.
-            const char *lp = reinterpret_cast<const char *>(sp.light_pairs);
-            auto finish = [&](v2 dx, v2 dy, v2 dz, const f4v &Bq, const f4v &C, uint32_t p) {
-                const v2 nd = accumulate_pair(pk, dx, dy, dz, (v2){Bq.z, Bq.w}, (v2){C.x, C.y}, (v2){C.z, C.w}, S);
-                if (STATS) {
-                    const bool second = 2 * p + 1 < sp.n_lights;
-                    const unsigned long long m0 = __ballot(nd.x > 0.0f), m1 = second ? __ballot(nd.y > 0.0f) : ~0ull;
-                    contributing += __popcll(m0) + (second ? __popcll(m1) : 0);
-                    wave_zero += (m0 == 0ull ? 1 : 0) + (m1 == 0ull ? 1 : 0);
-                }
-            };
-            if (n_pairs) {
-                f4v A0, B0, C0, A1, B1, C1;
-                v2 dx, dy, dz;
-                load_light_pair(lp, A0, B0, C0);
-                for (uint32_t p = 0;;) {
-                    wait_and_sub((v2){A0.x, A0.y}, (v2){A0.z, A0.w}, (v2){B0.x, B0.y}, pk.w_xy, pk.wz_a2, dx, dy, dz);   // set 0 has landed
-                    if (p + 1 < n_pairs) load_light_pair(lp + 48 * (p + 1), A1, B1, C1);                                  // set 1 in flight
-                    finish(dx, dy, dz, B0, C0, p);
-                    if (++p == n_pairs) break;
-                    wait_and_sub((v2){A1.x, A1.y}, (v2){A1.z, A1.w}, (v2){B1.x, B1.y}, pk.w_xy, pk.wz_a2, dx, dy, dz);
-                    if (p + 1 < n_pairs) load_light_pair(lp + 48 * (p + 1), A0, B0, C0);
-                    finish(dx, dy, dz, B1, C1, p);
-                    if (++p == n_pairs) break;
-                }
-            }
-            float A[3], Bs[3], Cs[3];
-            {   // the sun joins the sums
-                const f3 d = mk(-sp.sun_dir[0], -sp.sun_dir[1], -sp.sun_dir[2]);
-                float s1, s2, s3;
-                light_scalars<false>(px, d, dot(n, d), s1, s2, s3);
-                for (int k = 0; k < 3; ++k) {
-                    A[k] = __builtin_fmaf(sp.sun_color[k], s1, S.a[k].x + S.a[k].y);
-                    Bs[k] = __builtin_fmaf(sp.sun_color[k], s2, S.b[k].x + S.b[k].y);
-                    Cs[k] = __builtin_fmaf(sp.sun_color[k], s3, S.c[k].x + S.c[k].y);
-                }
-            }
-            Lo = resolve_sums(tp, A, Bs, Cs);
-        }
+        const f3 Lo = lit_radiance<LOOP, STATS>(sp, lane, nr, ng, nb, rough, metal, base, gc, gd, ge);
         color = mk(__builtin_fmaf(Lo.x, lit, color.x), __builtin_fmaf(Lo.y, lit, color.y), __builtin_fmaf(Lo.z, lit, color.z));
-        if (STATS) {
-            const unsigned long long active = __ballot(1);
-            if (lane == (uint32_t)__ffsll((long long)active) - 1) {
-                atomicAdd(sp.stats, (unsigned long long)__popcll(active) * sp.n_lights);   // point-light evaluations of lit pixels
-                atomicAdd(sp.stats + 1, (unsigned long long)__popcll(active));            // lit pixels
-                atomicAdd(sp.stats + 2, contributing);                                     // ... of which n.wi > 0
-                atomicAdd(sp.stats + 3, wave_zero);                                        // (tile, light) pairs with n.wi <= 0 in every lit lane
-                atomicAdd(sp.stats + 4, 1ull);                                             // tiles with a lit pixel
-            }
-        }
     }
 
     // ---- E: post_process + store ---------------------------------------------------------------------------------------
-    if (in_frame) store_pixel(sp, o, color);
+    if (in_frame) store_pixel(sp, sp.out_rgba8, o, o, color);
 }
 
 // the group of 8 tile rows a workgroup works on: block row g -> (g mod Q) * ceil(groups / Q) + g / Q (scalar shifts; the grid is padded to Q * ceil(groups / Q))
@@ -832,10 +959,11 @@ __global__ __launch_bounds__(256) void k_material(const ShadeParams sp) {
     stage_lds(sp, lut);
     __syncthreads();
     if (!tile_ok) return;
-    shade_tile<LOOP, STATS, LDS_SHADOW>(sp, lut, shadow_tiles[LDS_SHADOW ? wave : 0], ty, tx, lane, cur,
-                            [&](float4 &gc, float4 &gd, float4 &ge) {
-                                gc = gload_f4(sp.g.c + tile * 64, lane * 16u); gd = gload_f4(sp.g.d + tile * 64, lane * 16u); ge = gload_f4(sp.g.e + tile * 64, lane * 16u);
-                            });
+    const auto second = [&](float4 &gc, float4 &gd, float4 &ge) {
+        gc = gload_f4(sp.g.c + tile * 64, lane * 16u); gd = gload_f4(sp.g.d + tile * 64, lane * 16u); ge = gload_f4(sp.g.e + tile * 64, lane * 16u);
+    };
+    if (shade_tile_fast<LOOP, STATS>(sp, lut, ty, tx, lane, cur, second)) return;
+    shade_tile<LOOP, STATS, LDS_SHADOW>(sp, lut, shadow_tiles[LDS_SHADOW ? wave : 0], ty, tx, lane, cur, second);
 }
 
 // ---- the same without a G-buffer (whole frames): the tile walk straight from the visibility plane ----------------------
@@ -923,7 +1051,7 @@ __global__ __launch_bounds__(256) void k_material_vis(const ShadeParams sp) {
         cur.b0 = interpolate_attr(B, A0, A1, A2, 16); cur.b1 = interpolate_attr(B, A0, A1, A2, 17);
         cur.b2 = __uint_as_float(ob.material);
     }
-    shade_tile<LOOP, STATS, LDS_SHADOW>(sp, lut, shadow_tiles[LDS_SHADOW ? wave : 0], ty, tx, lane, cur, [&](float4 &gc, float4 &gd, float4 &ge) {
+    const auto second = [&](float4 &gc, float4 &gd, float4 &ge) {
         // attribute order (XVert::attr): uv 0-1, t 2-4, b 5-7, n 8-10, world 11-13, light space 14-17; planes as gbuffer_pack
         const auto mix = [&](float x0, float x1, float x2) {
 #pragma clang fp contract(off)
@@ -943,7 +1071,9 @@ __global__ __launch_bounds__(256) void k_material_vis(const ShadeParams sp) {
             gd = make_float4(interpolate_attr(B, A0, A1, A2, 3), interpolate_attr(B, A0, A1, A2, 4), interpolate_attr(B, A0, A1, A2, 5), interpolate_attr(B, A0, A1, A2, 6));
             ge = make_float4(interpolate_attr(B, A0, A1, A2, 7), interpolate_attr(B, A0, A1, A2, 8), interpolate_attr(B, A0, A1, A2, 9), interpolate_attr(B, A0, A1, A2, 10));
         }
-    });
+    };
+    if (shade_tile_fast<LOOP, STATS>(sp, lut, ty, tx, lane, cur, second)) return;
+    shade_tile<LOOP, STATS, LDS_SHADOW>(sp, lut, shadow_tiles[LDS_SHADOW ? wave : 0], ty, tx, lane, cur, second);
 }
 
 // ---- shadow bounds: the conservative min/max table calculate_lit tests first -------------------------------------------

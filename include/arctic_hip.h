@@ -264,7 +264,8 @@ int arctic_stats(ArcticRenderer *r, uint64_t *out, uint32_t n);
                                           bit 5 every triangle through the 64-bit integer rasteriser instead of the binary64 planes (same image: the path
                                           of triangles with snapped coordinates of 2^24 and more); bit 6 whole frames gather records and vertices through 64-bit
                                           pointers (the path of tables of 4 GiB and more) instead of 32-bit offsets (same image); bit 7 arctic_render_frame draws the
-                                          shadow map on the main stream before the visibility prepass instead of beside it on a second stream (same image) */
+                                          shadow map on the main stream before the visibility prepass instead of beside it on a second stream (same image);
+                                          bit 8 every tile through the general tile code, none through the fast tile (same image; A/B and tests) */
 #define ARCTIC_OPT_HDR16             6 /* 1 = round ps_main's colour through binary16 before post_process, like the reference's
                                         R16G16B16A16_FLOAT colour target (forward_pass.cpp:149, renderer.cpp:128-144); default 0 = fp32 */
 #define ARCTIC_OPT_SHADOW_CACHE      9 /* 1 (default) = arctic_render_frame redraws the shadow map only when the sun, the objects or the mesh list changed

@@ -148,6 +148,31 @@ def test_frame_from_visibility_plane_equals_frame_through_gbuffer(pair):
         r.set_option("debug", 0)
 
 
+def test_fast_tile_equals_general_tile(pair):
+    """shade.hip has two code paths per 8x8 tile: the fast tile (whole tile inside the target, one packed material, shadow test
+    decided by the bounds table: straight-line code) and the general tile (everything else).  ARCTIC_OPT_DEBUG bit 8 sends every
+    tile through the general one.  Both call the same arithmetic in the same order: float planes and RGBA8 are bit-identical,
+    through the G-buffer and through the visibility plane, with either light loop, with and without exact culling."""
+    sc, o, r = pair
+    try:
+        for path in (1, 2):
+            for culling in (1, 0):
+                r.set_option("light_path", path); r.set_option("culling", culling)
+                outs = []
+                for dbg in (0, 256):
+                    r.set_option("debug", dbg)
+                    r.pass_shadow_map(sc.desc); r.pass_gbuffer(sc.desc)
+                    r.pass_shade(sc.desc, sc.settings)
+                    ldr, hdr, rgba = (x.copy() for x in r.read_output())
+                    frame = r.render_frame(sc.desc, sc.settings).copy()
+                    outs.append((ldr, hdr, rgba, frame, r.read_output()[0].copy()))
+                for a, b in zip(*outs):
+                    np.testing.assert_array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b)
+    finally:
+        r.set_option("debug", 0); r.set_option("light_path", 0); r.set_option("culling", 1)
+        r.pass_shadow_map(sc.desc); r.pass_gbuffer(sc.desc)
+
+
 def test_light_paths_agree(pair, pkg):
     """ARCTIC_OPT_LIGHT_PATH: the shading kernel runs the light loop scalar (1: lights through the scalar cache) or two
     lights at a time in packed fp32 from LDS (2); 0 picks by light count.  Same formulas: the float images agree to fp32
