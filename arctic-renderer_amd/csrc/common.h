@@ -188,6 +188,7 @@ struct ShadeParams {
     int32_t hdr16;                      // 1: round ps_main's colour through binary16 like the reference's RGBA16F target
     int32_t compact_tables;             // 1: the record, vertex and object tables are below 4 GiB each: k_material_vis addresses them with 32-bit byte offsets
     int32_t debug;                      // timing experiments only: 1 skip material textures, 2 skip shadow test
+    unsigned long long *trace;          // ARCTIC_OPT_TILE_TRACE: 4 x u64 per tile (shade.hip: trace_end), or null
     uint32_t group_shift, group_q;      // dispatch order of the groups of 8 tile rows (ARCTIC_OPT_ROW_ORDER): block row g works on group (g & (Q - 1)) * group_q + (g >> group_shift), Q = 1 << group_shift
 };
 struct ShadeLaunch {

@@ -195,7 +195,8 @@ struct ArcticRenderer {
     uint32_t item_cap_floor = 1u << 22;   // its smallest size (ARCTIC_OPT_ITEM_TABLE_FLOOR; tests shrink it to reach the overflow path)
     uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t light_stats[2] = {0, 0};   // stats[8], [9]: (tile, light) pairs with n.wi <= 0 in every lit lane; tiles with a lit pixel
-    int keep_float = 0, count_evals = 0, culling = 1, debug = 0, hdr16 = 0, row_order = 0;
+    int keep_float = 0, count_evals = 0, culling = 1, debug = 0, hdr16 = 0, row_order = 0, tile_trace = 0;
+    DevBuf d_tile_trace;             // ARCTIC_OPT_TILE_TRACE: 4 x u64 per tile of the latest shading pass
     uint32_t raster_blocks[2] = {2048, 2048};  // persistent grid of k_raster: [0] forward pass, [1] shadow pass
     // render_frame re-renders the shadow map only when its inputs changed (sun, objects, meshes): the reference redraws it
     // every frame (renderer.cpp:300-337), but a depth map of unchanged geometry from an unchanged light is the same map
@@ -531,6 +532,13 @@ int fill_shade_params(ArcticRenderer *r, const ArcticScene *sc, const ArcticSett
         sp.out_ldr = r->d_ldr.as<float>(); sp.out_hdr = r->d_hdr.as<float>();
     }
     sp.stats = nullptr;
+    sp.trace = nullptr;
+    if (r->tile_trace) {
+        const size_t bytes = (size_t)r->tiles_x * r->tiles_y * 32;
+        HIPCHECK(r, r->d_tile_trace.ensure(bytes));
+        HIPCHECK(r, hipMemsetAsync(r->d_tile_trace.p, 0, bytes, r->stream));
+        sp.trace = r->d_tile_trace.as<unsigned long long>();
+    }
     sp.culling = r->culling;
     sp.debug = r->debug;
     sp.hdr16 = r->hdr16;
@@ -1117,6 +1125,21 @@ int arctic_stats(ArcticRenderer *r, uint64_t *out, uint32_t n) {
     return ARCTIC_OK;
 }
 
+int arctic_read_tile_trace(ArcticRenderer *r, uint64_t *out, uint64_t capacity_tiles, uint32_t *tiles_x, uint32_t *tiles_y) {
+    if (!r) return ARCTIC_E_INVALID;
+    if (tiles_x) *tiles_x = r->tiles_x;
+    if (tiles_y) *tiles_y = r->tiles_y;
+    const uint64_t n = (uint64_t)r->tiles_x * r->tiles_y;
+    if (!out) return ARCTIC_OK;   // size query
+    if (!r->tile_trace || r->d_tile_trace.cap < n * 32) return r->fail(ARCTIC_E_STATE, "read_tile_trace: no trace (set ARCTIC_OPT_TILE_TRACE, then shade)");
+    if (capacity_tiles < n) return r->fail(ARCTIC_E_CAPACITY, "read_tile_trace: %llu tiles, room for %llu", (unsigned long long)n, (unsigned long long)capacity_tiles);
+    int rc = select_device(r);
+    if (rc) return rc;
+    HIPCHECK(r, hipStreamSynchronize(r->stream));
+    HIPCHECK(r, hipMemcpy(out, r->d_tile_trace.p, n * 32, hipMemcpyDeviceToHost));
+    return ARCTIC_OK;
+}
+
 int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value) {
     if (!r) return ARCTIC_E_INVALID;
     switch (option) {
@@ -1146,6 +1169,7 @@ int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value) {
         if (value < 0 || value > 5) return r->fail(ARCTIC_E_INVALID, "set_option: row order must be 0..5");
         r->row_order = (int)value;
         break;
+    case ARCTIC_OPT_TILE_TRACE: r->tile_trace = value != 0; break;
     case ARCTIC_OPT_SHADOW_CACHE: r->shadow_cache = value != 0; r->shadow_key.clear(); break;
     case ARCTIC_OPT_SHADOW_SHARDED: r->shadow_sharded = value != 0; r->shadow_key.clear(); break;
     default: return r->fail(ARCTIC_E_INVALID, "set_option: unknown option %u", option);

@@ -932,6 +932,24 @@ __device__ __forceinline__ void shade_tile(const ShadeParams &sp, const float *l
 // the group of 8 tile rows a workgroup works on: block row g -> (g mod Q) * ceil(groups / Q) + g / Q (scalar shifts; the grid is padded to Q * ceil(groups / Q))
 __device__ __forceinline__ uint32_t row_group(const ShadeParams &sp) { return (blockIdx.y & ((1u << sp.group_shift) - 1u)) * sp.group_q + (blockIdx.y >> sp.group_shift); }
 
+// ARCTIC_OPT_TILE_TRACE (a measuring aid, off by default: one wave-uniform branch at either end of a tile): when and where every tile
+// was shaded.  Per tile 4 x u64: s_memrealtime (the 100 MHz reference clock, the same on every XCD) at the start and the end of its
+// wave's work, HW_ID | XCC_ID << 32 (which XCD / SE / CU / SIMD / wave slot) | reference-clock ticks between the kernel's entry and the start << 40, and 1 = the fast tile | shader-clock ticks (s_memtime)
+// between start and end << 8.  tools/experiments/tile_trace.py turns it into per-SIMD timelines.
+struct TraceStart { unsigned long long entry, real, core; };
+__device__ __forceinline__ unsigned long long trace_entry(const ShadeParams &sp) { return sp.trace ? __builtin_amdgcn_s_memrealtime() : 0ull; }   // first thing in the kernel
+__device__ __forceinline__ TraceStart trace_begin(const ShadeParams &sp, unsigned long long entry) {   // behind the head loads' wait and the LDS barrier
+    TraceStart t = {entry, 0ull, 0ull};
+    if (sp.trace) { t.real = __builtin_amdgcn_s_memrealtime(); t.core = __builtin_amdgcn_s_memtime(); }
+    return t;
+}
+__device__ __forceinline__ void trace_end(const ShadeParams &sp, size_t tile, uint32_t lane, TraceStart t0, bool fast) {
+    if (!sp.trace) return;
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long hw = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);   // HW_REG_HW_ID, HW_REG_XCC_ID
+    if (lane == 0) { unsigned long long *o = sp.trace + tile * 4; o[0] = t0.real; o[1] = r1; o[2] = hw | ((t0.real - t0.entry) << 40); o[3] = (fast ? 1ull : 0ull) | ((c1 - t0.core) << 8); }
+}
+
 // LDS: the sRGB LUT
 __device__ __forceinline__ void stage_lds(const ShadeParams &sp, float *lut) { lut[threadIdx.x] = sp.srgb_lut[threadIdx.x]; }
 
@@ -940,6 +958,7 @@ template <int LOOP, bool STATS, bool LDS_SHADOW>
 __global__ __launch_bounds__(256) void k_material(const ShadeParams sp) {
     __shared__ float lut[256];
     __shared__ float shadow_tiles[LDS_SHADOW ? 4 : 1][LDS_SHADOW ? SHADOW_TILE * SHADOW_TILE : 1];   // one per wave (the LDS variant of the PCF slow path)
+    const unsigned long long t_entry = trace_entry(sp);
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (each with its own 4 MiB L2), so physical block b
@@ -959,11 +978,13 @@ __global__ __launch_bounds__(256) void k_material(const ShadeParams sp) {
     stage_lds(sp, lut);
     __syncthreads();
     if (!tile_ok) return;
+    const TraceStart t0 = trace_begin(sp, t_entry);
     const auto second = [&](float4 &gc, float4 &gd, float4 &ge) {
         gc = gload_f4(sp.g.c + tile * 64, lane * 16u); gd = gload_f4(sp.g.d + tile * 64, lane * 16u); ge = gload_f4(sp.g.e + tile * 64, lane * 16u);
     };
-    if (shade_tile_fast<LOOP, STATS>(sp, lut, ty, tx, lane, cur, second)) return;
-    shade_tile<LOOP, STATS, LDS_SHADOW>(sp, lut, shadow_tiles[LDS_SHADOW ? wave : 0], ty, tx, lane, cur, second);
+    const bool fast = shade_tile_fast<LOOP, STATS>(sp, lut, ty, tx, lane, cur, second);
+    if (!fast) shade_tile<LOOP, STATS, LDS_SHADOW>(sp, lut, shadow_tiles[LDS_SHADOW ? wave : 0], ty, tx, lane, cur, second);
+    trace_end(sp, tile, lane, t0, fast);
 }
 
 // ---- the same without a G-buffer (whole frames): the tile walk straight from the visibility plane ----------------------
@@ -976,6 +997,7 @@ template <int LOOP, bool STATS, bool LDS_SHADOW>
 __global__ __launch_bounds__(256) void k_material_vis(const ShadeParams sp) {
     __shared__ float lut[256];
     __shared__ float shadow_tiles[LDS_SHADOW ? 4 : 1][LDS_SHADOW ? SHADOW_TILE * SHADOW_TILE : 1];   // one per wave (the LDS variant of the PCF slow path)
+    const unsigned long long t_entry = trace_entry(sp);
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t ty = row_group(sp) * 8 + (blockIdx.x & 7u), tx = (blockIdx.x >> 3) * 4 + wave;   // XCD-aware, interleaved order: see k_material
@@ -986,6 +1008,7 @@ __global__ __launch_bounds__(256) void k_material_vis(const ShadeParams sp) {
     stage_lds(sp, lut);
     __syncthreads();
     if (!tile_ok) return;
+    const TraceStart t0 = trace_begin(sp, t_entry);
     const int32_t px = (int32_t)(tx * 8 + (lane & 7));
     const int32_t py = (row_global((int)ty, sp.band_tiles, sp.shard_count, sp.shard_index) + sp.tile_y0) * 8 + (int32_t)(lane >> 3);
     TileHead cur;
@@ -1072,8 +1095,9 @@ __global__ __launch_bounds__(256) void k_material_vis(const ShadeParams sp) {
             ge = make_float4(interpolate_attr(B, A0, A1, A2, 7), interpolate_attr(B, A0, A1, A2, 8), interpolate_attr(B, A0, A1, A2, 9), interpolate_attr(B, A0, A1, A2, 10));
         }
     };
-    if (shade_tile_fast<LOOP, STATS>(sp, lut, ty, tx, lane, cur, second)) return;
-    shade_tile<LOOP, STATS, LDS_SHADOW>(sp, lut, shadow_tiles[LDS_SHADOW ? wave : 0], ty, tx, lane, cur, second);
+    const bool fast = shade_tile_fast<LOOP, STATS>(sp, lut, ty, tx, lane, cur, second);
+    if (!fast) shade_tile<LOOP, STATS, LDS_SHADOW>(sp, lut, shadow_tiles[LDS_SHADOW ? wave : 0], ty, tx, lane, cur, second);
+    trace_end(sp, (size_t)ty * sp.tiles_x + tx, lane, t0, fast);
 }
 
 // ---- shadow bounds: the conservative min/max table calculate_lit tests first -------------------------------------------

@@ -233,6 +233,15 @@ class Renderer:
         self._check(self.L.arctic_stats(self.h, _ptr(s), 10))
         return s
 
+    def tile_trace(self):
+        """(tiles_y, tiles_x, 4) uint64 of the latest shading pass under set_option("tile_trace", 1): start, end (100 MHz
+        reference clock), HW_ID | XCC_ID << 32, 1 = fast tile | shader-clock ticks << 8 (arctic_read_tile_trace)."""
+        tx, ty = C.c_uint32(0), C.c_uint32(0)
+        self._check(self.L.arctic_read_tile_trace(self.h, None, 0, C.byref(tx), C.byref(ty)))
+        out = np.zeros((ty.value, tx.value, 4), np.uint64)
+        self._check(self.L.arctic_read_tile_trace(self.h, _ptr(out), tx.value * ty.value, C.byref(tx), C.byref(ty)))
+        return out
+
     def set_option(self, name, value):
         self._check(self.L.arctic_set_option(self.h, binding.OPTIONS[name], int(value)))
 

@@ -286,8 +286,17 @@ int arctic_stats(ArcticRenderer *r, uint64_t *out, uint32_t n);
                                          (group 0, n/Q, 2n/Q, ..., 1, n/Q + 1, ...), so that the workgroups resident at one time come from Q distant parts of
                                          the frame -- lit (ALU-bound) and shadowed (latency-bound) regions are spatially clustered, and a SIMD hides the
                                          one behind the other only while it holds waves of both kinds.  0 = top to bottom.  Placement only: same image */
+#define ARCTIC_OPT_TILE_TRACE        17 /* 1 = the shading pass records per 8x8 tile when its wave started and ended and where it ran (a measuring aid, default 0:
+                                         the kernels then pay one wave-uniform branch at either end of a tile); read with arctic_read_tile_trace */
 #define ARCTIC_OPT_MARKERS          13 /* 1 = roctx ranges around each pass, named like the reference's Tracy zones (process-wide; libroctx64 is loaded on demand) */
 int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value);
+
+/* The trace of the latest shading pass under ARCTIC_OPT_TILE_TRACE: 4 x uint64 per tile, tile-row major over the handle's tile
+   grid (tiles_x x tiles_y, returned too): the 100 MHz reference clock (s_memrealtime) when the tile's wave started, when it ended,
+   HW_ID | XCC_ID << 32 (XCD / SE / CU / SIMD / wave slot it ran on), and 1 = shaded by the fast tile code | shader-clock ticks between
+   start and end << 8.  out == NULL only reports the grid.  Synchronises.  No counterpart in
+   the reference (its GPU timing is Tracy zones per pass, renderer.cpp:285-357); tools/experiments/tile_trace.py reads it. */
+int arctic_read_tile_trace(ArcticRenderer *r, uint64_t *out, uint64_t capacity_tiles, uint32_t *tiles_x, uint32_t *tiles_y);
 
 /* library/ABI version: major*10000 + minor*100 + patch */
 int arctic_version(void);
