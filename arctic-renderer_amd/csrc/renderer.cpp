@@ -196,8 +196,6 @@ struct ArcticRenderer {
     uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t light_stats[2] = {0, 0};   // stats[8], [9]: (tile, light) pairs with n.wi <= 0 in every lit lane; tiles with a lit pixel
     int keep_float = 0, count_evals = 0, culling = 1, debug = 0, hdr16 = 0, row_order = 0, tile_trace = 0;
-    uint32_t shade_blocks_per_cu = 0; // ARCTIC_OPT_SHADE_BLOCKS_PER_CU (0 = what a CU holds)
-    DevBuf d_shade_queue;            // ShadeParams::queue: zeroed once, left zeroed by every launch
     DevBuf d_tile_trace;             // ARCTIC_OPT_TILE_TRACE: 4 x u64 per tile of the latest shading pass
     uint32_t raster_blocks[2] = {2048, 2048};  // persistent grid of k_raster: [0] forward pass, [1] shadow pass
     // render_frame re-renders the shadow map only when its inputs changed (sun, objects, meshes): the reference redraws it
@@ -549,12 +547,12 @@ int fill_shade_params(ArcticRenderer *r, const ArcticScene *sc, const ArcticSett
     sp.ndc_sx = 2.0f / (float)r->width; sp.ndc_sy = 2.0f / (float)r->height;
     sp.band_tiles = (int32_t)(r->band_rows / TILE); sp.shard_index = (int32_t)r->shard_index; sp.shard_count = (int32_t)r->shard_count;
     sp.tile_y0 = (int32_t)r->tile_y0;
-    sp.walk_mirror = r->row_order == 0 ? 1u : 0u;   // shade.hip: StripQueue
-    if (!r->d_shade_queue.p) {
-        HIPCHECK(r, r->d_shade_queue.ensure(SHADE_QUEUE_DWORDS * 4));
-        HIPCHECK(r, hipMemsetAsync(r->d_shade_queue.p, 0, SHADE_QUEUE_DWORDS * 4, r->stream));
+    {   // dispatch order of the row groups (shade.hip: row_group)
+        const uint32_t groups = (r->tiles_y + 7) / 8;
+        uint32_t sh = (uint32_t)r->row_order;
+        while (sh && (1u << sh) > groups) --sh;
+        sp.group_shift = sh; sp.group_q = (groups + (1u << sh) - 1) >> sh;
     }
-    sp.queue = r->d_shade_queue.as<uint32_t>();
     const uint32_t nb = shadow_bounds_pitch(r->shadow_size);
     if (nb && !(r->debug & 8)) {   // the min/max table of the shadow map: rebuilt whenever the map was written
         int rc = build_shadow_bounds(r, r->stream);
@@ -572,8 +570,6 @@ hipError_t shade_once(ArcticRenderer *r, const ShadeParams &sp, bool from_vis, b
     L.loop = r->light_path == 0 ? (sp.n_lights <= 16 ? 1u : 2u) : (uint32_t)r->light_path;
     L.from_vis = from_vis ? 1u : 0u;
     L.stats = stats ? 1u : 0u;
-    L.cu_count = r->cu_count;
-    L.blocks_per_cu = r->shade_blocks_per_cu;
     return launch_shade(sp, L);
 }
 
@@ -722,7 +718,7 @@ void arctic_destroy(ArcticRenderer *r) {
     for (Mesh &m : r->meshes) { if (m.d_vertices) (void)hipFree(m.d_vertices); if (m.d_indices) (void)hipFree(m.d_indices); }
     for (void *p : r->tex_allocs) (void)hipFree(p);
     DevBuf *bufs[] = {&r->d_tex, &r->d_lut, &r->d_lights, &r->d_light_pairs, &r->d_shadow_set[0], &r->d_shadow_set[1], &r->d_env, &r->d_vis_set[0], &r->d_vis_set[1], &r->d_p0, &r->d_p1, &r->d_p2, &r->d_p3, &r->d_p4,
-                      &r->d_rgba8, &r->d_ldr, &r->d_hdr, &r->d_counter, &r->d_shade_queue, &r->d_tile_trace, &r->d_shadow_blocks_set[0], &r->d_shadow_blocks_set[1], &r->d_shadow_bounds_set[0], &r->d_shadow_bounds_set[1], &r->d_staging, &r->d_layout, &r->geo[0].d_xverts, &r->geo[1].d_xverts, &r->geo[2].d_xverts,
+                      &r->d_rgba8, &r->d_ldr, &r->d_hdr, &r->d_counter, &r->d_shadow_blocks_set[0], &r->d_shadow_blocks_set[1], &r->d_shadow_bounds_set[0], &r->d_shadow_bounds_set[1], &r->d_staging, &r->d_layout, &r->geo[0].d_xverts, &r->geo[1].d_xverts, &r->geo[2].d_xverts,
                       &r->geo[2].d_recs, &r->geo[2].d_rrecs, &r->geo[2].d_clip_list, &r->geo[2].d_rec_of, &r->geo[2].d_items, &r->tables[2].d,
                       &r->geo[0].d_recs, &r->geo[0].d_rrecs, &r->geo[0].d_clip_list, &r->geo[0].d_rec_of, &r->geo[0].d_items,
                       &r->geo[1].d_recs, &r->geo[1].d_rrecs, &r->geo[1].d_clip_list, &r->geo[1].d_rec_of, &r->geo[1].d_items, &r->d_geo_counters, &r->d_stage, &r->tables[0].d, &r->tables[1].d};
@@ -1170,12 +1166,8 @@ int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value) {
         r->item_cap_floor = (uint32_t)value; r->geo[0].item_cap = r->geo[1].item_cap = r->geo[2].item_cap = 0;
         break;
     case ARCTIC_OPT_ROW_ORDER:
-        if (value < 0 || value > 1) return r->fail(ARCTIC_E_INVALID, "set_option: row order must be 0 or 1");
+        if (value < 0 || value > 5) return r->fail(ARCTIC_E_INVALID, "set_option: row order must be 0..5");
         r->row_order = (int)value;
-        break;
-    case ARCTIC_OPT_SHADE_BLOCKS_PER_CU:
-        if (value < 0 || value > 64) return r->fail(ARCTIC_E_INVALID, "set_option: shade blocks per CU must be 0 (default) .. 64");
-        r->shade_blocks_per_cu = (uint32_t)value;
         break;
     case ARCTIC_OPT_TILE_TRACE: r->tile_trace = value != 0; break;
     case ARCTIC_OPT_SHADOW_CACHE: r->shadow_cache = value != 0; r->shadow_key.clear(); break;

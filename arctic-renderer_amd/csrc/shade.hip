@@ -36,13 +36,6 @@ namespace arctic {
 
 namespace {
 
-// The kernels read their argument block through the CONSTANT address space at the point of use (scalar loads), from a pointer
-// that is "changed" by an empty asm once per tile: inside the persistent tile loop nothing derived from it can be hoisted
-// in front of the loop and kept in registers for all of it (the block is 100 dwords: left alone, the compiler loads it once,
-// spills SGPRs into VGPR lanes and keeps a dozen 64-bit per-lane addresses alive).
-typedef const ShadeParams __attribute__((address_space(4))) &SP;
-typedef const ShadeParams __attribute__((address_space(4))) *KernArgs;
-
 struct f3 { float x, y, z; };
 __device__ __forceinline__ f3 mk(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
 __device__ __forceinline__ f3 operator+(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
@@ -270,7 +263,7 @@ __device__ __forceinline__ int wave_min_i32(int v) {
     return v;
 }
 // returns true when the wave's undecided lanes were handled here (lit updated); false: the caller takes the register path
-__device__ __forceinline__ bool shadow_lds_tile(SP sp, float *tile /* this wave's SHADOW_TILE^2 floats */, uint32_t lane, bool undecided,
+__device__ __forceinline__ bool shadow_lds_tile(const ShadeParams &sp, float *tile /* this wave's SHADOW_TILE^2 floats */, uint32_t lane, bool undecided,
                                                 const float px, const float py, const float pz, float &lit) {
 #pragma clang fp contract(off)
     const uint32_t S = sp.shadow_size;
@@ -312,7 +305,7 @@ __device__ __forceinline__ bool shadow_lds_tile(SP sp, float *tile /* this wave'
 // 1 - shadow in two steps.  shadow_quick decides from the bounds table where it can (and for every pixel outside the map);
 // returns false for the lanes that need shadow_slow: tiles on a shadow edge, the map's border, maps above 5000^2.
 struct ShadowPos { float px, py, pz; };
-__device__ __forceinline__ bool shadow_quick(SP sp, float lsx, float lsy, float lsz, float lsw, ShadowPos &p, float &lit) {
+__device__ __forceinline__ bool shadow_quick(const ShadeParams &sp, float lsx, float lsy, float lsz, float lsw, ShadowPos &p, float &lit) {
 #pragma clang fp contract(off)
     lit = 1.0f;
     if (sp.shadow_map == nullptr) return true;
@@ -336,7 +329,7 @@ __device__ __forceinline__ bool shadow_quick(SP sp, float lsx, float lsy, float 
     // outside the map: no shadow (forward.hlsl:75-77); everything else takes the slow path
     return p.pz > 1.0f || p.px < 0.0f || p.py < 0.0f || p.px > 1.0f || p.py > 1.0f;
 }
-__device__ __forceinline__ float shadow_slow(SP sp, const ShadowPos &p) {
+__device__ __forceinline__ float shadow_slow(const ShadeParams &sp, const ShadowPos &p) {
     const uint32_t S = sp.shadow_size;
     return 1.0f - (S <= 5000u ? shadow_window(sp.shadow_map, S, p.px, p.py, p.pz) : shadow_generic(sp.shadow_map, S, p.px, p.py, p.pz));
 }
@@ -600,26 +593,12 @@ struct TileHead { float4 a; float b0, b1, b2; };   // a = uv.xy, ls.xy; b = ls.z
 typedef float f3v __attribute__((ext_vector_type(3), aligned(4)));
 typedef float f4a __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 gload_f4(const void *base, uint32_t o) { const f4a v = *(const f4a __attribute__((address_space(1))) *)((gchar)base + o); return make_float4(v.x, v.y, v.z, v.w); }
-__device__ __forceinline__ TileHead load_head(SP sp, size_t tile /* wave-uniform */, uint32_t lane) {
+__device__ __forceinline__ TileHead load_head(const GBuffer &g, size_t tile /* wave-uniform */, uint32_t lane) {
     TileHead t;
-    t.a = gload_f4(sp.g.a + tile * 64, lane * 16u);
-    const f3v b = *(const f3v __attribute__((address_space(1))) *)((gchar)(sp.g.b + tile * 192) + lane * 12u);
+    t.a = gload_f4(g.a + tile * 64, lane * 16u);
+    const f3v b = *(const f3v __attribute__((address_space(1))) *)((gchar)(g.b + tile * 192) + lane * 12u);
     t.b0 = b.x; t.b1 = b.y; t.b2 = b.z;
     return t;
-}
-
-// Start the head of the wave's NEXT tile on its way without a register for it: one 4-byte load per 128-byte line of the tile's run
-// in plane a (1 KiB: lanes 0..7) and in plane b (768 B: lanes 8..13), as a load-to-LDS (global_load_lds_dword: the data goes
-// straight into a scratch row of LDS nobody reads, there is no destination register to keep or to wait for).  When the wave comes
-// to that tile its head loads find the lines in the L2 / the Infinity Cache instead of HBM.
-typedef uint32_t __attribute__((address_space(3))) *lds_u32;
-__device__ __forceinline__ void touch_lines(const void *base /* wave-uniform */, uint32_t lane, uint32_t n_lines, uint32_t *sink /* this wave's 64 words of LDS */) {
-    if (lane < n_lines)
-        __builtin_amdgcn_global_load_lds((const uint32_t __attribute__((address_space(1))) *)((gchar)base + lane * 128u), (lds_u32)sink, 4, 0, 0);
-}
-__device__ __forceinline__ void touch_head(SP sp, size_t tile /* wave-uniform */, uint32_t lane, uint32_t *sink) {
-    touch_lines(sp.g.a + tile * 64, lane, 8u, sink);
-    touch_lines(sp.g.b + tile * 192, lane, 6u, sink);
 }
 
 // the reference renders ps_main into an R16G16B16A16_FLOAT target (forward_pass.cpp:149) that post_process then reads:
@@ -630,7 +609,7 @@ __device__ __forceinline__ float through_half(float x) { return (float)(_Float16
 // or the target itself), o = the pixel's index behind it (32-bit: targets are at most 16384^2 pixels); po = the pixel's index
 // in the whole target, for the optional float planes of the tests.  The uniform options are real branches (an empty volatile asm
 // keeps the compiler from turning them into conversions + selects executed by every pixel).
-__device__ __forceinline__ void store_pixel(SP sp, const uint8_t *out, uint32_t o, uint32_t po, f3 color) {
+__device__ __forceinline__ void store_pixel(const ShadeParams &sp, const uint8_t *out, uint32_t o, uint32_t po, f3 color) {
     if (sp.hdr16) { asm volatile(""); color = mk(through_half(color.x), through_half(color.y), through_half(color.z)); }
     uint32_t word;
     f3 g = mk(0.0f, 0.0f, 0.0f);
@@ -686,7 +665,7 @@ __device__ __noinline__ f3 sample_environment(const float4 *__restrict__ env, ui
 // LOOP 1: scalar loop.  LOOP 2: two lights at a time in packed fp32.  Both read the lights through the scalar cache.
 // STATS: count lit pixels, evaluated lights, contributing (n.wi > 0) evaluations and wave-wide zero evaluations into sp.stats.
 template <int LOOP, bool STATS>
-__device__ __forceinline__ f3 lit_radiance(SP sp, uint32_t lane, float nr, float ng, float nb, float rough, float metal, f3 base,
+__device__ __forceinline__ f3 lit_radiance(const ShadeParams &sp, uint32_t lane, float nr, float ng, float nb, float rough, float metal, f3 base,
                                            const float4 &gc, const float4 &gd, const float4 &ge) {
     // get_normal :104-111: rgb with g -> 1 - g, * 2 - 1, then mul(tbn, v), tbn columns t, b, n
     const float r = snorm_of_bytes(nr), g = -snorm_of_bytes(ng), b = snorm_of_bytes(nb);   // (1 - g) * 2 - 1 = -(2 g - 1); nr, ng, nb on the 0..255 scale
@@ -793,11 +772,8 @@ __device__ __forceinline__ f3 lit_radiance(SP sp, uint32_t lane, float nr, float
 // that kind (decided wave-wide; the texel loads already issued are then dropped): the caller shades it with shade_tile.
 // `second(gc, gd, ge)` delivers the lit pixels' remaining attributes (world position + tangent frame, packed like the
 // G-buffer planes c, d, e): loaded from the G-buffer, or interpolated on the spot by the visibility-buffer kernel.
-// `prefetch()` starts the loads of the wave's NEXT tile; a tile function calls it exactly once, wave-wide, at the point from where
-// the registers they land in cost nothing: a tile without lit pixels as soon as that is known, a tile with lit pixels behind its
-// light loop (the loop is what sets the kernel's register count).  The fast tile calls it only once it will not return false.
-template <int LOOP, bool STATS, class Second, class Prefetch>
-__device__ __forceinline__ bool shade_tile_fast(SP sp, const float *lut, uint32_t ty, uint32_t tx, uint32_t lane, const TileHead &cur, Second second, Prefetch prefetch) {
+template <int LOOP, bool STATS, class Second>
+__device__ __forceinline__ bool shade_tile_fast(const ShadeParams &sp, const float *lut, uint32_t ty, uint32_t tx, uint32_t lane, const TileHead &cur, Second second) {
     const int32_t row0 = (int32_t)(ty * 8) - (int32_t)sp.row0_in_tile;   // the tile's first pixel row in the target (wave-uniform)
     if ((sp.debug & (1 | 2 | 4 | 256)) != 0 || tx * 8 + 8 > sp.width || row0 < 0 || row0 + 8 > (int32_t)sp.rows) return false;
     if (sp.shadow_map != nullptr && sp.shadow_bounds == nullptr) return false;
@@ -820,8 +796,6 @@ __device__ __forceinline__ bool shade_tile_fast(SP sp, const float *lut, uint32_
     // 230), so a fully shadowed pixel is ambient * base and needs neither the sun, nor any point light, nor its normal,
     // tangent frame, position, metalness or roughness.
     const bool live = sp.culling ? lit != 0.0f : true;
-    const bool any_live = __ballot(live) != 0ull;
-    if (!any_live) prefetch();
     float4 gc, gd, ge;
     if (live) second(gc, gd, ge);   // second wave of loads: lit pixels only (48 B / pixel, whole 128-byte tile rows)
     // ---- C: base colour
@@ -834,7 +808,6 @@ __device__ __forceinline__ bool shade_tile_fast(SP sp, const float *lut, uint32_
                                                 base, gc, gd, ge);
         color = mk(__builtin_fmaf(Lo.x, lit, color.x), __builtin_fmaf(Lo.y, lit, color.y), __builtin_fmaf(Lo.z, lit, color.z));
     }
-    if (any_live) prefetch();
     // ---- E: post_process + store: the tile's first pixel is a scalar address, the lane adds (lane >> 3) rows + (lane & 7)
     const uint32_t tile_px = (uint32_t)row0 * sp.width + tx * 8;
     const uint32_t o = __umul24(lane >> 3, sp.width) + (lane & 7u);   // (width <= 16384)
@@ -844,9 +817,9 @@ __device__ __forceinline__ bool shade_tile_fast(SP sp, const float *lut, uint32_
 
 // ---- the GENERAL tile: ragged tiles at the target's edge, pixels without geometry (skybox), several materials in one tile,
 // materials with images of unequal sizes, the 25-tap shadow test, the debug / timing options --------------------------------
-template <int LOOP, bool STATS, bool LDS_SHADOW, class Second, class Prefetch>
-__device__ __forceinline__ void shade_tile(SP sp, const float *lut, float *shadow_tile, uint32_t ty, uint32_t tx,
-                                           uint32_t lane, const TileHead &cur, Second second, Prefetch prefetch) {
+template <int LOOP, bool STATS, bool LDS_SHADOW, class Second>
+__device__ __forceinline__ void shade_tile(const ShadeParams &sp, const float *lut, float *shadow_tile, uint32_t ty, uint32_t tx,
+                                           uint32_t lane, const TileHead &cur, Second second) {
     const uint32_t x = tx * 8 + (lane & 7);
     const int32_t y = (int32_t)(ty * 8 + (lane >> 3)) - (int32_t)sp.row0_in_tile;
     const bool in_frame = x < sp.width && y >= 0 && y < (int32_t)sp.rows;
@@ -952,131 +925,66 @@ __device__ __forceinline__ void shade_tile(SP sp, const float *lut, float *shado
         color = mk(__builtin_fmaf(Lo.x, lit, color.x), __builtin_fmaf(Lo.y, lit, color.y), __builtin_fmaf(Lo.z, lit, color.z));
     }
 
-    prefetch();
     // ---- E: post_process + store ---------------------------------------------------------------------------------------
     if (in_frame) store_pixel(sp, sp.out_rgba8, o, o, color);
 }
 
-// the kernel's argument block (its only parameter, at offset 0 of the kernarg segment)
-__device__ __forceinline__ KernArgs kernel_args() { return (KernArgs)__builtin_amdgcn_kernarg_segment_ptr(); }
-
-// LDS: the sRGB LUT
-__device__ __forceinline__ void stage_lds(SP sp, float *lut) { lut[threadIdx.x] = sp.srgb_lut[threadIdx.x]; }
-
-// ---- which tiles a workgroup shades: persistent workgroups, strips of four tiles claimed from a queue per XCD ---------------------
-// The shading kernels are launched as ONE workgroup per workgroup slot of the chip (launch_shade asks the runtime how many a CU
-// holds), and every workgroup shades strips of four horizontally adjacent tiles -- one per wave: neighbours share texture and
-// shadow-map lines -- until none is left.  What the round measured on the way here (profiles/r3_tile_trace_*.txt, tile by tile):
-//   * one workgroup per strip, 32,400 launches at 4K: 3.3 of the 6-7 wave slots of a SIMD hold a tile's work at any time; a third of a
-//     wave's life goes by between its launch and the arrival of its first loads, the hardware deals workgroups to the shader engines
-//     round-robin whatever their load (SIMDs hold 2.6 - 4.2 waves), and it dispatches in order: the lit region, at the bottom of
-//     the frame, comes last, so the launch begins latency-bound and ends ALU-bound instead of being both all the time;
-//   * persistent waves with a fixed share of the tiles: every slot filled, and a third of the span left to stragglers.
-// So the workgroups CLAIM their strips: one atomic add per strip on a counter per XCD (blocks are dealt round-robin over the 8
-// XCDs, each with its own L2: block b runs on XCD b % 8, and XCD x owns the tile rows y = x (mod 8) as one row-major list),
-// issued by one lane two strips ahead -- its latency is behind a whole tile's work -- and handed to the other waves through LDS at
-// the barrier that ends each strip.  Claim c is strip c / 2 from the top of the list when c is even, from the bottom when it is odd
-// (ARCTIC_OPT_ROW_ORDER 0, the default): lit regions (ALU-bound tiles) and shadowed ones (latency-bound) are spatially clustered,
-// and this way every SIMD holds both kinds all the time, wherever in the frame the light falls.  While a tile is shaded the head
-// of the wave's next tile is already on its way (touch_head).  The last workgroup to leave zeroes the counters for the next launch.
-constexpr uint32_t QUEUE_STRIDE = 32;   // dwords between the counters of two XCDs (a 128-byte line each); counter 8 = workgroups that have left
-struct StripQueue {
-    uint32_t xcd, n, strips, tiles_x, magic, mirror;
-    uint32_t *counter;
-    __device__ __forceinline__ StripQueue(SP sp) {
-        xcd = blockIdx.x & 7u;
-        tiles_x = sp.tiles_x; magic = sp.tiles_x_magic; mirror = sp.walk_mirror;
-        n = ((sp.tiles_y + 7u - xcd) >> 3) * tiles_x;   // tile rows ty = xcd + 8 r < tiles_y
-        strips = (n + 3u) >> 2;
-        counter = sp.queue + xcd * QUEUE_STRIDE;
-    }
-    __device__ __forceinline__ uint32_t claim() const { return __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    __device__ __forceinline__ bool valid(uint32_t c) const { return c < strips; }
-    // the tile of wave `wave` in the strip of claim c; false: the strip's ragged end
-    __device__ __forceinline__ bool locate(uint32_t c, uint32_t wave, uint32_t &ty, uint32_t &tx) const {   // wave-uniform (scalar unit)
-        const uint32_t strip = mirror == 0u ? c : ((c & 1u) ? strips - 1u - (c >> 1) : (c >> 1));
-        const uint32_t at = strip * 4u + wave;
-        const uint32_t r = tiles_x == 1u ? at : __umulhi(at, magic);   // at / tiles_x: exact while at * tiles_x < 2^32 (launch_shade)
-        tx = at - r * tiles_x;
-        ty = r * 8u + xcd;
-        return at < n;
-    }
-    __device__ __forceinline__ void leave(SP sp) const {   // one lane of the workgroup, after its last claim has returned
-        uint32_t *left = sp.queue + 8u * QUEUE_STRIDE;
-        if (__hip_atomic_fetch_add(left, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {
-            for (uint32_t x = 0; x < 8u; ++x) __hip_atomic_store(sp.queue + x * QUEUE_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(left, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-};
-// The loop of a persistent workgroup: body(sp, lane, ty, tx, has_next, nty, ntx) for every tile this wave gets.
-// `args` / `lane` pass through an empty asm once per tile: see SP.
-template <class Body>
-__device__ __forceinline__ void for_each_claimed_tile(KernArgs args, uint32_t lane, uint32_t wave, uint32_t *claims /* 2 words of LDS */, float *lut, Body body) {
-    const StripQueue q(*args);
-    const bool claimer = threadIdx.x == 0;
-    if (claimer) { claims[0] = q.claim(); claims[1] = q.claim(); }
-    stage_lds(*args, lut);
-    __syncthreads();
-    for (uint32_t it = 0;; ++it) {
-        asm volatile("" : "+s"(args), "+v"(lane));
-        SP sp = *args;
-        const uint32_t c = __builtin_amdgcn_readfirstlane(claims[it & 1u]);
-        if (!q.valid(c)) break;
-        const uint32_t cn = __builtin_amdgcn_readfirstlane(claims[(it + 1u) & 1u]);
-        uint32_t ahead = 0u;
-        if (claimer) ahead = q.claim();   // for the strip after the next: back long before the barrier below
-        uint32_t ty, tx, nty = 0, ntx = 0;
-        const bool has_next = q.valid(cn) && q.locate(cn, wave, nty, ntx);
-        if (q.locate(c, wave, ty, tx)) body(sp, lane, ty, tx, has_next, nty, ntx);
-        __syncthreads();   // every wave has read claims[it & 1]
-        if (claimer) claims[it & 1u] = ahead;
-    }
-    if (claimer) q.leave(*args);
-}
+// the group of 8 tile rows a workgroup works on: block row g -> (g mod Q) * ceil(groups / Q) + g / Q (scalar shifts; the grid is padded to Q * ceil(groups / Q))
+__device__ __forceinline__ uint32_t row_group(const ShadeParams &sp) { return (blockIdx.y & ((1u << sp.group_shift) - 1u)) * sp.group_q + (blockIdx.y >> sp.group_shift); }
 
 // ARCTIC_OPT_TILE_TRACE (a measuring aid, off by default: one wave-uniform branch at either end of a tile): when and where every tile
 // was shaded.  Per tile 4 x u64: s_memrealtime (the 100 MHz reference clock, the same on every XCD) at the start and the end of its
-// wave's work, HW_ID | XCC_ID << 32 (which XCD / SE / CU / SIMD / wave slot) | reference-clock ticks between the end of the wave's previous tile (or the kernel's entry) and the start << 40, and 1 = the fast tile | shader-clock ticks (s_memtime)
+// wave's work, HW_ID | XCC_ID << 32 (which XCD / SE / CU / SIMD / wave slot) | reference-clock ticks between the kernel's entry and the start << 40, and 1 = the fast tile | shader-clock ticks (s_memtime)
 // between start and end << 8.  tools/experiments/tile_trace.py turns it into per-SIMD timelines.
 struct TraceStart { unsigned long long entry, real, core; };
-__device__ __forceinline__ unsigned long long trace_entry(SP sp) { return sp.trace ? __builtin_amdgcn_s_memrealtime() : 0ull; }   // first thing in the kernel
-__device__ __forceinline__ TraceStart trace_begin(SP sp, unsigned long long entry) {   // behind the head loads' wait and the LDS barrier
+__device__ __forceinline__ unsigned long long trace_entry(const ShadeParams &sp) { return sp.trace ? __builtin_amdgcn_s_memrealtime() : 0ull; }   // first thing in the kernel
+__device__ __forceinline__ TraceStart trace_begin(const ShadeParams &sp, unsigned long long entry) {   // behind the head loads' wait and the LDS barrier
     TraceStart t = {entry, 0ull, 0ull};
     if (sp.trace) { t.real = __builtin_amdgcn_s_memrealtime(); t.core = __builtin_amdgcn_s_memtime(); }
     return t;
 }
-__device__ __forceinline__ unsigned long long trace_end(SP sp, size_t tile, uint32_t lane, TraceStart t0, bool fast) {   // returns the time: the next tile's entry
-    if (!sp.trace) return 0ull;
+__device__ __forceinline__ void trace_end(const ShadeParams &sp, size_t tile, uint32_t lane, TraceStart t0, bool fast) {
+    if (!sp.trace) return;
     const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long hw = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);   // HW_REG_HW_ID, HW_REG_XCC_ID
     if (lane == 0) { unsigned long long *o = sp.trace + tile * 4; o[0] = t0.real; o[1] = r1; o[2] = hw | ((t0.real - t0.entry) << 40); o[3] = (fast ? 1ull : 0ull) | ((c1 - t0.core) << 8); }
-    return r1;
 }
 
+// LDS: the sRGB LUT
+__device__ __forceinline__ void stage_lds(const ShadeParams &sp, float *lut) { lut[threadIdx.x] = sp.srgb_lut[threadIdx.x]; }
 
 // ---- the shading pass over a resident G-buffer ------------------------------------------------------------------------
 template <int LOOP, bool STATS, bool LDS_SHADOW>
-__global__ __launch_bounds__(256) void k_material(const ShadeParams sp_by_value) {
+__global__ __launch_bounds__(256) void k_material(const ShadeParams sp) {
     __shared__ float lut[256];
     __shared__ float shadow_tiles[LDS_SHADOW ? 4 : 1][LDS_SHADOW ? SHADOW_TILE * SHADOW_TILE : 1];   // one per wave (the LDS variant of the PCF slow path)
-    __shared__ uint32_t sink[4][64];   // where the prefetches' data goes (touch_lines): never read
-    __shared__ uint32_t claims[2];
-    const KernArgs args = kernel_args();
-    unsigned long long t_entry = trace_entry(*args);
+    const unsigned long long t_entry = trace_entry(sp);
+    const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for_each_claimed_tile(args, threadIdx.x & 63, wave, claims, lut, [&](SP sp, uint32_t lane, uint32_t ty, uint32_t tx, bool has_next, uint32_t nty, uint32_t ntx) {
-        const TraceStart t0 = trace_begin(sp, t_entry);
-        const size_t tile = (size_t)ty * sp.tiles_x + tx;   // wave-uniform
-        const TileHead cur = load_head(sp, tile, lane);
-        const auto prefetch = [&]() { if (has_next) touch_head(sp, (size_t)nty * sp.tiles_x + ntx, lane, sink[wave]); };
-        const auto second = [&](float4 &gc, float4 &gd, float4 &ge) {
-            gc = gload_f4(sp.g.c + tile * 64, lane * 16u); gd = gload_f4(sp.g.d + tile * 64, lane * 16u); ge = gload_f4(sp.g.e + tile * 64, lane * 16u);
-        };
-        const bool fast = shade_tile_fast<LOOP, STATS>(sp, lut, ty, tx, lane, cur, second, prefetch);
-        if (!fast) shade_tile<LOOP, STATS, LDS_SHADOW>(sp, lut, shadow_tiles[LDS_SHADOW ? wave : 0], ty, tx, lane, cur, second, prefetch);
-        t_entry = trace_end(sp, tile, lane, t0, fast);
-    });
+    // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (each with its own 4 MiB L2), so physical block b
+    // runs on XCD b % 8.  A workgroup = 4 horizontally adjacent tiles; XCD x takes the tile rows y = x (mod 8), walking
+    // each row left to right, so horizontal neighbours -- which share texture and shadow-map cache lines -- meet in the
+    // same L2, while all eight XCDs stay within 8 tile rows of each other in the G-buffer stream.  (Placement is a speed
+    // matter only; the grid is padded to whole groups of 8 rows and surplus blocks exit.)
+    // grid = (8 x workgroups per tile row, groups of 8 tile rows): the linear block id advances along x first, so id % 8 = x % 8
+    // ... and the row groups themselves are visited Q-way interleaved (ARCTIC_OPT_ROW_ORDER): the ~1800 workgroups resident at one time
+    // then come from Q distant bands of the frame, so a SIMD holds waves of lit tiles (ALU-bound) next to waves of shadowed ones
+    // (latency-bound) and each kind hides behind the other.
+    const uint32_t ty = row_group(sp) * 8 + (blockIdx.x & 7u), tx = (blockIdx.x >> 3) * 4 + wave;
+    const bool tile_ok = ty < sp.tiles_y && tx < sp.tiles_x;
+    const size_t tile = (size_t)ty * sp.tiles_x + tx;   // wave-uniform
+    TileHead cur;
+    if (tile_ok) cur = load_head(sp.g, tile, lane);   // in flight while LDS is staged
+    stage_lds(sp, lut);
+    __syncthreads();
+    if (!tile_ok) return;
+    const TraceStart t0 = trace_begin(sp, t_entry);
+    const auto second = [&](float4 &gc, float4 &gd, float4 &ge) {
+        gc = gload_f4(sp.g.c + tile * 64, lane * 16u); gd = gload_f4(sp.g.d + tile * 64, lane * 16u); ge = gload_f4(sp.g.e + tile * 64, lane * 16u);
+    };
+    const bool fast = shade_tile_fast<LOOP, STATS>(sp, lut, ty, tx, lane, cur, second);
+    if (!fast) shade_tile<LOOP, STATS, LDS_SHADOW>(sp, lut, shadow_tiles[LDS_SHADOW ? wave : 0], ty, tx, lane, cur, second);
+    trace_end(sp, tile, lane, t0, fast);
 }
 
 // ---- the same without a G-buffer (whole frames): the tile walk straight from the visibility plane ----------------------
@@ -1086,19 +994,21 @@ __global__ __launch_bounds__(256) void k_material(const ShadeParams sp_by_value)
 // for the lit ones -- with the very operations of k_resolve (edges.h, fp contraction off), so the pixels are bit-identical
 // to the G-buffer path.  Everything after the attributes is shade_tile, shared.
 template <int LOOP, bool STATS, bool LDS_SHADOW>
-__global__ __launch_bounds__(256) void k_material_vis(const ShadeParams sp_by_value) {
+__global__ __launch_bounds__(256) void k_material_vis(const ShadeParams sp) {
     __shared__ float lut[256];
     __shared__ float shadow_tiles[LDS_SHADOW ? 4 : 1][LDS_SHADOW ? SHADOW_TILE * SHADOW_TILE : 1];   // one per wave (the LDS variant of the PCF slow path)
-    __shared__ uint32_t sink[4][64];   // where the prefetches' data goes (touch_lines): never read
-    __shared__ uint32_t claims[2];
-    const KernArgs args = kernel_args();
-    unsigned long long t_entry = trace_entry(*args);
+    const unsigned long long t_entry = trace_entry(sp);
+    const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // (see StripQueue; what is prefetched here are the next tile's visibility keys)
-    for_each_claimed_tile(args, threadIdx.x & 63, wave, claims, lut, [&](SP sp, uint32_t lane, uint32_t ty, uint32_t tx, bool has_next, uint32_t nty, uint32_t ntx) {
+    const uint32_t ty = row_group(sp) * 8 + (blockIdx.x & 7u), tx = (blockIdx.x >> 3) * 4 + wave;   // XCD-aware, interleaved order: see k_material
+    const bool tile_ok = ty < sp.tiles_y && tx < sp.tiles_x;
+    const size_t gi = ((size_t)ty * sp.tiles_x + tx) * 64 + lane;
+    unsigned long long key = ~0ull;
+    if (tile_ok) key = sp.vis[gi];
+    stage_lds(sp, lut);
+    __syncthreads();
+    if (!tile_ok) return;
     const TraceStart t0 = trace_begin(sp, t_entry);
-    const unsigned long long key = sp.vis[((size_t)ty * sp.tiles_x + tx) * 64 + lane];
-    const auto prefetch = [&]() { if (has_next) touch_lines(sp.vis + ((size_t)nty * sp.tiles_x + ntx) * 64, lane, 4u, sink[wave]); };   // the next tile's 512 bytes of visibility keys
     const int32_t px = (int32_t)(tx * 8 + (lane & 7));
     const int32_t py = (row_global((int)ty, sp.band_tiles, sp.shard_count, sp.shard_index) + sp.tile_y0) * 8 + (int32_t)(lane >> 3);
     TileHead cur;
@@ -1185,10 +1095,9 @@ __global__ __launch_bounds__(256) void k_material_vis(const ShadeParams sp_by_va
             ge = make_float4(interpolate_attr(B, A0, A1, A2, 7), interpolate_attr(B, A0, A1, A2, 8), interpolate_attr(B, A0, A1, A2, 9), interpolate_attr(B, A0, A1, A2, 10));
         }
     };
-    const bool fast = shade_tile_fast<LOOP, STATS>(sp, lut, ty, tx, lane, cur, second, prefetch);
-    if (!fast) shade_tile<LOOP, STATS, LDS_SHADOW>(sp, lut, shadow_tiles[LDS_SHADOW ? wave : 0], ty, tx, lane, cur, second, prefetch);
-    t_entry = trace_end(sp, (size_t)ty * sp.tiles_x + tx, lane, t0, fast);
-    });
+    const bool fast = shade_tile_fast<LOOP, STATS>(sp, lut, ty, tx, lane, cur, second);
+    if (!fast) shade_tile<LOOP, STATS, LDS_SHADOW>(sp, lut, shadow_tiles[LDS_SHADOW ? wave : 0], ty, tx, lane, cur, second);
+    trace_end(sp, (size_t)ty * sp.tiles_x + tx, lane, t0, fast);
 }
 
 // ---- shadow bounds: the conservative min/max table calculate_lit tests first -------------------------------------------
@@ -1230,41 +1139,26 @@ __global__ __launch_bounds__(256) void k_post_process(const float4 *__restrict__
     if (ldr) { ldr[i * 3] = l.x; ldr[i * 3 + 1] = l.y; ldr[i * 3 + 2] = l.z; }
 }
 
-// One workgroup per workgroup slot: CUs x the workgroups of this kernel a CU holds at a time (asked of the runtime once per kernel),
-// a multiple of 8 so that every XCD gets the same number, and no more than there are strips.
 template <int LOOP, bool STATS, bool LDS_SHADOW>
-hipError_t launch_variant(const ShadeParams &sp, const ShadeLaunch &L) {
-    static int per_cu[2] = {0, 0};
-    int &occ = per_cu[L.from_vis ? 1 : 0];
-    if (occ == 0) {
-        int n = 0;
-        const hipError_t e = L.from_vis ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_material_vis<LOOP, STATS, LDS_SHADOW>, 256, 0)
-                                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_material<LOOP, STATS, LDS_SHADOW>, 256, 0);
-        if (e != hipSuccess) return e;
-        occ = n > 0 ? n : 1;
-    }
-    uint32_t blocks = L.blocks_per_cu ? L.cu_count * L.blocks_per_cu : L.cu_count * (uint32_t)occ;
-    const uint32_t strips = (((sp.tiles_y + 7u) / 8u) * sp.tiles_x + 3u) / 4u;   // of the XCD with the most rows
-    if (blocks > 8u * strips) blocks = 8u * strips;
-    blocks = (blocks + 7u) & ~7u;
-    if (L.from_vis) k_material_vis<LOOP, STATS, LDS_SHADOW><<<blocks, 256, 0, L.stream>>>(sp);
-    else k_material<LOOP, STATS, LDS_SHADOW><<<blocks, 256, 0, L.stream>>>(sp);
+hipError_t launch_variant(const ShadeParams &sp, const ShadeLaunch &L, dim3 grid) {
+    if (L.from_vis) k_material_vis<LOOP, STATS, LDS_SHADOW><<<grid, 256, 0, L.stream>>>(sp);
+    else k_material<LOOP, STATS, LDS_SHADOW><<<grid, 256, 0, L.stream>>>(sp);
     return hipGetLastError();
 }
 
 }  // namespace
 
-// The shading pass: one launch of persistent workgroups (StripQueue).  L.loop: 1 scalar light loop, 2 packed pairs.
-// sp.queue: 9 x QUEUE_STRIDE zeroed dwords of device memory owned by the caller (the kernel leaves them zeroed).
-hipError_t launch_shade(const ShadeParams &sp_in, const ShadeLaunch &L) {
-    if (sp_in.tiles_x == 0 || sp_in.tiles_y == 0) return hipSuccess;
-    ShadeParams sp = sp_in;
-    sp.tiles_x_magic = sp.tiles_x > 1 ? (uint32_t)((1ull << 32) / sp.tiles_x) + 1u : 0u;   // StripQueue::locate: i / tiles_x = umulhi(i, magic) while i * tiles_x < 2^32
-    if ((uint64_t)((sp.tiles_y + 7u) / 8u + 1u) * sp.tiles_x * sp.tiles_x >= (1ull << 32)) return hipErrorInvalidValue;   // (16384^2 targets: 2^30)
+// The shading pass: one launch, one workgroup per 4 horizontally adjacent tiles (grid padded to whole groups of 8 tile rows
+// for the XCD-aware order).  L.loop: 1 scalar light loop, 2 packed pairs.
+hipError_t launch_shade(const ShadeParams &sp, const ShadeLaunch &L) {
+    const uint32_t n_tiles = sp.tiles_x * sp.tiles_y;
+    if (n_tiles == 0) return hipSuccess;
+    const uint32_t bpr = (sp.tiles_x + 3) / 4;
+    const dim3 grid(8 * bpr, sp.group_q << sp.group_shift);   // Q * ceil(row groups / Q) block rows: surplus groups exit
     if (sp.debug & 16)   // A/B only: the 25-tap path staged through LDS (a separate instantiation: it costs the default kernels nothing)
-        return L.loop == 2 ? launch_variant<2, false, true>(sp, L) : launch_variant<1, false, true>(sp, L);
-    if (L.loop == 2) return L.stats ? launch_variant<2, true, false>(sp, L) : launch_variant<2, false, false>(sp, L);
-    return L.stats ? launch_variant<1, true, false>(sp, L) : launch_variant<1, false, false>(sp, L);
+        return L.loop == 2 ? launch_variant<2, false, true>(sp, L, grid) : launch_variant<1, false, true>(sp, L, grid);
+    if (L.loop == 2) return L.stats ? launch_variant<2, true, false>(sp, L, grid) : launch_variant<2, false, false>(sp, L, grid);
+    return L.stats ? launch_variant<1, true, false>(sp, L, grid) : launch_variant<1, false, false>(sp, L, grid);
 }
 
 hipError_t launch_shadow_bounds(const float *map, uint32_t S, float2 *blocks, float2 *bounds, hipStream_t s) {
