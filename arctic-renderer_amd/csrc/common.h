@@ -189,15 +189,17 @@ struct ShadeParams {
     int32_t compact_tables;             // 1: the record, vertex and object tables are below 4 GiB each: k_material_vis addresses them with 32-bit byte offsets
     int32_t debug;                      // timing experiments only: 1 skip material textures, 2 skip shadow test
     unsigned long long *trace;          // ARCTIC_OPT_TILE_TRACE: 4 x u64 per tile (shade.hip: trace_end), or null
-    uint32_t group_shift, group_q;      // dispatch order of the groups of 8 tile rows (ARCTIC_OPT_ROW_ORDER): block row g works on group (g & (Q - 1)) * group_q + (g >> group_shift), Q = 1 << group_shift
+    uint32_t tiles_per_wave;            // tiles a wave of k_material shades one after the other (filled by launch_shade)
 };
 struct ShadeLaunch {
     hipStream_t stream;
     uint32_t loop;       // 1: scalar light loop; 2: two lights at a time in packed fp32 (both read the lights through the scalar cache)
     uint32_t from_vis;   // 1: k_material_vis (attributes interpolated from the visibility plane) instead of k_material
     uint32_t stats;      // 1: the counting variant (ShadeParams::stats)
+    uint32_t tiles_per_wave;   // 0: DEFAULT_TILES_PER_WAVE (ARCTIC_OPT_TILES_PER_WAVE)
 };
 constexpr uint32_t N_SHADE_STATS = 5;
+constexpr uint32_t DEFAULT_TILES_PER_WAVE = 2;
 // the shadow-bounds table: one entry per 4x4 texel block; only for maps whose 25 PCF taps (4e-4 S apart end to end, in fp32)
 // span less than 2 texels, so that a footprint never leaves the 4x4 window behind its first texel
 inline uint32_t shadow_bounds_pitch(uint32_t S) { return S >= 4 && S <= 4900 ? (S + 3) / 4 : 0; }

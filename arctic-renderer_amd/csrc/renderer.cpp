@@ -195,7 +195,8 @@ struct ArcticRenderer {
     uint32_t item_cap_floor = 1u << 22;   // its smallest size (ARCTIC_OPT_ITEM_TABLE_FLOOR; tests shrink it to reach the overflow path)
     uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t light_stats[2] = {0, 0};   // stats[8], [9]: (tile, light) pairs with n.wi <= 0 in every lit lane; tiles with a lit pixel
-    int keep_float = 0, count_evals = 0, culling = 1, debug = 0, hdr16 = 0, row_order = 0, tile_trace = 0;
+    int keep_float = 0, count_evals = 0, culling = 1, debug = 0, hdr16 = 0, tile_trace = 0;
+    uint32_t tiles_per_wave = 0;     // ARCTIC_OPT_TILES_PER_WAVE (0 = the library's default)
     DevBuf d_tile_trace;             // ARCTIC_OPT_TILE_TRACE: 4 x u64 per tile of the latest shading pass
     uint32_t raster_blocks[2] = {2048, 2048};  // persistent grid of k_raster: [0] forward pass, [1] shadow pass
     // render_frame re-renders the shadow map only when its inputs changed (sun, objects, meshes): the reference redraws it
@@ -547,12 +548,6 @@ int fill_shade_params(ArcticRenderer *r, const ArcticScene *sc, const ArcticSett
     sp.ndc_sx = 2.0f / (float)r->width; sp.ndc_sy = 2.0f / (float)r->height;
     sp.band_tiles = (int32_t)(r->band_rows / TILE); sp.shard_index = (int32_t)r->shard_index; sp.shard_count = (int32_t)r->shard_count;
     sp.tile_y0 = (int32_t)r->tile_y0;
-    {   // dispatch order of the row groups (shade.hip: row_group)
-        const uint32_t groups = (r->tiles_y + 7) / 8;
-        uint32_t sh = (uint32_t)r->row_order;
-        while (sh && (1u << sh) > groups) --sh;
-        sp.group_shift = sh; sp.group_q = (groups + (1u << sh) - 1) >> sh;
-    }
     const uint32_t nb = shadow_bounds_pitch(r->shadow_size);
     if (nb && !(r->debug & 8)) {   // the min/max table of the shadow map: rebuilt whenever the map was written
         int rc = build_shadow_bounds(r, r->stream);
@@ -570,6 +565,7 @@ hipError_t shade_once(ArcticRenderer *r, const ShadeParams &sp, bool from_vis, b
     L.loop = r->light_path == 0 ? (sp.n_lights <= 16 ? 1u : 2u) : (uint32_t)r->light_path;
     L.from_vis = from_vis ? 1u : 0u;
     L.stats = stats ? 1u : 0u;
+    L.tiles_per_wave = r->tiles_per_wave;
     return launch_shade(sp, L);
 }
 
@@ -1165,9 +1161,9 @@ int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value) {
         if (value < 64 || value > 0x7FFFFFF0ll) return r->fail(ARCTIC_E_INVALID, "set_option: item table floor out of range");
         r->item_cap_floor = (uint32_t)value; r->geo[0].item_cap = r->geo[1].item_cap = r->geo[2].item_cap = 0;
         break;
-    case ARCTIC_OPT_ROW_ORDER:
-        if (value < 0 || value > 5) return r->fail(ARCTIC_E_INVALID, "set_option: row order must be 0..5");
-        r->row_order = (int)value;
+    case ARCTIC_OPT_TILES_PER_WAVE:
+        if (value < 0 || value > 64) return r->fail(ARCTIC_E_INVALID, "set_option: tiles per wave must be 0 (default) .. 64");
+        r->tiles_per_wave = (uint32_t)value;
         break;
     case ARCTIC_OPT_TILE_TRACE: r->tile_trace = value != 0; break;
     case ARCTIC_OPT_SHADOW_CACHE: r->shadow_cache = value != 0; r->shadow_key.clear(); break;

@@ -36,6 +36,13 @@ namespace arctic {
 
 namespace {
 
+// The kernels read their argument block through the CONSTANT address space at the point of use (scalar loads).  k_material
+// shades up to two tiles one after the other in a loop: there the pointer to the block and the lane index pass through an empty asm
+// once per tile, so that nothing derived from them can be hoisted in front of the loop and kept in registers through it (the
+// block is 100 dwords: left alone the compiler loads it once, spills SGPRs into VGPR lanes and keeps per-lane addresses alive).
+typedef const ShadeParams __attribute__((address_space(4))) &SP;
+typedef const ShadeParams __attribute__((address_space(4))) *KernArgs;
+
 struct f3 { float x, y, z; };
 __device__ __forceinline__ f3 mk(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
 __device__ __forceinline__ f3 operator+(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
@@ -263,7 +270,7 @@ __device__ __forceinline__ int wave_min_i32(int v) {
     return v;
 }
 // returns true when the wave's undecided lanes were handled here (lit updated); false: the caller takes the register path
-__device__ __forceinline__ bool shadow_lds_tile(const ShadeParams &sp, float *tile /* this wave's SHADOW_TILE^2 floats */, uint32_t lane, bool undecided,
+__device__ __forceinline__ bool shadow_lds_tile(SP sp, float *tile /* this wave's SHADOW_TILE^2 floats */, uint32_t lane, bool undecided,
                                                 const float px, const float py, const float pz, float &lit) {
 #pragma clang fp contract(off)
     const uint32_t S = sp.shadow_size;
@@ -305,31 +312,40 @@ __device__ __forceinline__ bool shadow_lds_tile(const ShadeParams &sp, float *ti
 // 1 - shadow in two steps.  shadow_quick decides from the bounds table where it can (and for every pixel outside the map);
 // returns false for the lanes that need shadow_slow: tiles on a shadow edge, the map's border, maps above 5000^2.
 struct ShadowPos { float px, py, pz; };
-__device__ __forceinline__ bool shadow_quick(const ShadeParams &sp, float lsx, float lsy, float lsz, float lsw, ShadowPos &p, float &lit) {
+// light-space position -> shadow-map coordinates, forward.hlsl:69-74
+__device__ __forceinline__ void shadow_coords(float lsx, float lsy, float lsz, float lsw, ShadowPos &p) {
 #pragma clang fp contract(off)
-    lit = 1.0f;
-    if (sp.shadow_map == nullptr) return true;
     if (__ballot(lsw != 1.0f) == 0ull) { p.px = lsx; p.py = lsy; p.pz = lsz; }   // orthographic sun: w == 1, x / 1 == x
     else { p.px = lsx / lsw; p.py = lsy / lsw; p.pz = lsz / lsw; }
     p.px = p.px * 0.5f + 0.5f;
     p.py = p.py * 0.5f + 0.5f;
     p.py = 1.0f - p.py;
-    if (sp.shadow_bounds != nullptr) {   // only for S <= 4900 (shadow_bounds_pitch)
-        // first texel of tap 0 (u_0 = px - 2e-4) per axis.  0 <= bx < S - 3 means: inside the map with three more texels after it,
-        // so 0 < px < 1, no tap wraps, and -- the taps spanning 4e-4 S < 2 texels -- every texel a tap reads lies in [bx, bx + 3]
-        const uint32_t S = sp.shadow_size;
-        const float Sf = (float)S;
-        const int bx = floor_to_int((p.px + -0.0002f) * Sf - 0.5f), by = floor_to_int((p.py + -0.0002f) * Sf - 0.5f);
-        if ((uint32_t)bx < S - 3u && (uint32_t)by < S - 3u && !(p.pz > 1.0f)) {
-            const float2 mm = gload_f2(sp.shadow_bounds, (((uint32_t)by >> 2) * sp.bounds_pitch + ((uint32_t)bx >> 2)) * 8u);
-            if (p.pz > mm.y) { lit = 0.0f; return true; }
-            return !(p.pz > mm.x);
-        }
+}
+// the bounds-table entry that covers all 25 taps of p (byte offset into sp.shadow_bounds), or false: outside the table's reach
+__device__ __forceinline__ bool shadow_table_entry(SP sp, const ShadowPos &p, uint32_t &offset) {
+#pragma clang fp contract(off)
+    // first texel of tap 0 (u_0 = px - 2e-4) per axis.  0 <= bx < S - 3 means: inside the map with three more texels after it,
+    // so 0 < px < 1, no tap wraps, and -- the taps spanning 4e-4 S < 2 texels -- every texel a tap reads lies in [bx, bx + 3]
+    const uint32_t S = sp.shadow_size;
+    const float Sf = (float)S;
+    const int bx = floor_to_int((p.px + -0.0002f) * Sf - 0.5f), by = floor_to_int((p.py + -0.0002f) * Sf - 0.5f);
+    offset = (((uint32_t)by >> 2) * sp.bounds_pitch + ((uint32_t)bx >> 2)) * 8u;
+    return (uint32_t)bx < S - 3u && (uint32_t)by < S - 3u && !(p.pz > 1.0f);
+}
+__device__ __forceinline__ bool shadow_quick(SP sp, float lsx, float lsy, float lsz, float lsw, ShadowPos &p, float &lit) {
+    lit = 1.0f;
+    if (sp.shadow_map == nullptr) return true;
+    shadow_coords(lsx, lsy, lsz, lsw, p);
+    uint32_t offset;
+    if (sp.shadow_bounds != nullptr && shadow_table_entry(sp, p, offset)) {   // (a table only for S <= 4900: shadow_bounds_pitch)
+        const float2 mm = gload_f2(sp.shadow_bounds, offset);
+        if (p.pz > mm.y) { lit = 0.0f; return true; }
+        return !(p.pz > mm.x);
     }
     // outside the map: no shadow (forward.hlsl:75-77); everything else takes the slow path
     return p.pz > 1.0f || p.px < 0.0f || p.py < 0.0f || p.px > 1.0f || p.py > 1.0f;
 }
-__device__ __forceinline__ float shadow_slow(const ShadeParams &sp, const ShadowPos &p) {
+__device__ __forceinline__ float shadow_slow(SP sp, const ShadowPos &p) {
     const uint32_t S = sp.shadow_size;
     return 1.0f - (S <= 5000u ? shadow_window(sp.shadow_map, S, p.px, p.py, p.pz) : shadow_generic(sp.shadow_map, S, p.px, p.py, p.pz));
 }
@@ -593,10 +609,10 @@ struct TileHead { float4 a; float b0, b1, b2; };   // a = uv.xy, ls.xy; b = ls.z
 typedef float f3v __attribute__((ext_vector_type(3), aligned(4)));
 typedef float f4a __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 gload_f4(const void *base, uint32_t o) { const f4a v = *(const f4a __attribute__((address_space(1))) *)((gchar)base + o); return make_float4(v.x, v.y, v.z, v.w); }
-__device__ __forceinline__ TileHead load_head(const GBuffer &g, size_t tile /* wave-uniform */, uint32_t lane) {
+__device__ __forceinline__ TileHead load_head(SP sp, size_t tile /* wave-uniform */, uint32_t lane) {
     TileHead t;
-    t.a = gload_f4(g.a + tile * 64, lane * 16u);
-    const f3v b = *(const f3v __attribute__((address_space(1))) *)((gchar)(g.b + tile * 192) + lane * 12u);
+    t.a = gload_f4(sp.g.a + tile * 64, lane * 16u);
+    const f3v b = *(const f3v __attribute__((address_space(1))) *)((gchar)(sp.g.b + tile * 192) + lane * 12u);
     t.b0 = b.x; t.b1 = b.y; t.b2 = b.z;
     return t;
 }
@@ -609,7 +625,7 @@ __device__ __forceinline__ float through_half(float x) { return (float)(_Float16
 // or the target itself), o = the pixel's index behind it (32-bit: targets are at most 16384^2 pixels); po = the pixel's index
 // in the whole target, for the optional float planes of the tests.  The uniform options are real branches (an empty volatile asm
 // keeps the compiler from turning them into conversions + selects executed by every pixel).
-__device__ __forceinline__ void store_pixel(const ShadeParams &sp, const uint8_t *out, uint32_t o, uint32_t po, f3 color) {
+__device__ __forceinline__ void store_pixel(SP sp, const uint8_t *out, uint32_t o, uint32_t po, f3 color) {
     if (sp.hdr16) { asm volatile(""); color = mk(through_half(color.x), through_half(color.y), through_half(color.z)); }
     uint32_t word;
     f3 g = mk(0.0f, 0.0f, 0.0f);
@@ -665,7 +681,7 @@ __device__ __noinline__ f3 sample_environment(const float4 *__restrict__ env, ui
 // LOOP 1: scalar loop.  LOOP 2: two lights at a time in packed fp32.  Both read the lights through the scalar cache.
 // STATS: count lit pixels, evaluated lights, contributing (n.wi > 0) evaluations and wave-wide zero evaluations into sp.stats.
 template <int LOOP, bool STATS>
-__device__ __forceinline__ f3 lit_radiance(const ShadeParams &sp, uint32_t lane, float nr, float ng, float nb, float rough, float metal, f3 base,
+__device__ __forceinline__ f3 lit_radiance(SP sp, uint32_t lane, float nr, float ng, float nb, float rough, float metal, f3 base,
                                            const float4 &gc, const float4 &gd, const float4 &ge) {
     // get_normal :104-111: rgb with g -> 1 - g, * 2 - 1, then mul(tbn, v), tbn columns t, b, n
     const float r = snorm_of_bytes(nr), g = -snorm_of_bytes(ng), b = snorm_of_bytes(nb);   // (1 - g) * 2 - 1 = -(2 g - 1); nr, ng, nb on the 0..255 scale
@@ -773,7 +789,7 @@ __device__ __forceinline__ f3 lit_radiance(const ShadeParams &sp, uint32_t lane,
 // `second(gc, gd, ge)` delivers the lit pixels' remaining attributes (world position + tangent frame, packed like the
 // G-buffer planes c, d, e): loaded from the G-buffer, or interpolated on the spot by the visibility-buffer kernel.
 template <int LOOP, bool STATS, class Second>
-__device__ __forceinline__ bool shade_tile_fast(const ShadeParams &sp, const float *lut, uint32_t ty, uint32_t tx, uint32_t lane, const TileHead &cur, Second second) {
+__device__ __forceinline__ bool shade_tile_fast(SP sp, const float *lut, uint32_t ty, uint32_t tx, uint32_t lane, const TileHead &cur, Second second) {
     const int32_t row0 = (int32_t)(ty * 8) - (int32_t)sp.row0_in_tile;   // the tile's first pixel row in the target (wave-uniform)
     if ((sp.debug & (1 | 2 | 4 | 256)) != 0 || tx * 8 + 8 > sp.width || row0 < 0 || row0 + 8 > (int32_t)sp.rows) return false;
     if (sp.shadow_map != nullptr && sp.shadow_bounds == nullptr) return false;
@@ -818,7 +834,7 @@ __device__ __forceinline__ bool shade_tile_fast(const ShadeParams &sp, const flo
 // ---- the GENERAL tile: ragged tiles at the target's edge, pixels without geometry (skybox), several materials in one tile,
 // materials with images of unequal sizes, the 25-tap shadow test, the debug / timing options --------------------------------
 template <int LOOP, bool STATS, bool LDS_SHADOW, class Second>
-__device__ __forceinline__ void shade_tile(const ShadeParams &sp, const float *lut, float *shadow_tile, uint32_t ty, uint32_t tx,
+__device__ __forceinline__ void shade_tile(SP sp, const float *lut, float *shadow_tile, uint32_t ty, uint32_t tx,
                                            uint32_t lane, const TileHead &cur, Second second) {
     const uint32_t x = tx * 8 + (lane & 7);
     const int32_t y = (int32_t)(ty * 8 + (lane >> 3)) - (int32_t)sp.row0_in_tile;
@@ -929,62 +945,72 @@ __device__ __forceinline__ void shade_tile(const ShadeParams &sp, const float *l
     if (in_frame) store_pixel(sp, sp.out_rgba8, o, o, color);
 }
 
-// the group of 8 tile rows a workgroup works on: block row g -> (g mod Q) * ceil(groups / Q) + g / Q (scalar shifts; the grid is padded to Q * ceil(groups / Q))
-__device__ __forceinline__ uint32_t row_group(const ShadeParams &sp) { return (blockIdx.y & ((1u << sp.group_shift) - 1u)) * sp.group_q + (blockIdx.y >> sp.group_shift); }
-
 // ARCTIC_OPT_TILE_TRACE (a measuring aid, off by default: one wave-uniform branch at either end of a tile): when and where every tile
 // was shaded.  Per tile 4 x u64: s_memrealtime (the 100 MHz reference clock, the same on every XCD) at the start and the end of its
 // wave's work, HW_ID | XCC_ID << 32 (which XCD / SE / CU / SIMD / wave slot) | reference-clock ticks between the kernel's entry and the start << 40, and 1 = the fast tile | shader-clock ticks (s_memtime)
 // between start and end << 8.  tools/experiments/tile_trace.py turns it into per-SIMD timelines.
 struct TraceStart { unsigned long long entry, real, core; };
-__device__ __forceinline__ unsigned long long trace_entry(const ShadeParams &sp) { return sp.trace ? __builtin_amdgcn_s_memrealtime() : 0ull; }   // first thing in the kernel
-__device__ __forceinline__ TraceStart trace_begin(const ShadeParams &sp, unsigned long long entry) {   // behind the head loads' wait and the LDS barrier
+__device__ __forceinline__ unsigned long long trace_entry(SP sp) { return sp.trace ? __builtin_amdgcn_s_memrealtime() : 0ull; }   // first thing in the kernel
+__device__ __forceinline__ TraceStart trace_begin(SP sp, unsigned long long entry) {   // behind the head loads' wait and the LDS barrier
     TraceStart t = {entry, 0ull, 0ull};
     if (sp.trace) { t.real = __builtin_amdgcn_s_memrealtime(); t.core = __builtin_amdgcn_s_memtime(); }
     return t;
 }
-__device__ __forceinline__ void trace_end(const ShadeParams &sp, size_t tile, uint32_t lane, TraceStart t0, bool fast) {
+__device__ __forceinline__ void trace_end(SP sp, size_t tile, uint32_t lane, TraceStart t0, bool fast) {
     if (!sp.trace) return;
     const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long hw = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);   // HW_REG_HW_ID, HW_REG_XCC_ID
     if (lane == 0) { unsigned long long *o = sp.trace + tile * 4; o[0] = t0.real; o[1] = r1; o[2] = hw | ((t0.real - t0.entry) << 40); o[3] = (fast ? 1ull : 0ull) | ((c1 - t0.core) << 8); }
 }
 
+// the kernel's argument block (its only parameter, at offset 0 of the kernarg segment)
+__device__ __forceinline__ KernArgs kernel_args() { return (KernArgs)__builtin_amdgcn_kernarg_segment_ptr(); }
+
 // LDS: the sRGB LUT
-__device__ __forceinline__ void stage_lds(const ShadeParams &sp, float *lut) { lut[threadIdx.x] = sp.srgb_lut[threadIdx.x]; }
+__device__ __forceinline__ void stage_lds(SP sp, float *lut) { lut[threadIdx.x] = sp.srgb_lut[threadIdx.x]; }
 
 // ---- the shading pass over a resident G-buffer ------------------------------------------------------------------------
+// Which tiles a wave shades.  Lit regions (ALU-bound tiles: ~8000 issue cycles each at 64 lights) and shadowed ones (latency-bound:
+// ~150 instructions behind three memory round trips) are spatially clustered -- in the benchmark scene the sun reaches the lower
+// 40 % of the frame -- and the hardware dispatches workgroups in order and deals them to the shader engines round-robin whatever
+// their load.  One tile per wave, top to bottom, makes the launch latency-bound first and ALU-bound afterwards; handing out the
+// two ends of the frame alternately makes half the shader engines the one and half the other (profiles/r3_tile_trace_*.txt).
+// So every wave shades T tiles, one after the other, 1 / T of the frame's height apart (ARCTIC_OPT_TILES_PER_WAVE): every wave
+// then carries the same mix, at any moment the waves of a SIMD are spread over both kinds, and each kind hides behind the other
+// wherever in the frame the light falls; and a wave is launched once for T tiles.
+// XCD-aware: workgroups are dealt round-robin over the 8 XCDs (each with its own 4 MiB L2), so physical block b runs on XCD b % 8.
+// A workgroup = 4 horizontally adjacent tiles (they share texture and shadow-map lines), T times; XCD x takes the tile rows
+// y = x (mod 8), walking each row left to right.  grid = (8 x workgroups per tile row, 1 / T of the groups of 8 tile rows): the
+// linear block id advances along x first, so id % 8 = x % 8.  (Placement is a speed matter only; surplus blocks exit.)
 template <int LOOP, bool STATS, bool LDS_SHADOW>
-__global__ __launch_bounds__(256) void k_material(const ShadeParams sp) {
+__global__ __launch_bounds__(256) void k_material(const ShadeParams sp_by_value) {
     __shared__ float lut[256];
     __shared__ float shadow_tiles[LDS_SHADOW ? 4 : 1][LDS_SHADOW ? SHADOW_TILE * SHADOW_TILE : 1];   // one per wave (the LDS variant of the PCF slow path)
-    const unsigned long long t_entry = trace_entry(sp);
-    const uint32_t lane = threadIdx.x & 63;
+    KernArgs args = kernel_args();
+    const unsigned long long t_entry = trace_entry(*args);
+    uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (each with its own 4 MiB L2), so physical block b
-    // runs on XCD b % 8.  A workgroup = 4 horizontally adjacent tiles; XCD x takes the tile rows y = x (mod 8), walking
-    // each row left to right, so horizontal neighbours -- which share texture and shadow-map cache lines -- meet in the
-    // same L2, while all eight XCDs stay within 8 tile rows of each other in the G-buffer stream.  (Placement is a speed
-    // matter only; the grid is padded to whole groups of 8 rows and surplus blocks exit.)
-    // grid = (8 x workgroups per tile row, groups of 8 tile rows): the linear block id advances along x first, so id % 8 = x % 8
-    // ... and the row groups themselves are visited Q-way interleaved (ARCTIC_OPT_ROW_ORDER): the ~1800 workgroups resident at one time
-    // then come from Q distant bands of the frame, so a SIMD holds waves of lit tiles (ALU-bound) next to waves of shadowed ones
-    // (latency-bound) and each kind hides behind the other.
-    const uint32_t ty = row_group(sp) * 8 + (blockIdx.x & 7u), tx = (blockIdx.x >> 3) * 4 + wave;
-    const bool tile_ok = ty < sp.tiles_y && tx < sp.tiles_x;
-    const size_t tile = (size_t)ty * sp.tiles_x + tx;   // wave-uniform
-    TileHead cur;
-    if (tile_ok) cur = load_head(sp.g, tile, lane);   // in flight while LDS is staged
-    stage_lds(sp, lut);
+    const uint32_t groups = (args->tiles_y + 7u) >> 3, tx = (blockIdx.x >> 3) * 4 + wave;
+    const uint32_t T = args->tiles_per_wave, stride = (groups + T - 1u) / T;   // the block's groups of 8 tile rows: blockIdx.y + k stride
+    stage_lds(*args, lut);
     __syncthreads();
-    if (!tile_ok) return;
-    const TraceStart t0 = trace_begin(sp, t_entry);
-    const auto second = [&](float4 &gc, float4 &gd, float4 &ge) {
-        gc = gload_f4(sp.g.c + tile * 64, lane * 16u); gd = gload_f4(sp.g.d + tile * 64, lane * 16u); ge = gload_f4(sp.g.e + tile * 64, lane * 16u);
-    };
-    const bool fast = shade_tile_fast<LOOP, STATS>(sp, lut, ty, tx, lane, cur, second);
-    if (!fast) shade_tile<LOOP, STATS, LDS_SHADOW>(sp, lut, shadow_tiles[LDS_SHADOW ? wave : 0], ty, tx, lane, cur, second);
-    trace_end(sp, tile, lane, t0, fast);
+    if (tx >= args->tiles_x) return;
+#pragma nounroll
+    for (uint32_t k = 0; k < T; ++k) {
+        const uint32_t g = blockIdx.y + k * stride, ty = g * 8 + (blockIdx.x & 7u);
+        if (g >= groups || ty >= args->tiles_y) break;
+        asm volatile("" : "+s"(args), "+v"(lane));   // see SP
+        SP sp = *args;
+        const TraceStart t0 = trace_begin(sp, t_entry);
+        const size_t tile = (size_t)ty * sp.tiles_x + tx;   // wave-uniform
+        const TileHead cur = load_head(sp, tile, lane);
+        const auto second = [&](float4 &gc, float4 &gd, float4 &ge) {
+            gc = gload_f4(sp.g.c + tile * 64, lane * 16u); gd = gload_f4(sp.g.d + tile * 64, lane * 16u); ge = gload_f4(sp.g.e + tile * 64, lane * 16u);
+        };
+        const bool fast = shade_tile_fast<LOOP, STATS>(sp, lut, ty, tx, lane, cur, second);
+        if (!fast) shade_tile<LOOP, STATS, LDS_SHADOW>(sp, lut, shadow_tiles[LDS_SHADOW ? wave : 0], ty, tx, lane, cur, second);
+        trace_end(sp, tile, lane, t0, fast);
+    }
 }
 
 // ---- the same without a G-buffer (whole frames): the tile walk straight from the visibility plane ----------------------
@@ -994,13 +1020,14 @@ __global__ __launch_bounds__(256) void k_material(const ShadeParams sp) {
 // for the lit ones -- with the very operations of k_resolve (edges.h, fp contraction off), so the pixels are bit-identical
 // to the G-buffer path.  Everything after the attributes is shade_tile, shared.
 template <int LOOP, bool STATS, bool LDS_SHADOW>
-__global__ __launch_bounds__(256) void k_material_vis(const ShadeParams sp) {
+__global__ __launch_bounds__(256) void k_material_vis(const ShadeParams sp_by_value) {
+    SP sp = *kernel_args();
     __shared__ float lut[256];
     __shared__ float shadow_tiles[LDS_SHADOW ? 4 : 1][LDS_SHADOW ? SHADOW_TILE * SHADOW_TILE : 1];   // one per wave (the LDS variant of the PCF slow path)
     const unsigned long long t_entry = trace_entry(sp);
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t ty = row_group(sp) * 8 + (blockIdx.x & 7u), tx = (blockIdx.x >> 3) * 4 + wave;   // XCD-aware, interleaved order: see k_material
+    const uint32_t ty = blockIdx.y * 8 + (blockIdx.x & 7u), tx = (blockIdx.x >> 3) * 4 + wave;   // XCD-aware order: see k_material
     const bool tile_ok = ty < sp.tiles_y && tx < sp.tiles_x;
     const size_t gi = ((size_t)ty * sp.tiles_x + tx) * 64 + lane;
     unsigned long long key = ~0ull;
@@ -1150,11 +1177,13 @@ hipError_t launch_variant(const ShadeParams &sp, const ShadeLaunch &L, dim3 grid
 
 // The shading pass: one launch, one workgroup per 4 horizontally adjacent tiles (grid padded to whole groups of 8 tile rows
 // for the XCD-aware order).  L.loop: 1 scalar light loop, 2 packed pairs.
-hipError_t launch_shade(const ShadeParams &sp, const ShadeLaunch &L) {
-    const uint32_t n_tiles = sp.tiles_x * sp.tiles_y;
+hipError_t launch_shade(const ShadeParams &sp_in, const ShadeLaunch &L) {
+    const uint32_t n_tiles = sp_in.tiles_x * sp_in.tiles_y;
     if (n_tiles == 0) return hipSuccess;
-    const uint32_t bpr = (sp.tiles_x + 3) / 4;
-    const dim3 grid(8 * bpr, sp.group_q << sp.group_shift);   // Q * ceil(row groups / Q) block rows: surplus groups exit
+    ShadeParams sp = sp_in;
+    sp.tiles_per_wave = L.tiles_per_wave ? L.tiles_per_wave : DEFAULT_TILES_PER_WAVE;
+    const uint32_t bpr = (sp.tiles_x + 3) / 4, groups = (sp.tiles_y + 7) / 8;
+    const dim3 grid(8 * bpr, L.from_vis ? groups : (groups + sp.tiles_per_wave - 1) / sp.tiles_per_wave);   // k_material: a block shades tiles_per_wave groups of 8 tile rows
     if (sp.debug & 16)   // A/B only: the 25-tap path staged through LDS (a separate instantiation: it costs the default kernels nothing)
         return L.loop == 2 ? launch_variant<2, false, true>(sp, L, grid) : launch_variant<1, false, true>(sp, L, grid);
     if (L.loop == 2) return L.stats ? launch_variant<2, true, false>(sp, L, grid) : launch_variant<2, false, false>(sp, L, grid);

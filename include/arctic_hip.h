@@ -282,10 +282,10 @@ int arctic_stats(ArcticRenderer *r, uint64_t *out, uint32_t n);
 #define ARCTIC_OPT_LIGHT_PATH       12 /* the light loop of the shading kernel: 0 = automatic (default: scalar up to 16 point lights -- the reference's
                                           MAX_NUM_POINT_LIGHTS -- packed pairs above), 1 = scalar fp32, lights through the scalar cache, 2 = two lights at a
                                           time in packed fp32 from LDS.  Same formulas (images agree to fp32 rounding, ~1e-7). */
-#define ARCTIC_OPT_ROW_ORDER        16 /* log2 Q (0..5) of the shading kernel's dispatch order: the groups of 8 tile rows are visited Q-way interleaved
-                                         (group 0, n/Q, 2n/Q, ..., 1, n/Q + 1, ...), so that the workgroups resident at one time come from Q distant parts of
-                                         the frame -- lit (ALU-bound) and shadowed (latency-bound) regions are spatially clustered, and a SIMD hides the
-                                         one behind the other only while it holds waves of both kinds.  0 = top to bottom.  Placement only: same image */
+#define ARCTIC_OPT_TILES_PER_WAVE    16 /* tiles a wave of the shading pass (arctic_pass_shade) shades one after the other, 1 / n-th of the frame's height apart:
+                                         lit (ALU-bound) and shadowed (latency-bound) regions are spatially clustered, and a wave that visits n distant parts of the
+                                         frame carries a mix of both, so that every SIMD holds both kinds all the time, wherever in the frame the light falls
+                                         (and a wave is launched once for n tiles).  0 (default) = the library's choice.  Placement only: same image */
 #define ARCTIC_OPT_TILE_TRACE        17 /* 1 = the shading pass records per 8x8 tile when its wave started and ended and where it ran (a measuring aid, default 0:
                                          the kernels then pay one wave-uniform branch at either end of a tile); read with arctic_read_tile_trace */
 #define ARCTIC_OPT_MARKERS          13 /* 1 = roctx ranges around each pass, named like the reference's Tracy zones (process-wide; libroctx64 is loaded on demand) */
