@@ -190,8 +190,6 @@ struct ShadeParams {
     int32_t debug;                      // timing experiments only: 1 skip material textures, 2 skip shadow test
     unsigned long long *trace;          // ARCTIC_OPT_TILE_TRACE: 4 x u64 per tile (shade.hip: trace_end), or null
     uint32_t tiles_per_wave;            // tiles a wave of k_material shades one after the other (filled by launch_shade)
-    uint32_t tiles_x_magic;             // floor(2^32 / tiles_x) + 1 (filled by launch_shade)
-    uint32_t *queue;                    // k_material_persistent: 65 counters, 32 dwords apart, zero between launches (shade.hip: TileQueue)
 };
 struct ShadeLaunch {
     hipStream_t stream;
@@ -199,12 +197,9 @@ struct ShadeLaunch {
     uint32_t from_vis;   // 1: k_material_vis (attributes interpolated from the visibility plane) instead of k_material
     uint32_t stats;      // 1: the counting variant (ShadeParams::stats)
     uint32_t tiles_per_wave;   // 0: DEFAULT_TILES_PER_WAVE (ARCTIC_OPT_TILES_PER_WAVE)
-    uint32_t persistent;       // ARCTIC_OPT_PERSISTENT: 0 = a workgroup per strip of tiles; 1 = persistent waves claiming tiles, as many workgroups per CU as it holds; n > 1: n - 1 per CU
-    uint32_t cu_count;         // compute units of the device
 };
 constexpr uint32_t N_SHADE_STATS = 5;
 constexpr uint32_t DEFAULT_TILES_PER_WAVE = 2;
-constexpr uint32_t SHADE_QUEUE_DWORDS = 65 * 32;  // ShadeParams::queue
 // the shadow-bounds table: one entry per 4x4 texel block; only for maps whose 25 PCF taps (4e-4 S apart end to end, in fp32)
 // span less than 2 texels, so that a footprint never leaves the 4x4 window behind its first texel
 inline uint32_t shadow_bounds_pitch(uint32_t S) { return S >= 4 && S <= 4900 ? (S + 3) / 4 : 0; }

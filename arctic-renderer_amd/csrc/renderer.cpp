@@ -197,8 +197,6 @@ struct ArcticRenderer {
     uint64_t light_stats[2] = {0, 0};   // stats[8], [9]: (tile, light) pairs with n.wi <= 0 in every lit lane; tiles with a lit pixel
     int keep_float = 0, count_evals = 0, culling = 1, debug = 0, hdr16 = 0, tile_trace = 0;
     uint32_t tiles_per_wave = 0;     // ARCTIC_OPT_TILES_PER_WAVE (0 = the library's default)
-    uint32_t persistent = 0;         // ARCTIC_OPT_PERSISTENT
-    DevBuf d_shade_queue;            // ShadeParams::queue: zeroed once, left zeroed by every launch
     DevBuf d_tile_trace;             // ARCTIC_OPT_TILE_TRACE: 4 x u64 per tile of the latest shading pass
     uint32_t raster_blocks[2] = {2048, 2048};  // persistent grid of k_raster: [0] forward pass, [1] shadow pass
     // render_frame re-renders the shadow map only when its inputs changed (sun, objects, meshes): the reference redraws it
@@ -534,11 +532,6 @@ int fill_shade_params(ArcticRenderer *r, const ArcticScene *sc, const ArcticSett
         HIPCHECK(r, r->d_hdr.ensure(out_px * 12));
         sp.out_ldr = r->d_ldr.as<float>(); sp.out_hdr = r->d_hdr.as<float>();
     }
-    if (!r->d_shade_queue.p) {
-        HIPCHECK(r, r->d_shade_queue.ensure(SHADE_QUEUE_DWORDS * 4));
-        HIPCHECK(r, hipMemsetAsync(r->d_shade_queue.p, 0, SHADE_QUEUE_DWORDS * 4, r->stream));
-    }
-    sp.queue = r->d_shade_queue.as<uint32_t>();
     sp.stats = nullptr;
     sp.trace = nullptr;
     if (r->tile_trace) {
@@ -573,8 +566,6 @@ hipError_t shade_once(ArcticRenderer *r, const ShadeParams &sp, bool from_vis, b
     L.from_vis = from_vis ? 1u : 0u;
     L.stats = stats ? 1u : 0u;
     L.tiles_per_wave = r->tiles_per_wave;
-    L.persistent = r->persistent;
-    L.cu_count = r->cu_count;
     return launch_shade(sp, L);
 }
 
@@ -723,7 +714,7 @@ void arctic_destroy(ArcticRenderer *r) {
     for (Mesh &m : r->meshes) { if (m.d_vertices) (void)hipFree(m.d_vertices); if (m.d_indices) (void)hipFree(m.d_indices); }
     for (void *p : r->tex_allocs) (void)hipFree(p);
     DevBuf *bufs[] = {&r->d_tex, &r->d_lut, &r->d_lights, &r->d_light_pairs, &r->d_shadow_set[0], &r->d_shadow_set[1], &r->d_env, &r->d_vis_set[0], &r->d_vis_set[1], &r->d_p0, &r->d_p1, &r->d_p2, &r->d_p3, &r->d_p4,
-                      &r->d_rgba8, &r->d_ldr, &r->d_hdr, &r->d_counter, &r->d_shade_queue, &r->d_tile_trace, &r->d_shadow_blocks_set[0], &r->d_shadow_blocks_set[1], &r->d_shadow_bounds_set[0], &r->d_shadow_bounds_set[1], &r->d_staging, &r->d_layout, &r->geo[0].d_xverts, &r->geo[1].d_xverts, &r->geo[2].d_xverts,
+                      &r->d_rgba8, &r->d_ldr, &r->d_hdr, &r->d_counter, &r->d_shadow_blocks_set[0], &r->d_shadow_blocks_set[1], &r->d_shadow_bounds_set[0], &r->d_shadow_bounds_set[1], &r->d_staging, &r->d_layout, &r->geo[0].d_xverts, &r->geo[1].d_xverts, &r->geo[2].d_xverts,
                       &r->geo[2].d_recs, &r->geo[2].d_rrecs, &r->geo[2].d_clip_list, &r->geo[2].d_rec_of, &r->geo[2].d_items, &r->tables[2].d,
                       &r->geo[0].d_recs, &r->geo[0].d_rrecs, &r->geo[0].d_clip_list, &r->geo[0].d_rec_of, &r->geo[0].d_items,
                       &r->geo[1].d_recs, &r->geo[1].d_rrecs, &r->geo[1].d_clip_list, &r->geo[1].d_rec_of, &r->geo[1].d_items, &r->d_geo_counters, &r->d_stage, &r->tables[0].d, &r->tables[1].d};
@@ -1169,10 +1160,6 @@ int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value) {
     case ARCTIC_OPT_ITEM_TABLE_FLOOR:
         if (value < 64 || value > 0x7FFFFFF0ll) return r->fail(ARCTIC_E_INVALID, "set_option: item table floor out of range");
         r->item_cap_floor = (uint32_t)value; r->geo[0].item_cap = r->geo[1].item_cap = r->geo[2].item_cap = 0;
-        break;
-    case ARCTIC_OPT_PERSISTENT:
-        if (value < 0 || value > 33) return r->fail(ARCTIC_E_INVALID, "set_option: persistent must be 0, 1 or 1 + workgroups per CU");
-        r->persistent = (uint32_t)value;
         break;
     case ARCTIC_OPT_TILES_PER_WAVE:
         if (value < 0 || value > 64) return r->fail(ARCTIC_E_INVALID, "set_option: tiles per wave must be 0 (default) .. 64");

@@ -617,20 +617,6 @@ __device__ __forceinline__ TileHead load_head(SP sp, size_t tile /* wave-uniform
     return t;
 }
 
-// Start the head of a wave's NEXT tile on its way without a register for it (k_material_persistent): one 4-byte load per 128-byte line
-// of the tile's run in plane a (1 KiB: lanes 0..7) and in plane b (768 B: lanes 8..13), as loads-to-LDS (global_load_lds_dword: the
-// data goes straight into a scratch row of LDS nobody reads; there is no destination register to keep or to wait for).  When the
-// wave comes to that tile its head loads find the lines in the L2 / the Infinity Cache instead of HBM.
-typedef uint32_t __attribute__((address_space(3))) *lds_u32;
-__device__ __forceinline__ void touch_lines(const void *base /* wave-uniform */, uint32_t lane, uint32_t n_lines, uint32_t *sink /* this wave's 64 words of LDS */) {
-    if (lane < n_lines)
-        __builtin_amdgcn_global_load_lds((const uint32_t __attribute__((address_space(1))) *)((gchar)base + lane * 128u), (lds_u32)sink, 4, 0, 0);
-}
-__device__ __forceinline__ void touch_head(SP sp, size_t tile /* wave-uniform */, uint32_t lane, uint32_t *sink) {
-    touch_lines(sp.g.a + tile * 64, lane, 8u, sink);
-    touch_lines(sp.g.b + tile * 192, lane, 6u, sink);
-}
-
 // the reference renders ps_main into an R16G16B16A16_FLOAT target (forward_pass.cpp:149) that post_process then reads:
 // hdr16 reproduces that rounding (round-to-nearest-even to binary16, finite overflow to +inf like the ROP's conversion)
 __device__ __forceinline__ float through_half(float x) { return (float)(_Float16)x; }
@@ -802,10 +788,8 @@ __device__ __forceinline__ f3 lit_radiance(SP sp, uint32_t lane, float nr, float
 // that kind (decided wave-wide; the texel loads already issued are then dropped): the caller shades it with shade_tile.
 // `second(gc, gd, ge)` delivers the lit pixels' remaining attributes (world position + tangent frame, packed like the
 // G-buffer planes c, d, e): loaded from the G-buffer, or interpolated on the spot by the visibility-buffer kernel.
-// `prefetch()` (k_material_persistent) starts the loads of the wave's NEXT tile; a tile function calls it exactly once, wave-wide,
-// behind its shadow test, and the fast tile only once it will not return false.
-template <int LOOP, bool STATS, class Second, class Prefetch>
-__device__ __forceinline__ bool shade_tile_fast(SP sp, const float *lut, uint32_t ty, uint32_t tx, uint32_t lane, const TileHead &cur, Second second, Prefetch prefetch) {
+template <int LOOP, bool STATS, class Second>
+__device__ __forceinline__ bool shade_tile_fast(SP sp, const float *lut, uint32_t ty, uint32_t tx, uint32_t lane, const TileHead &cur, Second second) {
     const int32_t row0 = (int32_t)(ty * 8) - (int32_t)sp.row0_in_tile;   // the tile's first pixel row in the target (wave-uniform)
     if ((sp.debug & (1 | 2 | 4 | 256)) != 0 || tx * 8 + 8 > sp.width || row0 < 0 || row0 + 8 > (int32_t)sp.rows) return false;
     if (sp.shadow_map != nullptr && sp.shadow_bounds == nullptr) return false;
@@ -828,7 +812,6 @@ __device__ __forceinline__ bool shade_tile_fast(SP sp, const float *lut, uint32_
     // 230), so a fully shadowed pixel is ambient * base and needs neither the sun, nor any point light, nor its normal,
     // tangent frame, position, metalness or roughness.
     const bool live = sp.culling ? lit != 0.0f : true;
-    prefetch();
     float4 gc, gd, ge;
     if (live) second(gc, gd, ge);   // second wave of loads: lit pixels only (48 B / pixel, whole 128-byte tile rows)
     // ---- C: base colour
@@ -850,9 +833,9 @@ __device__ __forceinline__ bool shade_tile_fast(SP sp, const float *lut, uint32_
 
 // ---- the GENERAL tile: ragged tiles at the target's edge, pixels without geometry (skybox), several materials in one tile,
 // materials with images of unequal sizes, the 25-tap shadow test, the debug / timing options --------------------------------
-template <int LOOP, bool STATS, bool LDS_SHADOW, class Second, class Prefetch>
+template <int LOOP, bool STATS, bool LDS_SHADOW, class Second>
 __device__ __forceinline__ void shade_tile(SP sp, const float *lut, float *shadow_tile, uint32_t ty, uint32_t tx,
-                                           uint32_t lane, const TileHead &cur, Second second, Prefetch prefetch) {
+                                           uint32_t lane, const TileHead &cur, Second second) {
     const uint32_t x = tx * 8 + (lane & 7);
     const int32_t y = (int32_t)(ty * 8 + (lane >> 3)) - (int32_t)sp.row0_in_tile;
     const bool in_frame = x < sp.width && y >= 0 && y < (int32_t)sp.rows;
@@ -914,7 +897,6 @@ __device__ __forceinline__ void shade_tile(SP sp, const float *lut, float *shado
             fetch_material();
         }
     }
-    prefetch();
     // exact culling: see shade_tile_fast
     const bool live = covered && (sp.culling ? lit != 0.0f : true);
     float4 gc, gd, ge;
@@ -974,12 +956,11 @@ __device__ __forceinline__ TraceStart trace_begin(SP sp, unsigned long long entr
     if (sp.trace) { t.real = __builtin_amdgcn_s_memrealtime(); t.core = __builtin_amdgcn_s_memtime(); }
     return t;
 }
-__device__ __forceinline__ unsigned long long trace_end(SP sp, size_t tile, uint32_t lane, TraceStart t0, bool fast) {   // returns the time: a persistent wave's next "entry"
-    if (!sp.trace) return 0ull;
+__device__ __forceinline__ void trace_end(SP sp, size_t tile, uint32_t lane, TraceStart t0, bool fast) {
+    if (!sp.trace) return;
     const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long hw = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);   // HW_REG_HW_ID, HW_REG_XCC_ID
     if (lane == 0) { unsigned long long *o = sp.trace + tile * 4; o[0] = t0.real; o[1] = r1; o[2] = hw | ((t0.real - t0.entry) << 40); o[3] = (fast ? 1ull : 0ull) | ((c1 - t0.core) << 8); }
-    return r1;
 }
 
 // the kernel's argument block (its only parameter, at offset 0 of the kernarg segment)
@@ -1002,7 +983,7 @@ __device__ __forceinline__ void stage_lds(SP sp, float *lut) { lut[threadIdx.x] 
 // y = x (mod 8), walking each row left to right.  grid = (8 x workgroups per tile row, 1 / T of the groups of 8 tile rows): the
 // linear block id advances along x first, so id % 8 = x % 8.  (Placement is a speed matter only; surplus blocks exit.)
 template <int LOOP, bool STATS, bool LDS_SHADOW>
-__global__ __launch_bounds__(256) void k_material(const ShadeParams sp_by_value) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_material(const ShadeParams sp_by_value) {
     __shared__ float lut[256];
     __shared__ float shadow_tiles[LDS_SHADOW ? 4 : 1][LDS_SHADOW ? SHADOW_TILE * SHADOW_TILE : 1];   // one per wave (the LDS variant of the PCF slow path)
     KernArgs args = kernel_args();
@@ -1026,98 +1007,10 @@ __global__ __launch_bounds__(256) void k_material(const ShadeParams sp_by_value)
         const auto second = [&](float4 &gc, float4 &gd, float4 &ge) {
             gc = gload_f4(sp.g.c + tile * 64, lane * 16u); gd = gload_f4(sp.g.d + tile * 64, lane * 16u); ge = gload_f4(sp.g.e + tile * 64, lane * 16u);
         };
-        const bool fast = shade_tile_fast<LOOP, STATS>(sp, lut, ty, tx, lane, cur, second, [] {});
-        if (!fast) shade_tile<LOOP, STATS, LDS_SHADOW>(sp, lut, shadow_tiles[LDS_SHADOW ? wave : 0], ty, tx, lane, cur, second, [] {});
+        const bool fast = shade_tile_fast<LOOP, STATS>(sp, lut, ty, tx, lane, cur, second);
+        if (!fast) shade_tile<LOOP, STATS, LDS_SHADOW>(sp, lut, shadow_tiles[LDS_SHADOW ? wave : 0], ty, tx, lane, cur, second);
         trace_end(sp, tile, lane, t0, fast);
     }
-}
-
-// ---- the same pass with PERSISTENT waves that claim their tiles (ARCTIC_OPT_PERSISTENT) -----------------------------------------------
-// One workgroup per workgroup slot of the chip (launch_shade asks the runtime how many a CU holds), no tile bound to any of them: a
-// wave CLAIMS tiles, one atomic add per tile, until none is left.  The dispatcher is out of the picture -- no launch per tile, no
-// slot standing empty between workgroups, no shader engine ahead of another: the chip finishes within a tile of itself.
-//   * An atomic counter serves ~70-88 claims per us (profiles/r3_claim_rates.txt), the pass needs ~700: every XCD (block b runs on
-//     XCD b % 8 and owns the tile rows y = x (mod 8), as before) has 8 queues -- queue q the rows x + 8 (q + 8 j) -- and a wave
-//     starts at the queue of its workgroup (four waves claiming one after the other shade horizontal neighbours, which share texture
-//     and shadow-map lines) and moves on to the next when that is empty.
-//   * Claim c of a queue is tile c / 2 from the top of its list when c is even, from the bottom when it is odd: lit (ALU-bound) and
-//     shadowed (latency-bound) regions are spatially clustered, and this way every SIMD holds both kinds all the time.
-//   * The claim for the next tile is issued when a tile begins and collected where that tile prefetches: the next tile's head is then
-//     touched (touch_head), so its loads find their lines in the L2.
-//   * The last workgroup to leave zeroes the counters for the next launch (sp.queue: 64 counters + 1, a 128-byte line each).
-constexpr uint32_t QUEUE_STRIDE = 32, QUEUES_PER_XCD = 8;
-struct TileQueue {
-    uint32_t q, tried;   // the queue claimed from, queues found empty so far (everything else is re-read from the argument block)
-    __device__ __forceinline__ TileQueue() { q = (blockIdx.x >> 3) & (QUEUES_PER_XCD - 1u); tried = 0u; }
-    __device__ __forceinline__ uint32_t issue(SP sp, uint32_t lane) const {   // one lane asks; collect() reads the answer
-        uint32_t c = 0u;
-        if (lane == 0u) c = __hip_atomic_fetch_add(sp.queue + ((blockIdx.x & 7u) * QUEUES_PER_XCD + q) * QUEUE_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return c;
-    }
-    // the claim issued earlier -> a tile, or (queue empty) claims from the following queues until one answers; false: no tile left
-    __device__ __forceinline__ bool collect(SP sp, uint32_t pending, uint32_t lane, uint32_t &ty, uint32_t &tx) {
-        const uint32_t xcd = blockIdx.x & 7u, tiles_x = sp.tiles_x;
-        const uint32_t rows = (sp.tiles_y + 7u - xcd) >> 3;   // tile rows of this XCD
-        uint32_t c = __builtin_amdgcn_readfirstlane(pending);
-        for (;;) {
-            const uint32_t n = q < rows ? ((rows - q + QUEUES_PER_XCD - 1u) / QUEUES_PER_XCD) * tiles_x : 0u;   // tiles of queue q
-            if (c < n) {
-                const uint32_t m = (c & 1u) ? n - 1u - (c >> 1) : (c >> 1);
-                const uint32_t j = tiles_x == 1u ? m : __umulhi(m, sp.tiles_x_magic);   // m / tiles_x: exact while m * tiles_x < 2^32 (launch_shade)
-                tx = m - j * tiles_x;
-                ty = xcd + 8u * (q + QUEUES_PER_XCD * j);
-                return true;
-            }
-            if (++tried == QUEUES_PER_XCD) return false;
-            q = (q + 1u) & (QUEUES_PER_XCD - 1u);
-            c = __builtin_amdgcn_readfirstlane(issue(sp, lane));
-        }
-    }
-    static __device__ __forceinline__ void leave(SP sp) {   // one lane of the workgroup, after all its waves' claims have returned
-        uint32_t *left = sp.queue + 8u * QUEUES_PER_XCD * QUEUE_STRIDE;
-        if (__hip_atomic_fetch_add(left, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {
-            for (uint32_t i = 0; i < 8u * QUEUES_PER_XCD; ++i) __hip_atomic_store(sp.queue + i * QUEUE_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(left, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-};
-template <int LOOP, bool STATS, bool LDS_SHADOW>
-__global__ __launch_bounds__(256) void k_material_persistent(const ShadeParams sp_by_value) {
-    __shared__ float lut[256];
-    __shared__ float shadow_tiles[LDS_SHADOW ? 4 : 1][LDS_SHADOW ? SHADOW_TILE * SHADOW_TILE : 1];   // one per wave (the LDS variant of the PCF slow path)
-    __shared__ uint32_t sink[4][64];   // where the prefetches' data goes (touch_lines): never read
-    KernArgs args = kernel_args();
-    unsigned long long t_entry = trace_entry(*args);
-    uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    TileQueue queue;
-    uint32_t ty, tx;
-    const uint32_t first = queue.issue(*args, lane);
-    stage_lds(*args, lut);
-    __syncthreads();
-    bool more = queue.collect(*args, first, lane, ty, tx);
-    while (more) {
-        asm volatile("" : "+s"(args), "+v"(lane));   // see SP
-        SP sp = *args;
-        const TraceStart t0 = trace_begin(sp, t_entry);
-        const uint32_t pending = queue.issue(sp, lane);   // the claim for the tile after this one: collected in prefetch()
-        const size_t tile = (size_t)ty * sp.tiles_x + tx;   // wave-uniform
-        const TileHead cur = load_head(sp, tile, lane);
-        uint32_t nty = 0, ntx = 0;
-        const auto prefetch = [&]() {
-            more = queue.collect(sp, pending, lane, nty, ntx);
-            if (more) touch_head(sp, (size_t)nty * sp.tiles_x + ntx, lane, sink[wave]);
-        };
-        const auto second = [&](float4 &gc, float4 &gd, float4 &ge) {
-            gc = gload_f4(sp.g.c + tile * 64, lane * 16u); gd = gload_f4(sp.g.d + tile * 64, lane * 16u); ge = gload_f4(sp.g.e + tile * 64, lane * 16u);
-        };
-        const bool fast = shade_tile_fast<LOOP, STATS>(sp, lut, ty, tx, lane, cur, second, prefetch);
-        if (!fast) shade_tile<LOOP, STATS, LDS_SHADOW>(sp, lut, shadow_tiles[LDS_SHADOW ? wave : 0], ty, tx, lane, cur, second, prefetch);
-        t_entry = trace_end(sp, tile, lane, t0, fast);
-        ty = nty; tx = ntx;
-    }
-    __syncthreads();   // all four waves are through
-    if (threadIdx.x == 0) TileQueue::leave(*args);
 }
 
 // ---- the same without a G-buffer (whole frames): the tile walk straight from the visibility plane ----------------------
@@ -1127,22 +1020,26 @@ __global__ __launch_bounds__(256) void k_material_persistent(const ShadeParams s
 // for the lit ones -- with the very operations of k_resolve (edges.h, fp contraction off), so the pixels are bit-identical
 // to the G-buffer path.  Everything after the attributes is shade_tile, shared.
 template <int LOOP, bool STATS, bool LDS_SHADOW>
-__global__ __launch_bounds__(256) void k_material_vis(const ShadeParams sp_by_value) {
-    SP sp = *kernel_args();
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_material_vis(const ShadeParams sp_by_value) {
     __shared__ float lut[256];
     __shared__ float shadow_tiles[LDS_SHADOW ? 4 : 1][LDS_SHADOW ? SHADOW_TILE * SHADOW_TILE : 1];   // one per wave (the LDS variant of the PCF slow path)
-    const unsigned long long t_entry = trace_entry(sp);
-    const uint32_t lane = threadIdx.x & 63;
+    KernArgs args = kernel_args();
+    const unsigned long long t_entry = trace_entry(*args);
+    uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t ty = blockIdx.y * 8 + (blockIdx.x & 7u), tx = (blockIdx.x >> 3) * 4 + wave;   // XCD-aware order: see k_material
-    const bool tile_ok = ty < sp.tiles_y && tx < sp.tiles_x;
-    const size_t gi = ((size_t)ty * sp.tiles_x + tx) * 64 + lane;
-    unsigned long long key = ~0ull;
-    if (tile_ok) key = sp.vis[gi];
-    stage_lds(sp, lut);
+    const uint32_t groups = (args->tiles_y + 7u) >> 3, tx = (blockIdx.x >> 3) * 4 + wave;   // XCD-aware order, T tiles per wave: see k_material
+    const uint32_t T = args->tiles_per_wave, stride = (groups + T - 1u) / T;
+    stage_lds(*args, lut);
     __syncthreads();
-    if (!tile_ok) return;
+    if (tx >= args->tiles_x) return;
+#pragma nounroll
+    for (uint32_t k = 0; k < T; ++k) {
+    const uint32_t g = blockIdx.y + k * stride, ty = g * 8 + (blockIdx.x & 7u);
+    if (g >= groups || ty >= args->tiles_y) break;
+    asm volatile("" : "+s"(args), "+v"(lane));   // see SP
+    SP sp = *args;
     const TraceStart t0 = trace_begin(sp, t_entry);
+    const unsigned long long key = sp.vis[((size_t)ty * sp.tiles_x + tx) * 64 + lane];
     const int32_t px = (int32_t)(tx * 8 + (lane & 7));
     const int32_t py = (row_global((int)ty, sp.band_tiles, sp.shard_count, sp.shard_index) + sp.tile_y0) * 8 + (int32_t)(lane >> 3);
     TileHead cur;
@@ -1229,9 +1126,10 @@ __global__ __launch_bounds__(256) void k_material_vis(const ShadeParams sp_by_va
             ge = make_float4(interpolate_attr(B, A0, A1, A2, 7), interpolate_attr(B, A0, A1, A2, 8), interpolate_attr(B, A0, A1, A2, 9), interpolate_attr(B, A0, A1, A2, 10));
         }
     };
-    const bool fast = shade_tile_fast<LOOP, STATS>(sp, lut, ty, tx, lane, cur, second, [] {});
-    if (!fast) shade_tile<LOOP, STATS, LDS_SHADOW>(sp, lut, shadow_tiles[LDS_SHADOW ? wave : 0], ty, tx, lane, cur, second, [] {});
+    const bool fast = shade_tile_fast<LOOP, STATS>(sp, lut, ty, tx, lane, cur, second);
+    if (!fast) shade_tile<LOOP, STATS, LDS_SHADOW>(sp, lut, shadow_tiles[LDS_SHADOW ? wave : 0], ty, tx, lane, cur, second);
     trace_end(sp, (size_t)ty * sp.tiles_x + tx, lane, t0, fast);
+    }
 }
 
 // ---- shadow bounds: the conservative min/max table calculate_lit tests first -------------------------------------------
@@ -1275,21 +1173,6 @@ __global__ __launch_bounds__(256) void k_post_process(const float4 *__restrict__
 
 template <int LOOP, bool STATS, bool LDS_SHADOW>
 hipError_t launch_variant(const ShadeParams &sp, const ShadeLaunch &L, dim3 grid) {
-    if (L.persistent && !L.from_vis) {   // one workgroup per workgroup slot: CUs x what a CU holds of this kernel (asked once), a multiple of 8
-        static int occ = 0;
-        if (occ == 0) {
-            int n = 0;
-            const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_material_persistent<LOOP, STATS, LDS_SHADOW>, 256, 0);
-            if (e != hipSuccess) return e;
-            occ = n > 0 ? n : 1;
-        }
-        uint32_t blocks = L.cu_count * (L.persistent > 1 ? L.persistent - 1u : (uint32_t)occ);
-        const uint32_t most = 8u * ((((sp.tiles_y + 7u) / 8u) * sp.tiles_x + 3u) / 4u);
-        if (blocks > most) blocks = most;
-        blocks = (blocks + 7u) & ~7u;
-        k_material_persistent<LOOP, STATS, LDS_SHADOW><<<blocks, 256, 0, L.stream>>>(sp);
-        return hipGetLastError();
-    }
     if (L.from_vis) k_material_vis<LOOP, STATS, LDS_SHADOW><<<grid, 256, 0, L.stream>>>(sp);
     else k_material<LOOP, STATS, LDS_SHADOW><<<grid, 256, 0, L.stream>>>(sp);
     return hipGetLastError();
@@ -1304,10 +1187,8 @@ hipError_t launch_shade(const ShadeParams &sp_in, const ShadeLaunch &L) {
     if (n_tiles == 0) return hipSuccess;
     ShadeParams sp = sp_in;
     sp.tiles_per_wave = L.tiles_per_wave ? L.tiles_per_wave : DEFAULT_TILES_PER_WAVE;
-    sp.tiles_x_magic = sp.tiles_x > 1 ? (uint32_t)((1ull << 32) / sp.tiles_x) + 1u : 0u;   // TileQueue::collect: m / tiles_x = umulhi(m, magic) while m * tiles_x < 2^32
-    if (L.persistent && (uint64_t)((sp.tiles_y + 7u) / 8u + 1u) * sp.tiles_x * sp.tiles_x >= (1ull << 32)) return hipErrorInvalidValue;   // (16384^2 targets: 2^30)
     const uint32_t bpr = (sp.tiles_x + 3) / 4, groups = (sp.tiles_y + 7) / 8;
-    const dim3 grid(8 * bpr, L.from_vis ? groups : (groups + sp.tiles_per_wave - 1) / sp.tiles_per_wave);   // k_material: a block shades tiles_per_wave groups of 8 tile rows
+    const dim3 grid(8 * bpr, (groups + sp.tiles_per_wave - 1) / sp.tiles_per_wave);   // a block shades tiles_per_wave groups of 8 tile rows
     if (sp.debug & 16)   // A/B only: the 25-tap path staged through LDS (a separate instantiation: it costs the default kernels nothing)
         return L.loop == 2 ? launch_variant<2, false, true>(sp, L, grid) : launch_variant<1, false, true>(sp, L, grid);
     if (L.loop == 2) return L.stats ? launch_variant<2, true, false>(sp, L, grid) : launch_variant<2, false, false>(sp, L, grid);

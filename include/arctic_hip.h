@@ -286,9 +286,6 @@ int arctic_stats(ArcticRenderer *r, uint64_t *out, uint32_t n);
                                          lit (ALU-bound) and shadowed (latency-bound) regions are spatially clustered, and a wave that visits n distant parts of the
                                          frame carries a mix of both, so that every SIMD holds both kinds all the time, wherever in the frame the light falls
                                          (and a wave is launched once for n tiles).  0 (default) = the library's choice.  Placement only: same image */
-#define ARCTIC_OPT_PERSISTENT        18 /* 1 = arctic_pass_shade runs one persistent workgroup per workgroup slot of the chip whose waves claim their tiles from
-                                         atomic queues (8 per XCD) instead of one workgroup per strip of tiles dealt by the hardware; n > 1: n - 1 workgroups per
-                                         CU.  Placement only: same image */
 #define ARCTIC_OPT_TILE_TRACE        17 /* 1 = the shading pass records per 8x8 tile when its wave started and ended and where it ran (a measuring aid, default 0:
                                          the kernels then pay one wave-uniform branch at either end of a tile); read with arctic_read_tile_trace */
 #define ARCTIC_OPT_MARKERS          13 /* 1 = roctx ranges around each pass, named like the reference's Tracy zones (process-wide; libroctx64 is loaded on demand) */
