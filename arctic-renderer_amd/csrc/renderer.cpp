@@ -557,12 +557,13 @@ int fill_shade_params(ArcticRenderer *r, const ArcticScene *sc, const ArcticSett
     return ARCTIC_OK;
 }
 
-// one shading pass = one launch.  The light loop: scalar (lights through the scalar cache, small register footprint) up to
-// 16 point lights -- the reference's MAX_NUM_POINT_LIGHTS -- packed pairs from LDS above (ARCTIC_OPT_LIGHT_PATH overrides).
+// one shading pass = one launch.  The light loop: scalar up to 12 point lights, packed pairs above (both read the lights through the scalar
+// cache; measured crossover, profiles/r3_light_paths.txt: 8 lights 0.1062 / 0.1072 ms, 12: 0.1125 / 0.1138, 16: 0.123 / 0.1186;
+// ARCTIC_OPT_LIGHT_PATH overrides).
 hipError_t shade_once(ArcticRenderer *r, const ShadeParams &sp, bool from_vis, bool stats) {
     ShadeLaunch L;
     L.stream = r->stream;
-    L.loop = r->light_path == 0 ? (sp.n_lights <= 16 ? 1u : 2u) : (uint32_t)r->light_path;
+    L.loop = r->light_path == 0 ? (sp.n_lights <= 12 ? 1u : 2u) : (uint32_t)r->light_path;
     L.from_vis = from_vis ? 1u : 0u;
     L.stats = stats ? 1u : 0u;
     L.tiles_per_wave = r->tiles_per_wave;

@@ -279,9 +279,9 @@ int arctic_stats(ArcticRenderer *r, uint64_t *out, uint32_t n);
                                           (bit-identical image; the G-buffer is materialised later if arctic_read_gbuffer / arctic_pass_shade ask); 0 = via the G-buffer */
 #define ARCTIC_OPT_ITEM_TABLE_FLOOR 11 /* smallest size (entries) of the rasteriser's work-item table, default 4 Mi; the table grows to 4x the largest
                                           count seen.  A frame that overflows it returns ARCTIC_E_CAPACITY from the next synchronising call. */
-#define ARCTIC_OPT_LIGHT_PATH       12 /* the light loop of the shading kernel: 0 = automatic (default: scalar up to 16 point lights -- the reference's
-                                          MAX_NUM_POINT_LIGHTS -- packed pairs above), 1 = scalar fp32, lights through the scalar cache, 2 = two lights at a
-                                          time in packed fp32 from LDS.  Same formulas (images agree to fp32 rounding, ~1e-7). */
+#define ARCTIC_OPT_LIGHT_PATH       12 /* the light loop of the shading kernel: 0 = automatic (default: scalar up to 12 point lights, packed pairs above -- the
+                                          measured crossover; the reference's MAX_NUM_POINT_LIGHTS is 16), 1 = scalar fp32, 2 = two lights at a time in packed
+                                          fp32; both read the lights through the scalar cache.  Same formulas (images agree to fp32 rounding, ~1e-7). */
 #define ARCTIC_OPT_TILES_PER_WAVE    16 /* tiles a wave of the shading pass (arctic_pass_shade) shades one after the other, 1 / n-th of the frame's height apart:
                                          lit (ALU-bound) and shadowed (latency-bound) regions are spatially clustered, and a wave that visits n distant parts of the
                                          frame carries a mix of both, so that every SIMD holds both kinds all the time, wherever in the frame the light falls

@@ -175,7 +175,7 @@ def test_fast_tile_equals_general_tile(pair):
 
 def test_light_paths_agree(pair, pkg):
     """ARCTIC_OPT_LIGHT_PATH: the shading kernel runs the light loop scalar (1: lights through the scalar cache) or two
-    lights at a time in packed fp32 from LDS (2); 0 picks by light count.  Same formulas: the float images agree to fp32
+    lights at a time in packed fp32 (2), both through the scalar cache; 0 picks by light count.  Same formulas: the float images agree to fp32
     rounding (the compiler contracts differently per kernel), each is within the parity bar of the oracle -- with the
     scene's own lights and as a sun-only scene, through the G-buffer and through the visibility-plane frame."""
     sc, o, r = pair
