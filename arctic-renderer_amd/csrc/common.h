@@ -82,7 +82,8 @@ struct RasterRec {
     float inv_area;            // 1 / (float)area2
     uint32_t order_id;
     uint32_t flags;
-    uint32_t pad[4];
+    uint32_t src_vertex[3];    // the SOURCE triangle's transformed vertices (indices into the pass's XVert table) and ...
+    uint32_t material;         // ... its material: what k_material_vis needs to interpolate the attributes of a pixel (one 16-byte load)
 };
 static_assert(sizeof(RasterRec) == 128, "RasterRec layout");
 constexpr uint32_t RASTER_EXACT_F64 = 1u;

@@ -175,7 +175,7 @@ __device__ __forceinline__ void make_raster_rec(const SetupRec &t, bool force_in
     q.inv_area = 1.0f / (float)t.area2;
     q.order_id = t.order_id;
     q.flags = (m < (1 << 24) && !force_integer) ? RASTER_EXACT_F64 : 0u;
-    q.pad[0] = q.pad[1] = q.pad[2] = q.pad[3] = 0;
+    q.src_vertex[0] = q.src_vertex[1] = q.src_vertex[2] = 0; q.material = 0;   // (place_triangle)
 }
 
 // can any pixel of the 16x16 block (bx, by) be covered?  The largest value of each edge function over the block's pixel centres
@@ -327,11 +327,16 @@ __device__ __forceinline__ void plan_triangle(bool has, const SetupRec &t, const
 // record slot r and item slots [ibase, ibase + e.nb) are this lane's: write them.  Called by whole waves (large records are
 // written by all lanes together).
 __device__ __forceinline__ void place_triangle(bool has, SetupRec &t, EmitPlan &e, uint32_t r, uint32_t ibase, uint32_t src, uint32_t oi, uint32_t sub,
-                                               const GeomParams &gp, const SetupTables &T) {
+                                               const GeomParams &gp, const SetupTables &T, const ObjectRec &ob) {
     const uint32_t lane = threadIdx.x & 63;
     if (has) {
         t.src_tri = src; t.object = oi; t.order_id = src * 8u + sub; t.pad = 0;
         e.q.order_id = t.order_id;
+        // what shading from the visibility plane needs of the SOURCE triangle, so that it finds it in the record it reads anyway instead
+        // of behind three more dependent loads (object -> index buffer -> ...): its transformed vertices and its material
+        const uint32_t *ind = ob.indices + 3u * (src - ob.first_triangle);
+        e.q.src_vertex[0] = ob.first_xvert + ind[0]; e.q.src_vertex[1] = ob.first_xvert + ind[1]; e.q.src_vertex[2] = ob.first_xvert + ind[2];
+        e.q.material = ob.material;
         if (r < T.rec_cap) { T.recs[r] = t; T.rrecs[r] = e.q; T.rec_of[src * 8u + sub] = r; }
         else e.nb = e.nbb = 0;   // record table full (flagged by the caller; k_raster then does nothing)
     }
@@ -418,7 +423,7 @@ __global__ __launch_bounds__(SETUP_THREADS) void k_setup(const ObjectRec *__rest
     __syncthreads();
     uint32_t rbase = s_base[0], ibase = s_base[1];
     for (uint32_t w = 0; w < wave; ++w) { rbase += s_count[w][0]; ibase += s_count[w][1]; }
-    place_triangle(has, t, e, rbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), ibase + iincl - e.nb, ob.first_triangle + ti, oi, 0u, gp, T);
+    place_triangle(has, t, e, rbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), ibase + iincl - e.nb, ob.first_triangle + ti, oi, 0u, gp, T, ob);
 }
 
 // The triangles of the clip list, one wave per workgroup.  First a lane per triangle (CLIP_LANES of them): Sutherland-Hodgman in
@@ -467,7 +472,7 @@ __global__ __launch_bounds__(64) void k_setup_clipped(const ObjectRec *__restric
             const unsigned long long below = m & ((1ull << lane) - 1ull);
             const uint32_t sub = (uint32_t)__popcll(below >> ((lane / 7) * 7));   // set-up fan triangles of the same polygon before this one
             place_triangle(has, t, e, (uint32_t)base + (uint32_t)__popcll(below), (uint32_t)(base >> 32) + iincl - e.nb,
-                           lane < 56 ? s_src[p] : 0u, lane < 56 ? s_obj[p] : 0u, sub, gp, T);
+                           lane < 56 ? s_src[p] : 0u, lane < 56 ? s_obj[p] : 0u, sub, gp, T, objs[lane < 56 ? s_obj[p] : 0u]);
         }
         __syncthreads();   // the polygons are read; the next sweep may overwrite them
     }

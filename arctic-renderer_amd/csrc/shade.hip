@@ -1053,7 +1053,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         const uint32_t ri = gload_u32(sp.rec_of, (uint32_t)key << 2);   // low word of the key = order id (k_setup)
         const uint32_t so = ri << 7;                                     // SetupRec and RasterRec are 128 bytes
         const float4u qf = gload_f4u(sp.rrecs, so + 96u);                // dz2, inv_area, order id, flags
-        const uint2 ids = gload_u2(sp.recs, so + 112u);                  // src_tri, object
+        const u4v src = gload_u4u(sp.rrecs, so + 112u);                  // the source triangle's three transformed vertices, its material
         if (__float_as_uint(qf.w) & RASTER_EXACT_F64) {
             typedef double d2v __attribute__((ext_vector_type(2)));
             const auto ld2 = [&](uint32_t o) { return *(const d2v __attribute__((address_space(1))) *)((gchar)sp.rrecs + o); };
@@ -1077,12 +1077,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
                 B[2] = (c0 * b0.z + c1 * b1.y) + c2 * b22;
             }
         } else source_barycentrics(sp.recs[ri], sp.rrecs[ri], px, py, B);   // rare: coordinates of 2^24 and more
-        const uint32_t oo = ids.y * (uint32_t)sizeof(ObjectRec);
-        const uint2 ip = gload_u2(sp.objs, oo + 72u);                    // ObjectRec::indices
-        const uint2 fx = gload_u2(sp.objs, oo + 88u);                    // first_xvert, first_triangle
-        cur.b2 = __uint_as_float(gload_u32(sp.objs, oo + 96u));          // material
-        const uint32_t *ind = reinterpret_cast<const uint32_t *>(((unsigned long long)ip.y << 32) | ip.x) + 3u * (ids.x - fx.y);
-        v0 = fx.x + ind[0]; v1 = fx.x + ind[1]; v2 = fx.x + ind[2];
+        cur.b2 = __uint_as_float(src.w);
+        v0 = src.x; v1 = src.y; v2 = src.z;
         const uint32_t a0 = v0 * 96u + 16u, a1 = v1 * 96u + 16u, a2 = v2 * 96u + 16u;
         const float2 u0 = gload_f2(sp.xv, a0), u1 = gload_f2(sp.xv, a1), u2 = gload_f2(sp.xv, a2);                    // attr 0, 1
         const float4u w0 = gload_f4u(sp.xv, a0 + 56u), w1 = gload_f4u(sp.xv, a1 + 56u), w2 = gload_f4u(sp.xv, a2 + 56u);   // attr 14..17

@@ -4,6 +4,7 @@ counts, automatic light loop, medians over the alternations.   usage: python too
 import os, sys, subprocess, numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 COUNTS = (64, 16, 0)
+NAMES = ["64 lights", "16 lights", "0 lights", "frame", "frame + shadow"]
 if len(sys.argv) > 1 and sys.argv[1] == "--worker":
     sys.path.insert(0, os.path.join(HERE, "..", ".."))
     import __graft_entry__ as e
@@ -19,6 +20,15 @@ if len(sys.argv) > 1 and sys.argv[1] == "--worker":
     for n in COUNTS:
         r.update_lights(sc.lights[:n])
         out.append(float(np.median(r.time_shade(sc.desc, sc.settings, warmup=20, iters=60))))
+    # whole frames (static sun / shadow map redrawn every frame), 64 lights, 40 frames enqueued back to back
+    import time
+    r.update_lights(sc.lights[:64])
+    for cache in (1, 0):
+        r.set_option("shadow_cache", cache)
+        for i in range(10): r.render_frame_device(sc.desc, sc.settings, None)
+        r.flush(); t = time.perf_counter()
+        for i in range(40): r.render_frame_device(sc.desc, sc.settings, None)
+        r.flush(); out.append((time.perf_counter() - t) / 40 * 1e3)
     print("TIMES " + " ".join(f"{t:.4f}" for t in out), flush=True)
     sys.exit(0)
 specs = [a for a in sys.argv[1:] if not a.isdigit()]
@@ -33,4 +43,4 @@ for _ in range(reps):
         if line: res[s].append([float(x) for x in line[0].split()[1:]])
 for s in specs:
     a = np.array(res[s])
-    print(f"{s}: " + "  ".join(f"{n} lights {np.median(a[:, i]):.4f} ms ({a[:, i].min():.4f}-{a[:, i].max():.4f})" for i, n in enumerate(COUNTS)), flush=True)
+    print(f"{s}: " + "  ".join(f"{n} {np.median(a[:, i]):.4f} ms ({a[:, i].min():.4f}-{a[:, i].max():.4f})" for i, n in enumerate(NAMES)), flush=True)
