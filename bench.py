@@ -27,12 +27,16 @@ The JSON line also carries
   roofline     the dominant kernel = the pass itself (ONE launch: k_material<loop>): achieved = 80 B x shaded pixels /
                kernel_ms, kernel_ms = HIP events on the launch stream around the K timed steps / K (the same launches
                ms_per_step is the wall clock of).  Which roof binds is DERIVED, not assumed: valu_issue_frac = the kernel's
-               vector-issue cycles (SQ_INSTS_VALU and the transcendental count priced with the issue costs measured by
-               tools/experiments/valu_rates.hip) / (1024 SIMDs x clock x kernel_ms), hbm_frac = real HBM bytes / kernel_ms /
-               8 TB/s; both counter inputs are STATIC, read from profiles/pmc_latest.json (collected with rocprofv3 --pmc
-               in separate passes by tools/profile_round.sh) and labelled so.  Also in the line: the same pass with exact
+               vector-issue cycles / (1024 SIMDs x 2.4 GHz x kernel_ms), priced per instruction class (the light loop's v_pk_*
+               from the executed pair trips x the census of its ISA, transcendentals from their counter, the rest by the static
+               mix of the kernel's other code; costs from tools/experiments/valu_rates.hip); valu_flop_frac = FP32 flops
+               (FMA = 2) / kernel_ms / 157.3 TFLOP/s; hbm_frac = real HBM bytes / kernel_ms / 8 TB/s.  The counter inputs are
+               STATIC, read from profiles/pmc_latest.json (rocprofv3 --pmc in separate passes, tools/profile_round.sh) and
+               profiles/isa_census_latest.json (make census), and labelled so.  Also in the line: the same pass with exact
                culling off (every pixel lit) and with 16 / 4 / 0 point lights (run after the timed loop; --no-extras
                leaves them out, which is what a rocprofv3 --stats run of this command wants).
+  settle       before anything is measured the pass is repeated, untimed, for ARCTIC_BENCH_SETTLE_MS (250): a device that has
+               been idle runs its first ~70 ms of load at other clocks than it sustains (0.22 against 0.19 ms per pass).
   cpu_baseline the CPU oracle (scalar C++ port of the same HLSL math) shading a bounded stripe of
                the SAME G-buffer on this host's cores -- a baseline, not the target.
 """
