@@ -294,7 +294,16 @@ struct EmitPlan {
     uint32_t nbx, nbb /*blocks of the bounding box*/, nb /*item slots*/;
     unsigned long long mask;   // reachable blocks of a record of up to 64
 };
-__device__ __forceinline__ void plan_triangle(bool has, const SetupRec &t, const GeomParams &gp, EmitPlan &e) {
+// does this shard own any pixel row of block row `by` (16 rows = tile rows 2 by, 2 by + 1)?  A contiguous shard is scissored to its
+// rows already; an interleaved one owns bands of band_tiles tile rows: blocks wholly inside other shards' bands are never emitted
+// (the rasteriser would walk them and skip every row: at 8 ranks 7 of 8 items).
+__device__ __forceinline__ bool block_row_owned(const GeomParams &gp, int32_t by) {
+    if (gp.band_tiles == 0) return true;
+    const int t0 = 2 * by - gp.tile_y0;
+    return (t0 >= 0 && row_owned(t0, gp.band_tiles, gp.shard_count, gp.shard_index)) || (t0 + 1 >= 0 && row_owned(t0 + 1, gp.band_tiles, gp.shard_count, gp.shard_index));
+}
+// (has is cleared when no block of the triangle is both reachable and owned: no record, no slot)
+__device__ __forceinline__ void plan_triangle(bool &has, const SetupRec &t, const GeomParams &gp, EmitPlan &e) {
     e.q = RasterRec{};
     e.bx0 = e.by0 = 0; e.nbx = 1; e.nbb = e.nb = 0; e.mask = 0ull;
     if (!has) return;
@@ -316,13 +325,25 @@ __device__ __forceinline__ void plan_triangle(bool has, const SetupRec &t, const
         }
         double v[3] = {row[0], row[1], row[2]};
         uint32_t x = 0;
+        int32_t y = e.by0;
+        bool mine = block_row_owned(gp, y), any_mine = mine;
         for (uint32_t j = 0; j < e.nbb; ++j) {
-            if ((high_word(v[0]) | high_word(v[1]) | high_word(v[2])) >= 0) e.mask |= 1ull << j;
-            if (++x == e.nbx) { x = 0; row[0] += sy[0]; row[1] += sy[1]; row[2] += sy[2]; v[0] = row[0]; v[1] = row[1]; v[2] = row[2]; }
+            if (mine && (high_word(v[0]) | high_word(v[1]) | high_word(v[2])) >= 0) e.mask |= 1ull << j;
+            if (++x == e.nbx) { x = 0; mine = block_row_owned(gp, ++y); any_mine |= mine && j + 1 < e.nbb; row[0] += sy[0]; row[1] += sy[1]; row[2] += sy[2]; v[0] = row[0]; v[1] = row[1]; v[2] = row[2]; }
             else { v[0] += sx[0]; v[1] += sx[1]; v[2] += sx[2]; }
         }
         e.nb = (uint32_t)__popcll(e.mask);
-    } else if (e.nbb <= LANE_BLOCKS) e.mask = e.nbb == 64 ? ~0ull : (1ull << e.nbb) - 1ull;
+        if (!any_mine) { has = false; e.nbb = 0u; }   // (a triangle none of whose OWN blocks is reachable keeps its record: it counts as set up, like on one device)
+    } else if (e.nbb <= LANE_BLOCKS) {
+        uint32_t x = 0;
+        int32_t y = e.by0;
+        for (uint32_t j = 0; j < e.nbb; ++j) {
+            if (block_row_owned(gp, y)) e.mask |= 1ull << j;
+            if (++x == e.nbx) { x = 0; ++y; }
+        }
+        e.nb = (uint32_t)__popcll(e.mask);
+        if (e.nb == 0u) { has = false; e.nbb = 0u; }
+    }
 }
 // record slot r and item slots [ibase, ibase + e.nb) are this lane's: write them.  Called by whole waves (large records are
 // written by all lanes together).
@@ -364,7 +385,7 @@ __device__ __forceinline__ void place_triangle(bool has, SetupRec &t, EmitPlan &
         const bool exact = (__shfl(e.q.flags, L) & RASTER_EXACT_F64) != 0;
         for (uint32_t j = lane; j < NB; j += 64) {
             const int32_t bx = X0 + (int32_t)(j % NX), by = Y0 + (int32_t)(j / NX);
-            const bool live = !exact || block_reachable(w, bx, by);
+            const bool live = block_row_owned(gp, by) && (!exact || block_reachable(w, bx, by));
             if (IB + j < T.item_cap) T.items[IB + j] = make_uint2(live ? R : ITEM_SKIP, block_code(bx, by));
         }
     }
@@ -407,7 +428,7 @@ __global__ __launch_bounds__(SETUP_THREADS) void k_setup(const ObjectRec *__rest
         if (straddles) clip_list[base + (uint32_t)__popcll(cm & ((1ull << lane) - 1ull))] = make_uint2(oi, ti);
     }
     SetupRec t;
-    const bool has = inside && setup_triangle(a, b, c, gp, t);
+    bool has = inside && setup_triangle(a, b, c, gp, t);
     EmitPlan e;
     plan_triangle(has, t, gp, e);
     const unsigned long long m = __ballot(has);
