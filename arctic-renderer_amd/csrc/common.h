@@ -92,7 +92,26 @@ constexpr uint32_t RASTER_EXACT_F64 = 1u;
 constexpr uint32_t SETUP_THREADS = 256;   // triangles per workgroup of k_setup (one slot atomic per workgroup).  512 is 1 us faster alone, but a 512-thread
                                           // workgroup finds no room beside a shading kernel of 256-thread workgroups (frames in flight): it starved until that ended
 constexpr uint32_t ITEM_SCISSOR = 1u << 24;
+constexpr uint32_t ITEM_INEXACT = 1u << 25;   // the record takes the 64-bit integer rasteriser (RASTER_EXACT_F64 clear): never binned
 constexpr uint32_t ITEM_SKIP = 0xFFFFFFFFu;
+// Block ownership (round 3, k_bin / k_raster_owned): every 16x16 block of the target has a bin of BIN_SLOTS record indices; k_bin moves
+// the work items into the bins of their blocks (one returning atomic per item on the block's counter), one wave per block then merges
+// its bin in registers and WRITES the block once -- no clear, no early read, no per-pixel atomic.  Items that find their bin full
+// (a dense mesh in a few blocks) and inexact records stay in the item table for the merging atomic rasteriser (k_raster), which
+// runs afterwards and spreads them over the whole chip.
+constexpr uint32_t BIN_SLOTS = 32;
+constexpr uint32_t N_GEO_COUNTERS = 8;   // device counters per table set: [0] records, [1] work items, [2] a table overflowed, [3] clip-list entries,
+                                         // [4] k_bin left items for the atomic rasteriser; zeroed by k_vertex
+struct BinTables {
+    uint32_t *count;      // items offered to each block's bin (may exceed BIN_SLOTS: the bin holds the first BIN_SLOTS)
+    uint32_t *slots;      // BIN_SLOTS record indices per block
+    uint32_t blocks_x;    // blocks per row of the table (whole target, whatever the shard)
+    uint32_t n_blocks;    // entries of count
+    // the grid of k_raster_owned: grid_x x grid_y blocks starting at block row by0; local_rows: grid row i is the i-th pair of
+    // tile rows this interleaved shard owns (bands of an even number of tile rows), else block row by0 + i of the target
+    uint32_t grid_x, grid_y, by0, local_rows;
+    uint32_t count_all;   // ARCTIC_OPT_DEBUG bit 9: full bins are asked too, so that count is every item offered (arctic_read_bin_counts as a histogram)
+};
 
 // frame constants for the geometry kernels
 struct GeomParams {
@@ -107,6 +126,7 @@ struct GeomParams {
     int32_t band_tiles;          // interleaved shard: tile rows per band (0 = contiguous shard), else see row_* below
     int32_t shard_index, shard_count;
     int32_t raster_flags;        // 1: every record takes the integer rasteriser (ARCTIC_OPT_DEBUG bit 5: A/B of the two paths)
+    int32_t tiles_y;             // tile rows the target stores (this shard's)
 };
 // tile-row bookkeeping of a shard.  ty_rel = global tile row - tile_y0.  Contiguous shard: local == ty_rel.  Interleaved
 // shard: bands of band_tiles tile rows are dealt round-robin, shard r owns bands r, r + n, ...; local rows are packed.
@@ -209,16 +229,22 @@ inline uint32_t shadow_bounds_pitch(uint32_t S) { return S >= 4 && S <= 4900 ? (
 // every launcher enqueues on `s` and returns the launch error, never synchronises.
 hipError_t launch_vertex(const ObjectRec *objs, const uint32_t *block_obj, const uint32_t *block_first,
                          uint32_t n_blocks, const GeomParams &gp, XVert *xv, int clip_only, uint32_t *counters /*zeroed here for k_setup*/,
-                         unsigned long long *clear, unsigned long long clear_value, size_t clear_count /*the pass's target, cleared in the same launch*/, hipStream_t s);
+                         unsigned long long *clear, unsigned long long clear_value, size_t clear_count /*the pass's target, cleared in the same launch*/,
+                         uint32_t *zero, size_t zero_count /*the bin counters of an owned raster, zeroed in the same launch*/, hipStream_t s);
 hipError_t launch_setup(const ObjectRec *objs, const uint32_t *block_obj, const uint32_t *block_first, uint32_t n_blocks,
                         const GeomParams &gp, const XVert *xv, SetupRec *recs, RasterRec *rrecs, uint32_t *rec_of /*8 per source triangle*/,
                         uint2 *items, uint32_t item_cap, uint32_t rec_cap, uint32_t *counters /*records, items, overflow, clip-list length: zeroed by launch_vertex*/,
                         uint2 *clip_list /*one entry per source triangle*/, hipStream_t s);
 uint32_t raster_grid_blocks(bool depth_only, uint32_t cu_count);
+// after_owned: the blocks were written by k_raster_owned; only what k_bin left in the item table (counters[4] != 0) is drawn
 hipError_t launch_raster_vis(const SetupRec *recs, const RasterRec *rrecs, const uint2 *items, uint32_t item_cap, const uint32_t *counters, uint32_t grid_blocks,
-                             const GeomParams &gp, unsigned long long *vis, uint32_t *host_counts /*mapped: records, items*/, uint32_t *host_overflow, hipStream_t s);
+                             const GeomParams &gp, unsigned long long *vis, uint32_t *host_counts /*mapped: records, items*/, uint32_t *host_overflow, bool after_owned, hipStream_t s);
 hipError_t launch_raster_depth(const SetupRec *recs, const RasterRec *rrecs, const uint2 *items, uint32_t item_cap, const uint32_t *counters, uint32_t grid_blocks,
-                               const GeomParams &gp, uint32_t *depth_bits, uint32_t *host_counts, uint32_t *host_overflow, hipStream_t s);
+                               const GeomParams &gp, uint32_t *depth_bits, uint32_t *host_counts, uint32_t *host_overflow, bool after_owned, hipStream_t s);
+// block ownership: k_bin (work items -> bins) + k_raster_owned (one wave per block, the block written once); the atomic rasteriser
+// launched after them finds what they left (counters[4]) or nothing
+hipError_t launch_raster_owned(bool depth_only, const RasterRec *rrecs, const uint2 *items, uint2 *left /*what the bins did not take: counters[4] entries*/, uint32_t item_cap, uint32_t *counters, const BinTables &B,
+                               const GeomParams &gp, unsigned long long *vis, uint32_t *depth_bits, hipStream_t s);
 hipError_t launch_resolve(const unsigned long long *vis, const SetupRec *recs, const RasterRec *rrecs, const uint32_t *rec_of, const ObjectRec *objs, const XVert *xv,
                           const GeomParams &gp, uint32_t n_tiles, GBuffer g, hipStream_t s);
 hipError_t launch_fill_u64(unsigned long long *p, unsigned long long v, size_t n, hipStream_t s);

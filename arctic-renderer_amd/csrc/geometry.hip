@@ -209,8 +209,9 @@ __device__ __forceinline__ void normalize3(const float *v, float *o) {
 __global__ __launch_bounds__(256) void k_vertex(const ObjectRec *__restrict__ objs, const uint32_t *__restrict__ block_obj,
                                                 const uint32_t *__restrict__ block_first, const GeomParams gp,
                                                 XVert *__restrict__ xv, int clip_only, uint32_t *__restrict__ counters,
-                                                unsigned long long *__restrict__ clear, unsigned long long clear_value, size_t clear_count) {
-    if (blockIdx.x == 0 && threadIdx.x < 4) counters[threadIdx.x] = 0;   // k_setup's slot counters and overflow flag (no memset launch)
+                                                unsigned long long *__restrict__ clear, unsigned long long clear_value, size_t clear_count,
+                                                uint32_t *__restrict__ zero, size_t zero_count) {
+    if (blockIdx.x == 0 && threadIdx.x < N_GEO_COUNTERS) counters[threadIdx.x] = 0;   // k_setup's slot counters and overflow flag (no memset launch)
     const ObjectRec &ob = objs[block_obj[blockIdx.x]];
     uint32_t vi = block_first[blockIdx.x] + threadIdx.x;
     const bool live = vi < ob.n_vertices;
@@ -227,6 +228,8 @@ __global__ __launch_bounds__(256) void k_vertex(const ObjectRec *__restrict__ ob
     // the pass's target is cleared here, a slice per workgroup: 66 MB of stores (bandwidth) behind the vertex fetches just issued
     // (latency), instead of a launch of their own in front of them
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < clear_count; i += (size_t)gridDim.x * 256) clear[i] = clear_value;
+    // ... or, when the blocks of the target have owners (k_raster_owned writes every pixel once), only the bins' counters
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < zero_count; i += (size_t)gridDim.x * 256) zero[i] = 0u;
     if (!live) return;
     float world[4];
     mat_vec(ob.trs, src[0], src[1], src[2], 1.0f, world);
@@ -361,16 +364,17 @@ __device__ __forceinline__ void place_triangle(bool has, SetupRec &t, EmitPlan &
         if (r < T.rec_cap) { T.recs[r] = t; T.rrecs[r] = e.q; T.rec_of[src * 8u + sub] = r; }
         else e.nb = e.nbb = 0;   // record table full (flagged by the caller; k_raster then does nothing)
     }
-    const auto block_code = [&](int32_t bx, int32_t by) {
+    const auto block_code = [&](int32_t bx, int32_t by, bool exact) {
         const bool whole = bx * 16 >= gp.sc_x0 && bx * 16 + 16 <= gp.sc_x1 && by * 16 >= gp.sc_y0 && by * 16 + 16 <= gp.sc_y1;
-        return (uint32_t)bx | ((uint32_t)by << 12) | (whole ? 0u : ITEM_SCISSOR);
+        return (uint32_t)bx | ((uint32_t)by << 12) | (whole ? 0u : ITEM_SCISSOR) | (exact ? 0u : ITEM_INEXACT);
     };
     // small records: the lane writes its own items; large ones (a wall across the screen is thousands of blocks): the
     // whole wave writes them, 64 per step
     if (e.nbb <= LANE_BLOCKS && e.nb != 0) {
+        const bool own_exact = (e.q.flags & RASTER_EXACT_F64) != 0;
         uint32_t x = 0, y = 0, at = ibase;
         for (uint32_t j = 0; j < e.nbb; ++j) {
-            if ((e.mask >> j) & 1ull) { if (at < T.item_cap) T.items[at] = make_uint2(r, block_code(e.bx0 + (int32_t)x, e.by0 + (int32_t)y)); ++at; }
+            if ((e.mask >> j) & 1ull) { if (at < T.item_cap) T.items[at] = make_uint2(r, block_code(e.bx0 + (int32_t)x, e.by0 + (int32_t)y, own_exact)); ++at; }
             if (++x == e.nbx) { x = 0; ++y; }
         }
     }
@@ -386,7 +390,7 @@ __device__ __forceinline__ void place_triangle(bool has, SetupRec &t, EmitPlan &
         for (uint32_t j = lane; j < NB; j += 64) {
             const int32_t bx = X0 + (int32_t)(j % NX), by = Y0 + (int32_t)(j / NX);
             const bool live = block_row_owned(gp, by) && (!exact || block_reachable(w, bx, by));
-            if (IB + j < T.item_cap) T.items[IB + j] = make_uint2(live ? R : ITEM_SKIP, block_code(bx, by));
+            if (IB + j < T.item_cap) T.items[IB + j] = make_uint2(live ? R : ITEM_SKIP, block_code(bx, by, exact));
         }
     }
 }
@@ -520,7 +524,12 @@ typedef char __attribute__((address_space(1))) *gbytes;   // wave-uniform base (
 // the four pixels of a lane in one work item: the depth bits where the pixel is covered and nearer than the clear value, else NONE
 constexpr uint32_t NO_DEPTH = 0xFFFFFFFFu;
 
-template <bool DEPTH_ONLY>
+// RAW (the block owners): the depth bits of every covered pixel, 0x3F800000 (1.0: fails LESS against the clear value) included --
+// the owner sorts those out once per block instead of once per item --, and the fill-rule thresholds of edges 0 and 2 are taken
+// off the high words as integers instead of off the values in binary64: for an integer-valued double e and t in {0, 1},
+// e >= t  <=>  high word of e, as int32, >= t  (e = 0 has high word 0, e >= 1 a high word of 0x3FF00000 and more, e < 0 a negative
+// one; the planes never produce -0.0: their coefficients come from integers and an exact zero sum rounds to +0.0).
+template <bool DEPTH_ONLY, bool RAW = false>
 __device__ __forceinline__ void item_pixels(const RasterRec &t, uint32_t code, uint32_t lane, const RasterFrame &fr, uint32_t zb[4]) {
     const int32_t ox = (int32_t)(code & 0xFFFu) << 4, oy = (int32_t)((code >> 12) & 0xFFFu) << 4;   // the block's first pixel
     const bool cut = (code & ITEM_SCISSOR) != 0;   // the block is cut by the scissor: test every pixel against it
@@ -554,12 +563,19 @@ __device__ __forceinline__ void item_pixels(const RasterRec &t, uint32_t code, u
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int32_t outside = high_word(e[k][0] - t.t0) | high_word(e[k][1]) | high_word(e[k][2] - t.t2)
-                              | out_x[DEPTH_ONLY ? 0 : k & 1] | out_y[DEPTH_ONLY ? k : k >> 1];
         const float l1 = (float)e[k][2] * t.inv_area, l2 = (float)e[k][0] * t.inv_area;
         float z = fmaf(l2, t.dz2, fmaf(l1, t.dz1, t.z0));
         z = fminf(fmaxf(z, 0.0f), 1.0f);
-        zb[k] = (outside >= 0 && z < 1.0f) ? __float_as_uint(z) : NO_DEPTH;   // depth LESS against the 1.0 clear
+        if (RAW) {
+            const int32_t t0i = high_word(t.t0) != 0, t2i = high_word(t.t2) != 0;   // wave-uniform: 0 or 1
+            const int32_t outside = (high_word(e[k][0]) - t0i) | high_word(e[k][1]) | (high_word(e[k][2]) - t2i)
+                                  | out_x[DEPTH_ONLY ? 0 : k & 1] | out_y[DEPTH_ONLY ? k : k >> 1];
+            zb[k] = __float_as_uint(z) | (uint32_t)(outside >> 31);   // NO_DEPTH where not covered
+        } else {
+            const int32_t outside = high_word(e[k][0] - t.t0) | high_word(e[k][1]) | high_word(e[k][2] - t.t2)
+                                  | out_x[DEPTH_ONLY ? 0 : k & 1] | out_y[DEPTH_ONLY ? k : k >> 1];
+            zb[k] = (outside >= 0 && z < 1.0f) ? __float_as_uint(z) : NO_DEPTH;   // depth LESS against the 1.0 clear
+        }
     }
 }
 
@@ -682,13 +698,14 @@ __global__ __launch_bounds__(256) void k_raster(const SetupRec *__restrict__ rec
                                                 const uint2 *__restrict__ items, uint32_t item_cap,
                                                 const uint32_t *__restrict__ counters, const GeomParams gp,
                                                 unsigned long long *__restrict__ vis, uint32_t *__restrict__ depth_bits,
-                                                uint32_t *__restrict__ host_counts, uint32_t *__restrict__ host_overflow) {
+                                                uint32_t *__restrict__ host_counts, uint32_t *__restrict__ host_overflow, uint32_t after_owned) {
     typedef typename KeyOf<DEPTH_ONLY>::type Key;
     constexpr Key NONE = (Key)~(Key)0;
     // records, work items and the overflow flag for the host (pinned, mapped memory: no copy launches); read after a synchronise
-    if (blockIdx.x == 0 && threadIdx.x == 0) { host_counts[0] = counters[0]; host_counts[1] = counters[1]; *host_overflow = counters[2]; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { host_counts[0] = counters[0]; host_counts[1] = counters[1]; *host_overflow = counters[2]; host_overflow[2] = after_owned ? counters[4] : counters[1]; }
     if (counters[2]) return;   // a table overflowed in k_setup: entries are missing, the host reports the frame as dropped
-    const uint32_t n_items = min(counters[1], item_cap);
+    // after the block owners: `items` is what the bins did not take (k_bin), usually nothing
+    const uint32_t n_items = min(after_owned ? counters[4] : counters[1], item_cap);
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n_waves = gridDim.x * 4;
     const RasterFrame fr = {gp.sc_x0, gp.sc_y0, gp.sc_x1, gp.sc_y1, gp.tiles_x, gp.tile_y0, gp.pitch, gp.band_tiles, gp.shard_index, gp.shard_count};
@@ -730,9 +747,9 @@ __global__ __launch_bounds__(256) void k_raster(const SetupRec *__restrict__ rec
             rec = en.x;
             if (rec != ITEM_SKIP) code = en.y;
         }
-        wave_sort(code, rec, lane);   // skipped entries sort to the end
         const uint32_t n_live = (uint32_t)__popcll(__ballot(rec != ITEM_SKIP));
-        if (n_live == 0) continue;
+        if (n_live == 0) continue;    // (after k_bin: most chunks)
+        wave_sort(code, rec, lane);   // skipped entries sort to the end
         Key acc[4] = {NONE, NONE, NONE, NONE};
         uint32_t run_code = __builtin_amdgcn_readlane(code, 0);
         for (uint32_t i = 0; i < n_live; ++i) {
@@ -758,6 +775,116 @@ __global__ __launch_bounds__(256) void k_raster(const SetupRec *__restrict__ rec
         read_run(acc, run_code);
     }
     write_pending();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Block ownership: no per-pixel atomics (round 3).  The atomic rasteriser above is bound by the memory side retiring one request
+// per 64-byte segment and instruction (25 per ns: 59 of its 72 us at 4K), and merging inside a wave only reaches the items a wave
+// happens to hold.  Here every 16x16 block of the target has ONE owner: k_bin hands each work item to the bin of its block (one
+// returning atomic per ITEM on the block's counter -- 160 k per 4K frame instead of 1.47 M per-pixel requests), then one wave per
+// block evaluates its bin with the block's 256 keys in registers and stores them once: that store is also the clear.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bin(const uint2 *__restrict__ items, uint2 *__restrict__ left, uint32_t item_cap, uint32_t *__restrict__ counters, const BinTables B) {
+    if (counters[2]) return;
+    const uint32_t n_items = min(counters[1], item_cap);
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t first = blockIdx.x * 256 + (threadIdx.x & ~63u); first < n_items; first += gridDim.x * 256) {   // uniform per wave
+        const uint32_t i = first + lane;
+        bool keep = false;     // not binned: the atomic rasteriser draws it
+        uint2 en = make_uint2(ITEM_SKIP, 0u);
+        if (i < n_items) en = items[i];
+        if (en.x != ITEM_SKIP) {
+            keep = (en.y & ITEM_INEXACT) != 0;
+            if (!keep) {
+                const uint32_t b = ((en.y >> 12) & 0xFFFu) * B.blocks_x + (en.y & 0xFFFu);
+                // a full bin is not asked again (the count only grows, so a stale read errs on the side of asking): a dense mesh in
+                // a few blocks would otherwise queue thousands of atomics on one address
+                keep = !B.count_all && __builtin_nontemporal_load(&B.count[b]) >= BIN_SLOTS;
+                if (!keep) {
+                    const uint32_t slot = atomicAdd(&B.count[b], 1u);
+                    if (slot < BIN_SLOTS) B.slots[b * BIN_SLOTS + slot] = en.x; else keep = true;
+                }
+            }
+        }
+        const unsigned long long m = __ballot(keep);
+        if (m) {   // rare: compacted behind one atomic per wave
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&counters[4], (uint32_t)__popcll(m));
+            base = __shfl(base, 0);
+            if (keep) left[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = en;
+        }
+    }
+}
+
+template <bool DEPTH_ONLY>
+__global__ __launch_bounds__(256) void k_raster_owned(const RasterRec *__restrict__ rrecs, const BinTables B, const GeomParams gp,
+                                                      unsigned long long *__restrict__ vis, uint32_t *__restrict__ depth_bits) {
+    typedef typename KeyOf<DEPTH_ONLY>::type Key;
+    constexpr Key NONE = (Key)~(Key)0;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t w = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (w >= B.grid_x * B.grid_y) return;
+    const uint32_t bx = w % B.grid_x, gy = w / B.grid_x;
+    // block row of the target: of an interleaved shard only the rows it owns are in the grid (bands of an even number of tile rows)
+    const uint32_t by = B.local_rows ? (uint32_t)(row_global((int)(2 * gy), gp.band_tiles, gp.shard_count, gp.shard_index) + gp.tile_y0) >> 1 : B.by0 + gy;
+    const RasterFrame fr = {gp.sc_x0, gp.sc_y0, gp.sc_x1, gp.sc_y1, gp.tiles_x, gp.tile_y0, gp.pitch, gp.band_tiles, gp.shard_index, gp.shard_count};
+    const int32_t ox = (int32_t)bx * 16, oy = (int32_t)by * 16;
+    const bool whole = ox >= gp.sc_x0 && ox + 16 <= gp.sc_x1 && oy >= gp.sc_y0 && oy + 16 <= gp.sc_y1;
+    const uint32_t code = bx | (by << 12) | (whole ? 0u : ITEM_SCISSOR);
+    // where the block's pixels live, and which of them this shard stores
+    uint32_t at[4]; bool mine[4];
+    block_targets<DEPTH_ONLY>(code, lane, fr, at, mine);
+    if (DEPTH_ONLY) {
+        const int32_t x0 = ox + (int32_t)(lane & 15u), y0 = oy + (int32_t)(lane >> 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mine[k] = x0 < gp.sc_x1 && y0 + 4 * k >= gp.sc_y0 && y0 + 4 * k < gp.sc_y1;   // (sc_x0 = 0: the map's rows, or this rank's slice of them)
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ty_rel = ((oy >> 3) + (k >> 1)) - gp.tile_y0;
+            const int lrow = row_local(ty_rel, gp.band_tiles, gp.shard_count);
+            mine[k] = mine[k] && ty_rel >= 0 && lrow < gp.tiles_y && (ox >> 3) + (k & 1) < gp.tiles_x;
+        }
+    }
+    const uint32_t b = by * B.blocks_x + bx;
+    // the bin: its counter through the scalar unit, its slots one per lane -- all BIN_SLOTS of them, used or not, so that the
+    // load does not wait for the counter
+    const uint32_t my = lane < BIN_SLOTS ? B.slots[b * BIN_SLOTS + lane] : 0u;
+    const uint32_t n = min(B.count[b], BIN_SLOTS);   // wave-uniform (scalar load)
+    // keys with depth bits of 0x3F800000 (a covered pixel at depth 1.0: fails LESS against the clear) or 0xFFFFFFFF (not covered)
+    // lose against every drawn pixel in the merge and are turned into "nothing drawn" once, at the end
+    Key acc[4] = {NONE, NONE, NONE, NONE};
+    const auto merge = [&](const RasterRec &q) {
+        uint32_t zb[4];
+        item_pixels<DEPTH_ONLY, true>(q, code, lane, fr, zb);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const Key key = DEPTH_ONLY ? (Key)zb[k] : (Key)(((unsigned long long)zb[k] << 32) | q.order_id);
+            acc[k] = key < acc[k] ? key : acc[k];
+        }
+    };
+    // the record of item i + 1 is requested when that of item i has arrived, i.e. before item i is evaluated: scalar loads return
+    // out of order, so the only wait there is waits for all of them -- the empty asm (a use of the record, a compiler barrier for
+    // memory operations) pins that wait in front of the next request instead of behind it
+    if (n) {
+        RasterRec q0 = rrecs[__builtin_amdgcn_readlane(my, 0)], q1 = q0;
+        for (uint32_t i = 0;;) {
+            asm volatile("" :: "s"(q0.flags) : "memory");
+            if (i + 1 < n) q1 = rrecs[__builtin_amdgcn_readlane(my, i + 1)];
+            merge(q0);
+            if (++i == n) break;
+            asm volatile("" :: "s"(q1.flags) : "memory");
+            if (i + 1 < n) q0 = rrecs[__builtin_amdgcn_readlane(my, i + 1)];
+            merge(q1);
+            if (++i == n) break;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (!mine[k]) continue;
+        if (DEPTH_ONLY) *(uint32_t __attribute__((address_space(1))) *)((gbytes)depth_bits + at[k] * 4u) = min((uint32_t)acc[k], 0x3F800000u);   // depth 1.0 where nothing was drawn
+        else *(unsigned long long __attribute__((address_space(1))) *)((gbytes)vis + at[k] * 8u) = (uint32_t)(acc[k] >> 32) >= 0x3F800000u ? ~0ull : (unsigned long long)acc[k];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -854,9 +981,9 @@ inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
 hipError_t launch_vertex(const ObjectRec *objs, const uint32_t *block_obj, const uint32_t *block_first, uint32_t n_blocks,
                          const GeomParams &gp, XVert *xv, int clip_only, uint32_t *counters, unsigned long long *clear, unsigned long long clear_value,
-                         size_t clear_count, hipStream_t s) {
+                         size_t clear_count, uint32_t *zero, size_t zero_count, hipStream_t s) {
     if (n_blocks == 0) return clear_count ? launch_fill_u64(clear, clear_value, clear_count, s) : hipSuccess;
-    k_vertex<<<n_blocks, 256, 0, s>>>(objs, block_obj, block_first, gp, xv, clip_only, counters, clear, clear_value, clear_count);
+    k_vertex<<<n_blocks, 256, 0, s>>>(objs, block_obj, block_first, gp, xv, clip_only, counters, clear, clear_value, clear_count, zero, zero_count);
     return hipGetLastError();
 }
 
@@ -882,14 +1009,26 @@ uint32_t raster_grid_blocks(bool depth_only, uint32_t cu_count) {
 }
 
 hipError_t launch_raster_vis(const SetupRec *recs, const RasterRec *rrecs, const uint2 *items, uint32_t item_cap, const uint32_t *counters, uint32_t grid_blocks,
-                             const GeomParams &gp, unsigned long long *vis, uint32_t *host_counts, uint32_t *host_overflow, hipStream_t s) {
-    k_raster<false, RASTER_CHUNK><<<grid_blocks, 256, 0, s>>>(recs, rrecs, items, item_cap, counters, gp, vis, nullptr, host_counts, host_overflow);
+                             const GeomParams &gp, unsigned long long *vis, uint32_t *host_counts, uint32_t *host_overflow, bool after_owned, hipStream_t s) {
+    k_raster<false, RASTER_CHUNK><<<grid_blocks, 256, 0, s>>>(recs, rrecs, items, item_cap, counters, gp, vis, nullptr, host_counts, host_overflow, after_owned ? 1u : 0u);
+    return hipGetLastError();
+}
+
+hipError_t launch_raster_owned(bool depth_only, const RasterRec *rrecs, const uint2 *items, uint2 *left, uint32_t item_cap, uint32_t *counters, const BinTables &B,
+                               const GeomParams &gp, unsigned long long *vis, uint32_t *depth_bits, hipStream_t s) {
+    // the item count stays on the device: a fixed grid strides over the table
+    k_bin<<<std::min<uint32_t>(div_up(item_cap, 256u), 1024u), 256, 0, s>>>(items, left, item_cap, counters, B);
+    const uint32_t n = B.grid_x * B.grid_y;
+    if (n) {
+        if (depth_only) k_raster_owned<true><<<div_up(n, 4), 256, 0, s>>>(rrecs, B, gp, vis, depth_bits);
+        else k_raster_owned<false><<<div_up(n, 4), 256, 0, s>>>(rrecs, B, gp, vis, depth_bits);
+    }
     return hipGetLastError();
 }
 
 hipError_t launch_raster_depth(const SetupRec *recs, const RasterRec *rrecs, const uint2 *items, uint32_t item_cap, const uint32_t *counters, uint32_t grid_blocks,
-                               const GeomParams &gp, uint32_t *depth_bits, uint32_t *host_counts, uint32_t *host_overflow, hipStream_t s) {
-    k_raster<true, RASTER_CHUNK><<<grid_blocks, 256, 0, s>>>(recs, rrecs, items, item_cap, counters, gp, nullptr, depth_bits, host_counts, host_overflow);
+                               const GeomParams &gp, uint32_t *depth_bits, uint32_t *host_counts, uint32_t *host_overflow, bool after_owned, hipStream_t s) {
+    k_raster<true, RASTER_CHUNK><<<grid_blocks, 256, 0, s>>>(recs, rrecs, items, item_cap, counters, gp, nullptr, depth_bits, host_counts, host_overflow, after_owned ? 1u : 0u);
     return hipGetLastError();
 }
 

@@ -169,7 +169,10 @@ struct ArcticRenderer {
     // can run side by side (arctic_render_frame) and the forward pass's records outlive a shadow pass (k_resolve, k_material_vis)
     struct GeoSet {
         DevBuf d_xverts, d_recs, d_rrecs, d_clip_list, d_rec_of, d_items;
+        DevBuf d_left;                     // ... and the work items the bins did not take (same capacity as d_items), for the atomic rasteriser
+        DevBuf d_bin_count, d_bin_slots;   // block ownership (common.h: BinTables): a counter and BIN_SLOTS record indices per 16x16 block of the target
         uint32_t item_cap = 0;      // entries of d_items (work-item table of the rasteriser)
+        uint32_t bins_x = 0, bins_y = 0;   // blocks of the latest owned pass (arctic_read_bin_counts)
     } geo[3];   // indexed like tables
     DevBuf d_geo_counters, d_stage;
     hipStream_t shadow_stream = nullptr;            // arctic_render_frame draws the shadow map here while the main stream runs the visibility prepass
@@ -198,6 +201,8 @@ struct ArcticRenderer {
     int keep_float = 0, count_evals = 0, culling = 1, debug = 0, hdr16 = 0, tile_trace = 0;
     uint32_t tiles_per_wave = 0;     // ARCTIC_OPT_TILES_PER_WAVE (0 = the library's default)
     DevBuf d_tile_trace;             // ARCTIC_OPT_TILE_TRACE: 4 x u64 per tile of the latest shading pass
+    int raster_owner = 1;            // ARCTIC_OPT_RASTER_OWNER: bit 0 forward pass, bit 1 shadow pass: the blocks of the target are written once by owner waves
+                                     // (k_bin + k_raster_owned) instead of per-pixel atomics
     uint32_t raster_blocks[2] = {2048, 2048};  // persistent grid of k_raster: [0] forward pass, [1] shadow pass
     // render_frame re-renders the shadow map only when its inputs changed (sun, objects, meshes): the reference redraws it
     // every frame (renderer.cpp:300-337), but a depth map of unchanged geometry from an unchanged light is the same map
@@ -217,7 +222,7 @@ struct ArcticRenderer {
     uint32_t layout_world = 0; bool layout_from_comm = false;
     bool shadow_sharded = false;                      // ARCTIC_OPT_SHADOW_SHARDED
     uint32_t *dh_counts = nullptr;  // the device's address of h_counts
-    uint32_t *h_counts = nullptr;   // pinned, mapped: [0] records, [1] work items (forward), [2], [3] the same for the shadow pass, [4], [5] item-table overflow flags
+    uint32_t *h_counts = nullptr;   // pinned, mapped: [0] records, [1] work items (forward), [2], [3] the same for the shadow pass, [4], [5] item-table overflow flags, [6], [7] work items drawn by the atomic rasteriser (forward, shadow)
     std::string err;
 
     int fail(int code, const char *fmt, ...) {
@@ -280,7 +285,7 @@ int alloc_targets(ArcticRenderer *r) {
     HIPCHECK(r, r->d_p4.ensure(px * 12));
     HIPCHECK(r, r->d_rgba8.ensure(out_px * 4));
     HIPCHECK(r, r->d_counter.ensure(8 * N_SHADE_STATS));
-    HIPCHECK(r, r->d_geo_counters.ensure(48));   // 4 words per table set
+    HIPCHECK(r, r->d_geo_counters.ensure(3 * N_GEO_COUNTERS * 4));   // N_GEO_COUNTERS words per table set
     r->have_gbuffer = r->have_output = r->have_vis = false;
     return ARCTIC_OK;
 }
@@ -386,6 +391,25 @@ int run_geometry(ArcticRenderer *r, const ArcticScene *sc, bool shadow_pass, hip
         gp.band_tiles = (int32_t)(r->band_rows / TILE); gp.shard_index = (int32_t)r->shard_index; gp.shard_count = (int32_t)r->shard_count;
     }
     gp.raster_flags = (r->debug & 32) ? 1 : 0;
+    gp.tiles_y = shadow_pass ? (int32_t)((r->shadow_size + 7) / 8) : (int32_t)r->tiles_y;
+    // block ownership (ARCTIC_OPT_RASTER_OWNER, default on): the blocks are written once by their owners, so nothing is cleared
+    const bool owned = (r->raster_owner & (shadow_pass ? 2 : 1)) != 0;
+    BinTables B{};
+    if (owned) {
+        const uint32_t tw = shadow_pass ? r->shadow_size : r->width, th = shadow_pass ? r->shadow_size : r->height;
+        B.blocks_x = (tw + 15) / 16;
+        B.n_blocks = B.blocks_x * ((th + 15) / 16);
+        B.grid_x = B.blocks_x;
+        if (shadow_pass) { B.by0 = 0; B.grid_y = (th + 15) / 16; B.local_rows = 0; }
+        else if (gp.band_tiles && gp.band_tiles % 2 == 0 && gp.tile_y0 == 0) { B.by0 = 0; B.grid_y = (r->tiles_y + 1) / 2; B.local_rows = 1; }
+        else if (gp.band_tiles) { B.by0 = 0; B.grid_y = (th + 15) / 16; B.local_rows = 0; }   // bands of an odd number of tile rows: every block row looks for its own tile rows
+        else { B.by0 = r->tile_y0 / 2; B.grid_y = (r->tile_y0 + r->tiles_y + 1) / 2 - B.by0; B.local_rows = 0; }
+        HIPCHECK(r, G.d_bin_count.ensure((size_t)B.n_blocks * 4));
+        HIPCHECK(r, G.d_bin_slots.ensure((size_t)B.n_blocks * BIN_SLOTS * 4));
+        B.count = G.d_bin_count.as<uint32_t>(); B.slots = G.d_bin_slots.as<uint32_t>();
+        B.count_all = (r->debug & 512) ? 1u : 0u;
+        G.bins_x = B.blocks_x; G.bins_y = B.n_blocks / B.blocks_x;
+    } else G.bins_x = G.bins_y = 0;
     PassTables &T = r->tables[set];
     uint32_t n_objs, n_xverts, n_src, n_vblocks, n_tblocks;
     int rc = upload_pass_tables(r, T, G.d_xverts, stream, gp, sc, n_objs, n_xverts, n_src, n_vblocks, n_tblocks);
@@ -398,7 +422,7 @@ int run_geometry(ArcticRenderer *r, const ArcticScene *sc, bool shadow_pass, hip
     }
     const ObjectRec *objs = T.objs;
     HIPCHECK(r, launch_vertex(objs, T.vblock_obj, T.vblock_first, n_vblocks, d_gp, G.d_xverts.as<XVert>(), shadow_pass ? 1 : 0,
-                              r->d_geo_counters.as<uint32_t>() + 4 * set, clear, clear_value, clear_count, stream));
+                              r->d_geo_counters.as<uint32_t>() + N_GEO_COUNTERS * set, clear, clear_value, owned ? 0 : clear_count, B.count, owned ? B.n_blocks : 0, stream));
     // Record slots: a triangle clipped against 6 planes yields at most 7 triangles, so 7 * n_src slots can never overflow.
     // Records and work items are allocated on the device from two counters (k_setup): no count pass, no scan, and neither
     // count has to come back to the host -- the frame stays asynchronous.
@@ -415,23 +439,34 @@ int run_geometry(ArcticRenderer *r, const ArcticScene *sc, bool shadow_pass, hip
         HIPCHECK(r, G.d_items.ensure((size_t)want * 8));
         G.item_cap = (uint32_t)std::min<uint64_t>(want, 0x7FFFFFF0ull);
     }
+    if (owned) HIPCHECK(r, G.d_left.ensure((size_t)G.item_cap * 8));
     HIPCHECK(r, G.d_recs.ensure((size_t)n_slots * sizeof(SetupRec)));
     HIPCHECK(r, G.d_rrecs.ensure((size_t)n_slots * sizeof(RasterRec)));
     HIPCHECK(r, G.d_rec_of.ensure((size_t)n_src * 8 * 4));
     HIPCHECK(r, G.d_clip_list.ensure((size_t)n_src * 8));
-    uint32_t *counters = r->d_geo_counters.as<uint32_t>() + 4 * set;   // zeroed by k_vertex
+    uint32_t *counters = r->d_geo_counters.as<uint32_t>() + N_GEO_COUNTERS * set;   // zeroed by k_vertex
     HIPCHECK(r, launch_setup(objs, T.tblock_obj, T.tblock_first, n_tblocks, d_gp, G.d_xverts.as<XVert>(), G.d_recs.as<SetupRec>(),
                              G.d_rrecs.as<RasterRec>(), G.d_rec_of.as<uint32_t>(), G.d_items.as<uint2>(), G.item_cap, n_slots, counters,
                              G.d_clip_list.as<uint2>(), stream));
     // counts for arctic_stats() and the overflow flag: k_raster stores them into pinned, mapped memory (no copy launches between
     // the kernels); looked at only when the stream has been synchronised
     uint32_t *dh = r->dh_counts + (shadow_pass ? 2 : 0), *dh_overflow = r->dh_counts + 4 + (shadow_pass ? 1 : 0);
+    uint32_t grid = r->raster_blocks[shadow_pass ? 1 : 0];
+    const uint2 *draw = G.d_items.as<uint2>();
+    if (owned) {
+        HIPCHECK(r, launch_raster_owned(shadow_pass, G.d_rrecs.as<RasterRec>(), G.d_items.as<uint2>(), G.d_left.as<uint2>(), G.item_cap, counters, B, d_gp,
+                                        shadow_pass ? nullptr : r->d_vis().as<unsigned long long>(), shadow_pass ? r->d_shadow().as<uint32_t>() : nullptr, stream));
+        // what the bins left goes through the atomic rasteriser: a grid for twice what the previous pass left (pinned h_counts,
+        // a frame late: it only sizes the grid), so that a frame that leaves nothing pays for a launch of 64 workgroups
+        draw = G.d_left.as<uint2>();
+        grid = (uint32_t)std::min<uint64_t>(grid, 64 + 2ull * r->h_counts[6 + (shadow_pass ? 1 : 0)] / (4 * 32));
+    }
     if (shadow_pass)
-        HIPCHECK(r, launch_raster_depth(G.d_recs.as<SetupRec>(), G.d_rrecs.as<RasterRec>(), G.d_items.as<uint2>(), G.item_cap, counters, r->raster_blocks[1], d_gp,
-                                        r->d_shadow().as<uint32_t>(), dh, dh_overflow, stream));
+        HIPCHECK(r, launch_raster_depth(G.d_recs.as<SetupRec>(), G.d_rrecs.as<RasterRec>(), draw, G.item_cap, counters, grid, d_gp,
+                                        r->d_shadow().as<uint32_t>(), dh, dh_overflow, owned, stream));
     else
-        HIPCHECK(r, launch_raster_vis(G.d_recs.as<SetupRec>(), G.d_rrecs.as<RasterRec>(), G.d_items.as<uint2>(), G.item_cap, counters, r->raster_blocks[0], d_gp,
-                                      r->d_vis().as<unsigned long long>(), dh, dh_overflow, stream));
+        HIPCHECK(r, launch_raster_vis(G.d_recs.as<SetupRec>(), G.d_rrecs.as<RasterRec>(), draw, G.item_cap, counters, grid, d_gp,
+                                      r->d_vis().as<unsigned long long>(), dh, dh_overflow, owned, stream));
     return ARCTIC_OK;
 }
 
@@ -718,7 +753,7 @@ void arctic_destroy(ArcticRenderer *r) {
                       &r->d_rgba8, &r->d_ldr, &r->d_hdr, &r->d_counter, &r->d_shadow_blocks_set[0], &r->d_shadow_blocks_set[1], &r->d_shadow_bounds_set[0], &r->d_shadow_bounds_set[1], &r->d_staging, &r->d_layout, &r->geo[0].d_xverts, &r->geo[1].d_xverts, &r->geo[2].d_xverts,
                       &r->geo[2].d_recs, &r->geo[2].d_rrecs, &r->geo[2].d_clip_list, &r->geo[2].d_rec_of, &r->geo[2].d_items, &r->tables[2].d,
                       &r->geo[0].d_recs, &r->geo[0].d_rrecs, &r->geo[0].d_clip_list, &r->geo[0].d_rec_of, &r->geo[0].d_items,
-                      &r->geo[1].d_recs, &r->geo[1].d_rrecs, &r->geo[1].d_clip_list, &r->geo[1].d_rec_of, &r->geo[1].d_items, &r->d_geo_counters, &r->d_stage, &r->tables[0].d, &r->tables[1].d};
+                      &r->geo[1].d_recs, &r->geo[1].d_rrecs, &r->geo[1].d_clip_list, &r->geo[1].d_rec_of, &r->geo[1].d_items, &r->geo[0].d_left, &r->geo[1].d_left, &r->geo[2].d_left, &r->geo[0].d_bin_count, &r->geo[0].d_bin_slots, &r->geo[1].d_bin_count, &r->geo[1].d_bin_slots, &r->geo[2].d_bin_count, &r->geo[2].d_bin_slots, &r->d_geo_counters, &r->d_stage, &r->tables[0].d, &r->tables[1].d};
     for (PassTables &T : r->tables) { if (T.h) (void)hipHostFree(T.h); if (T.copied) (void)hipEventDestroy(T.copied); }
     for (DevBuf *b : bufs) b->release();
     delete r;
@@ -1118,7 +1153,22 @@ int arctic_stats(ArcticRenderer *r, uint64_t *out, uint32_t n) {
     if (!r || !out) return ARCTIC_E_INVALID;
     if (select_device(r) == ARCTIC_OK) (void)hipStreamSynchronize(r->stream);
     if (r->h_counts) for (int i = 0; i < 4; ++i) r->stats[i] = r->h_counts[i];
-    for (uint32_t i = 0; i < n && i < 10; ++i) out[i] = i < 8 ? r->stats[i] : r->light_stats[i - 8];
+    for (uint32_t i = 0; i < n && i < 12; ++i) out[i] = i < 8 ? r->stats[i] : i < 10 ? r->light_stats[i - 8] : (r->h_counts ? r->h_counts[6 + (i - 10)] : 0);
+    return ARCTIC_OK;
+}
+
+int arctic_read_bin_counts(ArcticRenderer *r, int shadow_pass, uint32_t *out, uint64_t capacity_blocks, uint32_t *blocks_x, uint32_t *blocks_y) {
+    if (!r) return ARCTIC_E_INVALID;
+    const ArcticRenderer::GeoSet &G = r->geo[shadow_pass ? 1 : r->fwd()];
+    if (blocks_x) *blocks_x = G.bins_x;
+    if (blocks_y) *blocks_y = G.bins_y;
+    const uint64_t n = (uint64_t)G.bins_x * G.bins_y;
+    if (!out) return ARCTIC_OK;   // size query
+    if (!n) return r->fail(ARCTIC_E_STATE, "read_bin_counts: the latest %s pass had no block owners (ARCTIC_OPT_RASTER_OWNER)", shadow_pass ? "shadow" : "forward");
+    if (capacity_blocks < n) return r->fail(ARCTIC_E_CAPACITY, "read_bin_counts: %llu blocks, room for %llu", (unsigned long long)n, (unsigned long long)capacity_blocks);
+    int rc = arctic_flush(r);
+    if (rc) return rc;
+    HIPCHECK(r, hipMemcpy(out, G.d_bin_count.p, n * 4, hipMemcpyDeviceToHost));
     return ARCTIC_OK;
 }
 
@@ -1167,6 +1217,7 @@ int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value) {
         r->tiles_per_wave = (uint32_t)value;
         break;
     case ARCTIC_OPT_TILE_TRACE: r->tile_trace = value != 0; break;
+    case ARCTIC_OPT_RASTER_OWNER: r->raster_owner = (int)(value & 3); r->shadow_key.clear(); break;
     case ARCTIC_OPT_SHADOW_CACHE: r->shadow_cache = value != 0; r->shadow_key.clear(); break;
     case ARCTIC_OPT_SHADOW_SHARDED: r->shadow_sharded = value != 0; r->shadow_key.clear(); break;
     default: return r->fail(ARCTIC_E_INVALID, "set_option: unknown option %u", option);

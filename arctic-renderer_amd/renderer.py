@@ -229,8 +229,8 @@ class Renderer:
         return ldr, hdr, rgba
 
     def stats(self):
-        s = np.zeros(10, np.uint64)
-        self._check(self.L.arctic_stats(self.h, _ptr(s), 10))
+        s = np.zeros(12, np.uint64)
+        self._check(self.L.arctic_stats(self.h, _ptr(s), 12))
         return s
 
     def tile_trace(self):
@@ -240,6 +240,15 @@ class Renderer:
         self._check(self.L.arctic_read_tile_trace(self.h, None, 0, C.byref(tx), C.byref(ty)))
         out = np.zeros((ty.value, tx.value, 4), np.uint64)
         self._check(self.L.arctic_read_tile_trace(self.h, _ptr(out), tx.value * ty.value, C.byref(tx), C.byref(ty)))
+        return out
+
+    def bin_counts(self, shadow_pass=False):
+        """(blocks_y, blocks_x) uint32: work items per 16x16 block of the latest forward / shadow prepass drawn with block
+        owners (arctic_read_bin_counts)."""
+        bx, by = C.c_uint32(0), C.c_uint32(0)
+        self._check(self.L.arctic_read_bin_counts(self.h, int(shadow_pass), None, 0, C.byref(bx), C.byref(by)))
+        out = np.zeros((by.value, bx.value), np.uint32)
+        self._check(self.L.arctic_read_bin_counts(self.h, int(shadow_pass), _ptr(out), bx.value * by.value, C.byref(bx), C.byref(by)))
         return out
 
     def set_option(self, name, value):

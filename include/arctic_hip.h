@@ -250,7 +250,10 @@ int arctic_frame_constants(const ArcticScene *scene, float *proj_view, float *li
  * [7] evaluations with n.wi > 0 (the others contribute exactly 0,
  * forward.hlsl:191-192), [8] (tile, light) pairs whose n.wi <= 0 in every lit
  * pixel of the 8x8 tile (what a per-tile light list could skip), [9] tiles
- * with a lit pixel.  n <= 10. */
+ * with a lit pixel; [10], [11] work items of the forward / shadow pass that
+ * went through the atomicMin rasteriser (all of them with
+ * ARCTIC_OPT_RASTER_OWNER = 0; with block ownership those that found their
+ * block's bin full or whose record takes the integer path).  n <= 12. */
 int arctic_stats(ArcticRenderer *r, uint64_t *out, uint32_t n);
 
 /* tuning / debug switches. */
@@ -265,7 +268,8 @@ int arctic_stats(ArcticRenderer *r, uint64_t *out, uint32_t n);
                                           of triangles with snapped coordinates of 2^24 and more); bit 6 whole frames gather records and vertices through 64-bit
                                           pointers (the path of tables of 4 GiB and more) instead of 32-bit offsets (same image); bit 7 arctic_render_frame draws the
                                           shadow map on the main stream before the visibility prepass instead of beside it on a second stream (same image);
-                                          bit 8 every tile through the general tile code, none through the fast tile (same image; A/B and tests) */
+                                          bit 8 every tile through the general tile code, none through the fast tile (same image; A/B and tests);
+                                          bit 9 the bins of the block owners count every work item offered, full or not (arctic_read_bin_counts as a histogram; same image) */
 #define ARCTIC_OPT_HDR16             6 /* 1 = round ps_main's colour through binary16 before post_process, like the reference's
                                         R16G16B16A16_FLOAT colour target (forward_pass.cpp:149, renderer.cpp:128-144); default 0 = fp32 */
 #define ARCTIC_OPT_SHADOW_CACHE      9 /* 1 (default) = arctic_render_frame redraws the shadow map only when the sun, the objects or the mesh list changed
@@ -288,6 +292,12 @@ int arctic_stats(ArcticRenderer *r, uint64_t *out, uint32_t n);
                                          (and a wave is launched once for n tiles).  0 (default) = the library's choice.  Placement only: same image */
 #define ARCTIC_OPT_TILE_TRACE        17 /* 1 = the shading pass records per 8x8 tile when its wave started and ended and where it ran (a measuring aid, default 0:
                                          the kernels then pay one wave-uniform branch at either end of a tile); read with arctic_read_tile_trace */
+#define ARCTIC_OPT_RASTER_OWNER      18 /* bit 0 (default on): the forward prepass, bit 1 (default off): the shadow pass -- the rasteriser gives every 16x16 block of
+                                         its target ONE owner wave: work items are handed to per-block bins, the owner merges its bin in registers and writes the
+                                         block once (no clear, no early depth read, no per-pixel atomic); items that find their bin full, and records too large
+                                         for the exact binary64 planes, go through the merging atomicMin rasteriser afterwards.  Bit clear = atomicMin rasteriser
+                                         only (round 2; the shadow pass is instruction bound, not atomic bound: measured slower with owners).  Same visibility /
+                                         shadow map, bit for bit (D3D12's fixed-function raster of forward_pass.cpp:137-151,212-224 / shadow_map_pass.cpp:96-97,157-167) */
 #define ARCTIC_OPT_MARKERS          13 /* 1 = roctx ranges around each pass, named like the reference's Tracy zones (process-wide; libroctx64 is loaded on demand) */
 int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value);
 
@@ -297,6 +307,13 @@ int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value);
    start and end << 8.  out == NULL only reports the grid.  Synchronises.  No counterpart in
    the reference (its GPU timing is Tracy zones per pass, renderer.cpp:285-357); tools/experiments/tile_trace.py reads it. */
 int arctic_read_tile_trace(ArcticRenderer *r, uint64_t *out, uint64_t capacity_tiles, uint32_t *tiles_x, uint32_t *tiles_y);
+
+/* Work items per 16x16 block of the latest forward (shadow_pass = 0) or shadow (1) prepass drawn with block owners
+   (ARCTIC_OPT_RASTER_OWNER): blocks_x x blocks_y counters, row-major over the whole target; a block's owner drew the first 32, the
+   atomicMin rasteriser the rest.  out == NULL only reports the grid.  Synchronises.  A measuring aid (load balance of the owner
+   waves, choice of the bin size); no counterpart in the reference, whose rasteriser is the GPU's fixed function
+   (forward_pass.cpp:212-224). */
+int arctic_read_bin_counts(ArcticRenderer *r, int shadow_pass, uint32_t *out, uint64_t capacity_blocks, uint32_t *blocks_x, uint32_t *blocks_y);
 
 /* library/ABI version: major*10000 + minor*100 + patch */
 int arctic_version(void);
