@@ -201,8 +201,8 @@ struct ArcticRenderer {
     int keep_float = 0, count_evals = 0, culling = 1, debug = 0, hdr16 = 0, tile_trace = 0;
     uint32_t tiles_per_wave = 0;     // ARCTIC_OPT_TILES_PER_WAVE (0 = the library's default)
     DevBuf d_tile_trace;             // ARCTIC_OPT_TILE_TRACE: 4 x u64 per tile of the latest shading pass
-    int raster_owner = 1;            // ARCTIC_OPT_RASTER_OWNER: bit 0 forward pass, bit 1 shadow pass: the blocks of the target are written once by owner waves
-                                     // (k_bin + k_raster_owned) instead of per-pixel atomics
+    int raster_owner = -1;           // ARCTIC_OPT_RASTER_OWNER: bit 0 forward pass, bit 1 shadow pass: the blocks of the target are written once by owner waves
+                                     // (k_bin + k_raster_owned) instead of per-pixel atomics; -1: the library's choice
     uint32_t raster_blocks[2] = {2048, 2048};  // persistent grid of k_raster: [0] forward pass, [1] shadow pass
     // render_frame re-renders the shadow map only when its inputs changed (sun, objects, meshes): the reference redraws it
     // every frame (renderer.cpp:300-337), but a depth map of unchanged geometry from an unchanged light is the same map
@@ -393,7 +393,10 @@ int run_geometry(ArcticRenderer *r, const ArcticScene *sc, bool shadow_pass, hip
     gp.raster_flags = (r->debug & 32) ? 1 : 0;
     gp.tiles_y = shadow_pass ? (int32_t)((r->shadow_size + 7) / 8) : (int32_t)r->tiles_y;
     // block ownership (ARCTIC_OPT_RASTER_OWNER, default on): the blocks are written once by their owners, so nothing is cleared
-    const bool owned = (r->raster_owner & (shadow_pass ? 2 : 1)) != 0;
+    // the library's choice: the forward pass of a handle that owns a third of the frame or more (three launches instead of one:
+    // measured on one rank of R at 4K, whole frames: R = 1 0.304 -> 0.283 ms, R = 2 0.184 -> 0.178, R = 4 0.130 -> 0.136, R = 8 0.102 -> 0.106);
+    // never the shadow pass (instruction bound, two thirds of its blocks empty: 0.124 -> 0.163 ms)
+    const bool owned = r->raster_owner < 0 ? (!shadow_pass && 3ull * r->rows() >= r->height) : (r->raster_owner & (shadow_pass ? 2 : 1)) != 0;
     BinTables B{};
     if (owned) {
         const uint32_t tw = shadow_pass ? r->shadow_size : r->width, th = shadow_pass ? r->shadow_size : r->height;
@@ -1217,7 +1220,7 @@ int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value) {
         r->tiles_per_wave = (uint32_t)value;
         break;
     case ARCTIC_OPT_TILE_TRACE: r->tile_trace = value != 0; break;
-    case ARCTIC_OPT_RASTER_OWNER: r->raster_owner = (int)(value & 3); r->shadow_key.clear(); break;
+    case ARCTIC_OPT_RASTER_OWNER: r->raster_owner = value < 0 ? -1 : (int)(value & 3); r->shadow_key.clear(); break;
     case ARCTIC_OPT_SHADOW_CACHE: r->shadow_cache = value != 0; r->shadow_key.clear(); break;
     case ARCTIC_OPT_SHADOW_SHARDED: r->shadow_sharded = value != 0; r->shadow_key.clear(); break;
     default: return r->fail(ARCTIC_E_INVALID, "set_option: unknown option %u", option);
