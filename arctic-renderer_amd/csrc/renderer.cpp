@@ -72,7 +72,11 @@ struct Rccl {
     bool load() {
         if (!tried) {
             tried = true;
-            void *h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+            // an RCCL the process has loaded already (a host that also runs torch.distributed: PyTorch-ROCm brings its own librccl.so.1)
+            // is the one to use -- ONE library instance with two communicators, not two RCCL builds side by side on the same devices
+            void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+            if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+            if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
             if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
             if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
             if (h) {
