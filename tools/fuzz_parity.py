@@ -36,6 +36,7 @@ for case in range(n_cases):
             d_, n_, m_ = sc.materials[mi]
             sc.materials[mi] = (d_, np.ascontiguousarray(n_[::2, ::3]) if n_.shape[0] > 4 and n_.shape[1] > 6 else n_, np.ascontiguousarray(m_[::3, ::2]) if m_.shape[0] > 6 and m_.shape[1] > 4 else m_)
         hip_options = dict(culling=int(rng.integers(0, 2)), light_path=int(rng.integers(0, 3)))   # exact culling on / off; auto, scalar or packed light loop
+        hip_options["raster_owner"] = (-1, 3, 1, 0)[case % 4]   # the library's choice, block owners in both prepasses, forward only, atomics only (no draw: the stream stays what it was)
         for ob in desc.objects[: 1 + int(rng.integers(0, 3))]:   # move / scale the first few objects (glm column-major trs)
             ob["trs"][12] += float(rng.uniform(-0.3, 0.3)); ob["trs"][13] += float(rng.uniform(0.0, 0.2)); ob["trs"][0] *= float(rng.uniform(0.9, 1.1))
     if cfg == 2:
