@@ -14,7 +14,9 @@
 //             64-bit atomicAdd per workgroup) -> SetupRec[] + RasterRec[] in arbitrary order + explicit work items
 //             (record, 16x16 block), only blocks an edge function can reach; triangles a plane cuts -> clip list
 //   clipped : the clip list, a lane per triangle: Sutherland-Hodgman in LDS, then the same set-up per fan triangle
-//   raster  : persistent; edge functions as exact binary64 planes of the record, four pixels per lane; a wave sorts a chunk of
+//   bin + owned raster (forward pass): every 16x16 block of the target has a bin of 32 record indices and ONE owner wave that merges
+//             the bin in registers and stores the block once -- no clear, no early read, no per-pixel atomic (k_bin, k_raster_owned)
+//   raster  : (shadow pass; small shards; what the bins leave) persistent; edge functions as exact binary64 planes of the record, four pixels per lane; a wave sorts a chunk of
 //             work items by block and merges each run in registers before ONE early read + atomicMin per pixel and run of
 //             (depth bits << 32 | order id) into a tile-major visibility plane: order-independent, so no global sorting and
 //             no per-pixel locks; order id = 8 * source triangle + sub-triangle keeps "first drawn wins" deterministic
