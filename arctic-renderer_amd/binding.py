@@ -49,6 +49,8 @@ SIGNATURES = {
     "arctic_stats": (_i32, [_vp, _vp, _u32]),
     "arctic_read_tile_trace": (_i32, [_vp, _vp, _u64, _vp, _vp]),
     "arctic_read_bin_counts": (_i32, [_vp, _i32, _vp, _u64, _vp, _vp]),
+    "arctic_owner_grid": (_i32, [_u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp]),
+    "arctic_owner_visit": (_i32, [_u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp]),
     "arctic_set_option": (_i32, [_vp, _u32, _i64]),
     "arctic_version": (_i32, []),
     # include/arctic_dist.h: the multi-GPU exchange steps

@@ -134,6 +134,36 @@ __host__ __device__ inline bool row_owned(int ty_rel, int band_tiles, int n, int
 __host__ __device__ inline int row_local(int ty_rel, int band_tiles, int n) { return band_tiles == 0 ? ty_rel : ((ty_rel / band_tiles) / n) * band_tiles + ty_rel % band_tiles; }
 __host__ __device__ inline int row_global(int lt, int band_tiles, int n, int r) { return band_tiles == 0 ? lt : ((lt / band_tiles) * n + r) * band_tiles + lt % band_tiles; }
 
+// The owner grid of a forward prepass (k_raster_owned; the host-side plan: arctic_owner_grid / arctic_owner_visit).  ONE definition of
+// which block row a grid row visits and which of a block's two tile rows the shard stores, for the kernel and for the CPU tests.
+__host__ __device__ inline uint32_t owner_block_row(uint32_t gy, uint32_t by0, uint32_t local_rows, int band_tiles, int shard_count, int shard_index, int tile_y0) {
+    // of an interleaved shard only the rows it owns are in the grid (bands of an even number of tile rows): grid row gy = its gy-th pair of tile rows
+    return local_rows ? (uint32_t)(row_global((int)(2 * gy), band_tiles, shard_count, shard_index) + tile_y0) >> 1 : by0 + gy;
+}
+// tile row j (0: upper, 1: lower) of block row `by`: does this shard store it, and as which of its tile rows?
+__host__ __device__ inline bool owner_tile_row(uint32_t by, int j, int tile_y0, int tiles_y, int band_tiles, int shard_count, int shard_index, int &lrow) {
+    const int ty_rel = (int)(2 * by) + j - tile_y0;
+    lrow = row_local(ty_rel, band_tiles, shard_count);
+    return ty_rel >= 0 && row_owned(ty_rel, band_tiles, shard_count, shard_index) && lrow < tiles_y;
+}
+// grid_x x grid_y blocks from block row by0 (see BinTables) for a target of tw x th pixels stored as tiles_y tile rows from tile_y0
+inline void owner_grid(uint32_t tw, uint32_t th, uint32_t tile_y0, uint32_t tiles_y, uint32_t band_tiles, uint32_t &grid_x, uint32_t &grid_y, uint32_t &by0, uint32_t &local_rows) {
+    grid_x = (tw + 15) / 16;
+    if (band_tiles && band_tiles % 2 == 0 && tile_y0 == 0) { by0 = 0; grid_y = (tiles_y + 1) / 2; local_rows = 1; }
+    else if (band_tiles) { by0 = 0; grid_y = (th + 15) / 16; local_rows = 0; }   // bands of an odd number of tile rows: every block row looks for its own tile rows
+    else { by0 = tile_y0 / 2; grid_y = tiles_y ? (tile_y0 + tiles_y + 1) / 2 - by0 : 0; local_rows = 0; }
+}
+// the tile rows a shard stores: from tile_y0, tiles_y of them (interleaved: the tile rows of its bands, packed)
+inline void shard_tile_rows(uint32_t height, uint32_t row_begin, uint32_t row_end, uint32_t band_rows, uint32_t shard_index, uint32_t shard_count, uint32_t &tile_y0, uint32_t &tiles_y) {
+    tile_y0 = row_begin / TILE;
+    tiles_y = (row_end + TILE - 1) / TILE - tile_y0;
+    if (band_rows) {
+        const int bt = (int)(band_rows / TILE), all = (int)((height + TILE - 1) / TILE);
+        tiles_y = 0;
+        for (int ty = 0; ty < all; ++ty) if (row_owned(ty, bt, (int)shard_count, (int)shard_index)) ++tiles_y;
+    }
+}
+
 // Which shard holds frame row y, and as which of its rows (the exchange step, include/arctic_dist.h).  Interleaved sharding
 // (band_rows > 0): row y belongs to band y / band_rows, the band to rank band % world, and is that rank's local row
 // (band / world) * band_rows + y % band_rows (all its earlier bands are full).  Row ranges (band_rows == 0): ranges[2k],

@@ -836,8 +836,7 @@ __global__ __launch_bounds__(256) void k_raster_owned(const RasterRec *__restric
     const uint32_t w = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (w >= B.grid_x * B.grid_y) return;
     const uint32_t bx = w % B.grid_x, gy = w / B.grid_x;
-    // block row of the target: of an interleaved shard only the rows it owns are in the grid (bands of an even number of tile rows)
-    const uint32_t by = B.local_rows ? (uint32_t)(row_global((int)(2 * gy), gp.band_tiles, gp.shard_count, gp.shard_index) + gp.tile_y0) >> 1 : B.by0 + gy;
+    const uint32_t by = owner_block_row(gy, B.by0, B.local_rows, gp.band_tiles, gp.shard_count, gp.shard_index, gp.tile_y0);   // block row of the target
     const RasterFrame fr = {gp.sc_x0, gp.sc_y0, gp.sc_x1, gp.sc_y1, gp.tiles_x, gp.tile_y0, gp.pitch, gp.band_tiles, gp.shard_index, gp.shard_count};
     const int32_t ox = (int32_t)bx * 16, oy = (int32_t)by * 16;
     const bool whole = ox >= gp.sc_x0 && ox + 16 <= gp.sc_x1 && oy >= gp.sc_y0 && oy + 16 <= gp.sc_y1;
@@ -852,9 +851,8 @@ __global__ __launch_bounds__(256) void k_raster_owned(const RasterRec *__restric
     } else {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int ty_rel = ((oy >> 3) + (k >> 1)) - gp.tile_y0;
-            const int lrow = row_local(ty_rel, gp.band_tiles, gp.shard_count);
-            mine[k] = mine[k] && ty_rel >= 0 && lrow < gp.tiles_y && (ox >> 3) + (k & 1) < gp.tiles_x;
+            int lrow;
+            mine[k] = owner_tile_row(by, k >> 1, gp.tile_y0, gp.tiles_y, gp.band_tiles, gp.shard_count, gp.shard_index, lrow) && (ox >> 3) + (k & 1) < gp.tiles_x;
         }
     }
     const uint32_t b = by * B.blocks_x + bx;

@@ -267,16 +267,15 @@ int select_device(ArcticRenderer *r) {
 
 int alloc_targets(ArcticRenderer *r) {
     r->shadow_key.clear();   // buffers may move: render_frame redraws the shadow map
-    r->tile_y0 = r->row_begin / TILE;
+    shard_tile_rows(r->height, r->row_begin, r->row_end, r->band_rows, r->shard_index, r->shard_count, r->tile_y0, r->tiles_y);
     r->row0_in_tile = r->row_begin - r->tile_y0 * TILE;
     r->tiles_x = (r->width + TILE - 1) / TILE;
-    r->tiles_y = (r->row_end + TILE - 1) / TILE - r->tile_y0;
-    if (r->band_rows) {   // interleaved shard: count the tile rows and pixel rows this shard owns
+    if (r->band_rows) {   // interleaved shard: count the pixel rows this shard owns
         const int bt = (int)(r->band_rows / TILE), all = (int)((r->height + TILE - 1) / TILE);
-        uint32_t own_t = 0, own_r = 0;
+        uint32_t own_r = 0;
         for (int ty = 0; ty < all; ++ty)
-            if (row_owned(ty, bt, (int)r->shard_count, (int)r->shard_index)) { ++own_t; own_r += std::min<uint32_t>(TILE, r->height - (uint32_t)ty * TILE); }
-        r->tiles_y = own_t; r->owned_rows = own_r;
+            if (row_owned(ty, bt, (int)r->shard_count, (int)r->shard_index)) own_r += std::min<uint32_t>(TILE, r->height - (uint32_t)ty * TILE);
+        r->owned_rows = own_r;
     }
     size_t px = r->n_tiles() * TILE_PIXELS, out_px = (size_t)r->rows() * r->width;
     HIPCHECK(r, r->d_vis_set[0].ensure(px * 8));
@@ -406,11 +405,8 @@ int run_geometry(ArcticRenderer *r, const ArcticScene *sc, bool shadow_pass, hip
         const uint32_t tw = shadow_pass ? r->shadow_size : r->width, th = shadow_pass ? r->shadow_size : r->height;
         B.blocks_x = (tw + 15) / 16;
         B.n_blocks = B.blocks_x * ((th + 15) / 16);
-        B.grid_x = B.blocks_x;
-        if (shadow_pass) { B.by0 = 0; B.grid_y = (th + 15) / 16; B.local_rows = 0; }
-        else if (gp.band_tiles && gp.band_tiles % 2 == 0 && gp.tile_y0 == 0) { B.by0 = 0; B.grid_y = (r->tiles_y + 1) / 2; B.local_rows = 1; }
-        else if (gp.band_tiles) { B.by0 = 0; B.grid_y = (th + 15) / 16; B.local_rows = 0; }   // bands of an odd number of tile rows: every block row looks for its own tile rows
-        else { B.by0 = r->tile_y0 / 2; B.grid_y = (r->tile_y0 + r->tiles_y + 1) / 2 - B.by0; B.local_rows = 0; }
+        if (shadow_pass) { B.grid_x = B.blocks_x; B.by0 = 0; B.grid_y = (th + 15) / 16; B.local_rows = 0; }
+        else owner_grid(tw, th, r->tile_y0, r->tiles_y, (uint32_t)gp.band_tiles, B.grid_x, B.grid_y, B.by0, B.local_rows);
         HIPCHECK(r, G.d_bin_count.ensure((size_t)B.n_blocks * 4));
         HIPCHECK(r, G.d_bin_slots.ensure((size_t)B.n_blocks * BIN_SLOTS * 4));
         B.count = G.d_bin_count.as<uint32_t>(); B.slots = G.d_bin_slots.as<uint32_t>();
@@ -1161,6 +1157,35 @@ int arctic_stats(ArcticRenderer *r, uint64_t *out, uint32_t n) {
     if (select_device(r) == ARCTIC_OK) (void)hipStreamSynchronize(r->stream);
     if (r->h_counts) for (int i = 0; i < 4; ++i) r->stats[i] = r->h_counts[i];
     for (uint32_t i = 0; i < n && i < 12; ++i) out[i] = i < 8 ? r->stats[i] : i < 10 ? r->light_stats[i - 8] : (r->h_counts ? r->h_counts[6 + (i - 10)] : 0);
+    return ARCTIC_OK;
+}
+
+// the owner grid as plain numbers (pure host functions: tests/test_owner_grid.py checks that every tile row a shard stores is visited
+// exactly once, for layouts no GPU test has time for)
+int arctic_owner_grid(uint32_t width, uint32_t height, uint32_t row_begin, uint32_t row_end, uint32_t band_rows, uint32_t shard_index, uint32_t shard_count,
+                      uint32_t *grid /* grid_x, grid_y, first block row, 1 = grid rows are the shard's own pairs of tile rows */) {
+    if (!grid || !width || !height || (band_rows ? (band_rows % TILE || !shard_count || shard_index >= shard_count) : (row_begin >= row_end || row_end > height))) return ARCTIC_E_INVALID;
+    if (band_rows) { row_begin = 0; row_end = height; }
+    uint32_t tile_y0, tiles_y;
+    shard_tile_rows(height, row_begin, row_end, band_rows, shard_index, band_rows ? shard_count : 1u, tile_y0, tiles_y);
+    owner_grid(width, height, tile_y0, tiles_y, band_rows / TILE, grid[0], grid[1], grid[2], grid[3]);
+    return ARCTIC_OK;
+}
+int arctic_owner_visit(uint32_t width, uint32_t height, uint32_t row_begin, uint32_t row_end, uint32_t band_rows, uint32_t shard_index, uint32_t shard_count,
+                       uint32_t grid_row, uint32_t *block_row, int32_t *local_tile_rows /* [2]: the shard's tile row stored for the block's upper / lower tile row, -1: none */) {
+    uint32_t grid[4];
+    const int rc = arctic_owner_grid(width, height, row_begin, row_end, band_rows, shard_index, shard_count, grid);
+    if (rc != ARCTIC_OK) return rc;
+    if (!block_row || !local_tile_rows || grid_row >= grid[1]) return ARCTIC_E_INVALID;
+    if (band_rows) { row_begin = 0; row_end = height; } else shard_count = 1, shard_index = 0;
+    uint32_t tile_y0, tiles_y;
+    shard_tile_rows(height, row_begin, row_end, band_rows, shard_index, shard_count, tile_y0, tiles_y);
+    const int bt = (int)(band_rows / TILE);
+    *block_row = owner_block_row(grid_row, grid[2], grid[3], bt, (int)shard_count, (int)shard_index, (int)tile_y0);
+    for (int j = 0; j < 2; ++j) {
+        int lrow;
+        local_tile_rows[j] = owner_tile_row(*block_row, j, (int)tile_y0, (int)tiles_y, bt, (int)shard_count, (int)shard_index, lrow) ? lrow : -1;
+    }
     return ARCTIC_OK;
 }
 

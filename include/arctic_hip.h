@@ -316,6 +316,16 @@ int arctic_read_tile_trace(ArcticRenderer *r, uint64_t *out, uint64_t capacity_t
    (forward_pass.cpp:212-224). */
 int arctic_read_bin_counts(ArcticRenderer *r, int shadow_pass, uint32_t *out, uint64_t capacity_blocks, uint32_t *blocks_x, uint32_t *blocks_y);
 
+/* The owner grid of a forward prepass as plain numbers -- pure host functions, no device, no handle (the library's kernels use the
+   same definitions).  A handle created with these sizes (row range [row_begin, row_end), or -- band_rows > 0 -- the interleaved
+   shard shard_index of shard_count) launches grid[0] x grid[1] owner waves, one per 16x16 block; arctic_owner_visit: grid row
+   `grid_row` visits block row *block_row of the frame and stores its upper / lower 8-pixel tile row as the shard's tile row
+   local_tile_rows[0] / [1] (-1: that tile row is not this shard's).  Every tile row a shard stores must be visited exactly once:
+   tests/test_owner_grid.py checks that for worlds 1..8, bands of odd and even numbers of tile rows and row ranges that cut blocks. */
+int arctic_owner_grid(uint32_t width, uint32_t height, uint32_t row_begin, uint32_t row_end, uint32_t band_rows, uint32_t shard_index, uint32_t shard_count, uint32_t *grid);
+int arctic_owner_visit(uint32_t width, uint32_t height, uint32_t row_begin, uint32_t row_end, uint32_t band_rows, uint32_t shard_index, uint32_t shard_count,
+                       uint32_t grid_row, uint32_t *block_row, int32_t *local_tile_rows);
+
 /* library/ABI version: major*10000 + minor*100 + patch */
 int arctic_version(void);
 
