@@ -51,6 +51,9 @@ import time
 # the HIP events around the same launches, 0.1948 -> 0.1910 -- back-to-back launches are handed over faster, and the timed
 # region of 20 steps ends ~40 us earlier.  A host-side choice (a core per rank spins while it waits); recorded in the line.
 os.environ.setdefault("HSA_ENABLE_INTERRUPT", "0")
+# ... and kernel arguments live in device memory (the default of this ROCm; with 0 -- arguments fetched from host memory --
+# whole frames measured 0.281 -> 0.292 ms and the pass 0.195 -> 0.198: the shading kernels re-read their 400 bytes per tile)
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 import numpy as np
 
