@@ -396,10 +396,12 @@ int run_geometry(ArcticRenderer *r, const ArcticScene *sc, bool shadow_pass, hip
     gp.raster_flags = (r->debug & 32) ? 1 : 0;
     gp.tiles_y = shadow_pass ? (int32_t)((r->shadow_size + 7) / 8) : (int32_t)r->tiles_y;
     // block ownership (ARCTIC_OPT_RASTER_OWNER, default on): the blocks are written once by their owners, so nothing is cleared
-    // the library's choice: the forward pass of a handle that owns a third of the frame or more (three launches instead of one:
-    // measured on one rank of R at 4K, whole frames: R = 1 0.304 -> 0.283 ms, R = 2 0.184 -> 0.178, R = 4 0.130 -> 0.136, R = 8 0.102 -> 0.106);
+    // the library's choice: the forward pass of a handle that owns 4 Mpx or more -- three launches instead of one cost ~12 us of fixed
+    // time, what the atomics cost grows with the pixels.  Whole frames with / without owners: 4K 0.283 / 0.304 ms, one rank of R = 2 at 4K
+    // (4.1 Mpx) 0.178 / 0.184, of R = 4 0.136 / 0.130, of R = 8 0.106 / 0.102; config 3 at 1080p 0.113 / 0.114, config 2 (1080p, dense
+    // meshes: 14 % of the items beyond their bins) 0.106 / 0.093, config 1 (512^2) 0.064 / 0.038;
     // never the shadow pass (instruction bound, two thirds of its blocks empty: 0.124 -> 0.163 ms)
-    const bool owned = r->raster_owner < 0 ? (!shadow_pass && 3ull * r->rows() >= r->height) : (r->raster_owner & (shadow_pass ? 2 : 1)) != 0;
+    const bool owned = r->raster_owner < 0 ? (!shadow_pass && (uint64_t)r->rows() * r->width >= 4000000ull) : (r->raster_owner & (shadow_pass ? 2 : 1)) != 0;
     BinTables B{};
     if (owned) {
         const uint32_t tw = shadow_pass ? r->shadow_size : r->width, th = shadow_pass ? r->shadow_size : r->height;
@@ -459,10 +461,11 @@ int run_geometry(ArcticRenderer *r, const ArcticScene *sc, bool shadow_pass, hip
     if (owned) {
         HIPCHECK(r, launch_raster_owned(shadow_pass, G.d_rrecs.as<RasterRec>(), G.d_items.as<uint2>(), G.d_left.as<uint2>(), G.item_cap, counters, B, d_gp,
                                         shadow_pass ? nullptr : r->d_vis().as<unsigned long long>(), shadow_pass ? r->d_shadow().as<uint32_t>() : nullptr, stream));
-        // what the bins left goes through the atomic rasteriser: a grid for twice what the previous pass left (pinned h_counts,
-        // a frame late: it only sizes the grid), so that a frame that leaves nothing pays for a launch of 64 workgroups
+        // what the bins left goes through the atomic rasteriser: when the previous pass left next to nothing (pinned h_counts, a frame
+        // late: it only sizes the grid) a launch of 64 workgroups, else the whole persistent grid -- the kernel shortens its chunks
+        // so that every resident wave gets one (a grid cut to the item count measured slower: config 1, half of whose items are left)
         draw = G.d_left.as<uint2>();
-        grid = (uint32_t)std::min<uint64_t>(grid, 64 + 2ull * r->h_counts[6 + (shadow_pass ? 1 : 0)] / (4 * 32));
+        if (r->h_counts[6 + (shadow_pass ? 1 : 0)] <= 64) grid = std::min<uint32_t>(grid, 64);
     }
     if (shadow_pass)
         HIPCHECK(r, launch_raster_depth(G.d_recs.as<SetupRec>(), G.d_rrecs.as<RasterRec>(), draw, G.item_cap, counters, grid, d_gp,

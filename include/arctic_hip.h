@@ -292,7 +292,7 @@ int arctic_stats(ArcticRenderer *r, uint64_t *out, uint32_t n);
                                          (and a wave is launched once for n tiles).  0 (default) = the library's choice.  Placement only: same image */
 #define ARCTIC_OPT_TILE_TRACE        17 /* 1 = the shading pass records per 8x8 tile when its wave started and ended and where it ran (a measuring aid, default 0:
                                          the kernels then pay one wave-uniform branch at either end of a tile); read with arctic_read_tile_trace */
-#define ARCTIC_OPT_RASTER_OWNER      18 /* -1 (default) = the library's choice: the forward prepass of a handle that owns a third of the frame's rows or more; otherwise
+#define ARCTIC_OPT_RASTER_OWNER      18 /* -1 (default) = the library's choice: the forward prepass of a handle that owns 4 Mpx of the frame or more; otherwise
                                          bit 0: the forward prepass, bit 1: the shadow pass -- the rasteriser gives every 16x16 block of
                                          its target ONE owner wave: work items are handed to per-block bins, the owner merges its bin in registers and writes the
                                          block once (no clear, no early depth read, no per-pixel atomic); items that find their bin full, and records too large
