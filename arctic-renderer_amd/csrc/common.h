@@ -251,6 +251,7 @@ struct ShadeLaunch {
 };
 constexpr uint32_t N_SHADE_STATS = 5;
 constexpr uint32_t DEFAULT_TILES_PER_WAVE = 2;
+constexpr uint32_t SMALL_FRAME_TILES = 48000;   // fewer 8x8 tiles than this (~3 Mpx): one tile per wave (launch_shade)
 // the shadow-bounds table: one entry per 4x4 texel block; only for maps whose 25 PCF taps (4e-4 S apart end to end, in fp32)
 // span less than 2 texels, so that a footprint never leaves the 4x4 window behind its first texel
 inline uint32_t shadow_bounds_pitch(uint32_t S) { return S >= 4 && S <= 4900 ? (S + 3) / 4 : 0; }

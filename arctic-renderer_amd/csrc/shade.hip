@@ -1182,7 +1182,10 @@ hipError_t launch_shade(const ShadeParams &sp_in, const ShadeLaunch &L) {
     const uint32_t n_tiles = sp_in.tiles_x * sp_in.tiles_y;
     if (n_tiles == 0) return hipSuccess;
     ShadeParams sp = sp_in;
-    sp.tiles_per_wave = L.tiles_per_wave ? L.tiles_per_wave : DEFAULT_TILES_PER_WAVE;
+    // two tiles per wave pay once a frame is several rounds of the chip's wave slots; below ~3 Mpx one tile per wave is faster
+    // (tools/experiments/small_frames.py: 1080p pass 0.0638 -> 0.0610 ms, whole frame 0.098 -> 0.084 ms with T = 1; 2688 x 1512: 0.101 against
+    // 0.104 ms and 0.142 against 0.153 with T = 2)
+    sp.tiles_per_wave = L.tiles_per_wave ? L.tiles_per_wave : (n_tiles < SMALL_FRAME_TILES ? 1u : DEFAULT_TILES_PER_WAVE);
     const uint32_t bpr = (sp.tiles_x + 3) / 4, groups = (sp.tiles_y + 7) / 8;
     const dim3 grid(8 * bpr, (groups + sp.tiles_per_wave - 1) / sp.tiles_per_wave);   // a block shades tiles_per_wave groups of 8 tile rows
     if (sp.debug & 16)   // A/B only: the 25-tap path staged through LDS (a separate instantiation: it costs the default kernels nothing)

@@ -289,7 +289,8 @@ int arctic_stats(ArcticRenderer *r, uint64_t *out, uint32_t n);
 #define ARCTIC_OPT_TILES_PER_WAVE    16 /* tiles a wave of the shading pass (arctic_pass_shade) shades one after the other, 1 / n-th of the frame's height apart:
                                          lit (ALU-bound) and shadowed (latency-bound) regions are spatially clustered, and a wave that visits n distant parts of the
                                          frame carries a mix of both, so that every SIMD holds both kinds all the time, wherever in the frame the light falls
-                                         (and a wave is launched once for n tiles).  0 (default) = the library's choice.  Placement only: same image */
+                                         (and a wave is launched once for n tiles).  0 (default) = the library's choice: 2, and 1 for targets below ~3 Mpx, where a frame is
+                                         only a few rounds of the chip's wave slots.  Placement only: same image */
 #define ARCTIC_OPT_TILE_TRACE        17 /* 1 = the shading pass records per 8x8 tile when its wave started and ended and where it ran (a measuring aid, default 0:
                                          the kernels then pay one wave-uniform branch at either end of a tile); read with arctic_read_tile_trace */
 #define ARCTIC_OPT_RASTER_OWNER      18 /* -1 (default) = the library's choice: the forward prepass of a handle that owns 4 Mpx of the frame or more; otherwise
