@@ -243,3 +243,23 @@ def test_profiler_markers_option(pkg, hip):
     r.set_option("markers", 0)
     np.testing.assert_array_equal(a, b)
     r.close()
+
+
+@pytest.mark.parametrize("scale", [0.05, 0.13])
+def test_tiles_per_wave_is_placement_only(pkg, hip, scale):
+    """ARCTIC_OPT_TILES_PER_WAVE (the library shades one tile per wave below ~3 Mpx, two above): a wave that shades T tiles
+    1 / T-th of the frame apart writes the same bytes whatever T, also when the groups of 8 tile rows do not divide by T --
+    through the G-buffer pass and through whole frames from the visibility plane."""
+    sc = pkg.scenes.config3(scale=scale)
+    outs = []
+    for T in (0, 1, 2, 3, 5):
+        r = sc.upload(hip.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights))
+        r.set_option("tiles_per_wave", T)
+        frame = r.render_frame(sc.desc, sc.settings).copy()
+        r.pass_shadow_map(sc.desc); r.pass_gbuffer(sc.desc); r.pass_shade(sc.desc, sc.settings)
+        outs.append((frame, r.read_output(want=("rgba8",))[2].copy()))
+        r.close()
+    for frame, passed in outs[1:]:
+        np.testing.assert_array_equal(frame, outs[0][0])
+        np.testing.assert_array_equal(passed, outs[0][1])
+    np.testing.assert_array_equal(outs[0][0], outs[0][1])
