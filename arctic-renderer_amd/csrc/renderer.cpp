@@ -163,12 +163,12 @@ struct ArcticRenderer {
     uint32_t env_w = 0, env_h = 0;
     uint32_t n_lights = 0;
     // frame targets
-    DevBuf d_vis_set[2], d_p0, d_p1, d_p2, d_p3, d_p4, d_rgba8, d_ldr, d_hdr, d_counter;
+    DevBuf d_vis_set[3], d_p0, d_p1, d_p2, d_p3, d_p4, d_rgba8, d_ldr, d_hdr, d_counter;
     bool have_gbuffer = false, have_output = false, have_vis = false;   // have_vis: d_vis holds the visibility of the current G-buffer
     int light_path = 0;             // ARCTIC_OPT_LIGHT_PATH: 0 automatic, 1 scalar light loop, 2 packed pairs
     bool visbuffer = true;          // arctic_render_frame shades straight from the visibility plane (no G-buffer)
     // per-frame geometry scratch
-    PassTables tables[3];   // [0], [2] forward pass (one per frame in flight), [1] shadow pass
+    PassTables tables[4];   // [0], [2], [3] forward pass (one per frame in flight), [1] shadow pass
     // transformed vertices, records, work items: one set per pass ([0] forward, [1] shadow), so that the two prepasses of a frame
     // can run side by side (arctic_render_frame) and the forward pass's records outlive a shadow pass (k_resolve, k_material_vis)
     struct GeoSet {
@@ -177,7 +177,7 @@ struct ArcticRenderer {
         DevBuf d_bin_count, d_bin_slots;   // block ownership (common.h: BinTables): a counter and BIN_SLOTS record indices per 16x16 block of the target
         uint32_t item_cap = 0;      // entries of d_items (work-item table of the rasteriser)
         uint32_t bins_x = 0, bins_y = 0;   // blocks of the latest owned pass (arctic_read_bin_counts)
-    } geo[3];   // indexed like tables
+    } geo[4];   // indexed like tables
     DevBuf d_geo_counters, d_stage;
     hipStream_t shadow_stream = nullptr;            // arctic_render_frame draws the shadow map here while the main stream runs the visibility prepass
     hipEvent_t ev_fork = nullptr, ev_shadow = nullptr;
@@ -192,12 +192,15 @@ struct ArcticRenderer {
     // shading reads -- visibility plane, vertex / record / item tables, object tables -- and `cur` names the set of the latest frame
     // (the one the pass-level calls and arctic_read_gbuffer see).  ev_released[s]: everything enqueued on the main stream up to
     // the moment the handle moved on from set s; the next prepass into s waits for it.
-    int frames_in_flight = 2, cur = 0;
-    hipStream_t prepass_stream = nullptr;
-    hipEvent_t ev_prepass = nullptr, ev_released[2] = {nullptr, nullptr};
-    bool released_valid[2] = {false, false};
+    // Up to three sets (the reference keeps 3 frames in flight, rhi.hpp:25) and two prepass streams used alternately: with three
+    // sets the prepasses of two consecutive frames are independent of each other as well, and a small frame -- whose prepass is a
+    // chain of launches longer than its shading -- is bound by neither chain alone.
+    int frames_in_flight = 2, frames_in_flight_opt = 0 /* ARCTIC_OPT_FRAMES_IN_FLIGHT; 0: by the target's size (alloc_targets) */, cur = 0, prepass_turn = 0;
+    hipStream_t prepass_stream[2] = {nullptr, nullptr};
+    hipEvent_t ev_prepass[2] = {nullptr, nullptr}, ev_released[3] = {nullptr, nullptr, nullptr};
+    bool released_valid[3] = {false, false, false};
     DevBuf &d_vis() { return d_vis_set[cur]; }
-    int fwd() const { return cur ? 2 : 0; }            // index of the current forward set in tables / geo
+    int fwd() const { return cur ? cur + 1 : 0; }      // index of the current forward set in tables / geo
     bool recs_worst_case = false;   // record table at 7 per source triangle (after an overflow of the 2-per-triangle table)
     uint32_t item_cap_floor = 1u << 22;   // its smallest size (ARCTIC_OPT_ITEM_TABLE_FLOOR; tests shrink it to reach the overflow path)
     uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -278,9 +281,12 @@ int alloc_targets(ArcticRenderer *r) {
         r->owned_rows = own_r;
     }
     size_t px = r->n_tiles() * TILE_PIXELS, out_px = (size_t)r->rows() * r->width;
-    HIPCHECK(r, r->d_vis_set[0].ensure(px * 8));
-    HIPCHECK(r, r->d_vis_set[1].ensure(px * 8));
-    r->released_valid[0] = r->released_valid[1] = false;   // (callers synchronise before they resize)
+    for (DevBuf &v : r->d_vis_set) HIPCHECK(r, v.ensure(px * 8));
+    // the library's choice of frames in flight: 2, and 3 for targets below 3 Mpx, whose prepass -- a chain of launches -- is longer than
+    // their shading (tools/experiments/in_flight.py, 2 / 3 in flight: 1080p config 2 0.077 / 0.065 ms, config 3 at 1080p 0.094 / 0.088,
+    // config 1 0.030 / 0.026; 4K 0.278 / 0.284)
+    if (r->frames_in_flight_opt == 0) { r->frames_in_flight = (uint64_t)r->rows() * r->width < 3000000ull ? 3 : 2; r->cur = 0; }
+    r->released_valid[0] = r->released_valid[1] = r->released_valid[2] = false;   // (callers synchronise before they resize)
     HIPCHECK(r, r->d_p0.ensure(px * 16));
     HIPCHECK(r, r->d_p1.ensure(px * 16));
     HIPCHECK(r, r->d_p2.ensure(px * 16));
@@ -288,7 +294,7 @@ int alloc_targets(ArcticRenderer *r) {
     HIPCHECK(r, r->d_p4.ensure(px * 12));
     HIPCHECK(r, r->d_rgba8.ensure(out_px * 4));
     HIPCHECK(r, r->d_counter.ensure(8 * N_SHADE_STATS));
-    HIPCHECK(r, r->d_geo_counters.ensure(3 * N_GEO_COUNTERS * 4));   // N_GEO_COUNTERS words per table set
+    HIPCHECK(r, r->d_geo_counters.ensure(4 * N_GEO_COUNTERS * 4));   // N_GEO_COUNTERS words per table set
     r->have_gbuffer = r->have_output = r->have_vis = false;
     return ARCTIC_OK;
 }
@@ -705,8 +711,10 @@ ArcticRenderer *arctic_create(const ArcticCreateInfo *info, char *err, uint64_t 
     if ((e = hipEventCreateWithFlags(&r->ev_fork, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&r->ev_shadow, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&r->ev_shadow_scratch, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
-    if ((e = hipStreamCreateWithFlags(&r->prepass_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
-    if ((e = hipEventCreateWithFlags(&r->ev_prepass, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    for (int k = 0; k < 2; ++k) {
+        if ((e = hipStreamCreateWithFlags(&r->prepass_stream[k], hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+        if ((e = hipEventCreateWithFlags(&r->ev_prepass[k], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    }
     for (hipEvent_t &ev : r->ev_released)
         if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     for (hipEvent_t &ev : r->ev_shadow_released)
@@ -745,8 +753,8 @@ void arctic_destroy(ArcticRenderer *r) {
     (void)hipStreamSynchronize(r->stream);
     (void)arctic_comm_destroy(r);
     if (r->shadow_stream) { (void)hipStreamSynchronize(r->shadow_stream); (void)hipStreamDestroy(r->shadow_stream); }
-    if (r->prepass_stream) { (void)hipStreamSynchronize(r->prepass_stream); (void)hipStreamDestroy(r->prepass_stream); }
-    if (r->ev_prepass) (void)hipEventDestroy(r->ev_prepass);
+    for (hipStream_t ps : r->prepass_stream) if (ps) { (void)hipStreamSynchronize(ps); (void)hipStreamDestroy(ps); }
+    for (hipEvent_t ev : r->ev_prepass) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : r->ev_released) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : r->ev_shadow_released) if (ev) (void)hipEventDestroy(ev);
     if (r->ev_fork) (void)hipEventDestroy(r->ev_fork);
@@ -755,9 +763,10 @@ void arctic_destroy(ArcticRenderer *r) {
     if (r->own_stream) { (void)hipStreamSynchronize(r->own_stream); (void)hipStreamDestroy(r->own_stream); }
     for (Mesh &m : r->meshes) { if (m.d_vertices) (void)hipFree(m.d_vertices); if (m.d_indices) (void)hipFree(m.d_indices); }
     for (void *p : r->tex_allocs) (void)hipFree(p);
-    DevBuf *bufs[] = {&r->d_tex, &r->d_lut, &r->d_lights, &r->d_light_pairs, &r->d_shadow_set[0], &r->d_shadow_set[1], &r->d_env, &r->d_vis_set[0], &r->d_vis_set[1], &r->d_p0, &r->d_p1, &r->d_p2, &r->d_p3, &r->d_p4,
+    DevBuf *bufs[] = {&r->d_tex, &r->d_lut, &r->d_lights, &r->d_light_pairs, &r->d_shadow_set[0], &r->d_shadow_set[1], &r->d_env, &r->d_vis_set[0], &r->d_vis_set[1], &r->d_vis_set[2], &r->d_p0, &r->d_p1, &r->d_p2, &r->d_p3, &r->d_p4,
                       &r->d_rgba8, &r->d_ldr, &r->d_hdr, &r->d_counter, &r->d_shadow_blocks_set[0], &r->d_shadow_blocks_set[1], &r->d_shadow_bounds_set[0], &r->d_shadow_bounds_set[1], &r->d_staging, &r->d_layout, &r->geo[0].d_xverts, &r->geo[1].d_xverts, &r->geo[2].d_xverts,
                       &r->geo[2].d_recs, &r->geo[2].d_rrecs, &r->geo[2].d_clip_list, &r->geo[2].d_rec_of, &r->geo[2].d_items, &r->tables[2].d,
+                      &r->geo[3].d_xverts, &r->geo[3].d_recs, &r->geo[3].d_rrecs, &r->geo[3].d_clip_list, &r->geo[3].d_rec_of, &r->geo[3].d_items, &r->geo[3].d_left, &r->geo[3].d_bin_count, &r->geo[3].d_bin_slots, &r->tables[3].d,
                       &r->geo[0].d_recs, &r->geo[0].d_rrecs, &r->geo[0].d_clip_list, &r->geo[0].d_rec_of, &r->geo[0].d_items,
                       &r->geo[1].d_recs, &r->geo[1].d_rrecs, &r->geo[1].d_clip_list, &r->geo[1].d_rec_of, &r->geo[1].d_items, &r->geo[0].d_left, &r->geo[1].d_left, &r->geo[2].d_left, &r->geo[0].d_bin_count, &r->geo[0].d_bin_slots, &r->geo[1].d_bin_count, &r->geo[1].d_bin_slots, &r->geo[2].d_bin_count, &r->geo[2].d_bin_slots, &r->d_geo_counters, &r->d_stage, &r->tables[0].d, &r->tables[1].d};
     for (PassTables &T : r->tables) { if (T.h) (void)hipHostFree(T.h); if (T.copied) (void)hipEventDestroy(T.copied); }
@@ -784,7 +793,7 @@ int arctic_flush(ArcticRenderer *r) {
     int rc = select_device(r);
     if (rc) return rc;
     HIPCHECK(r, hipStreamSynchronize(r->stream));
-    HIPCHECK(r, hipStreamSynchronize(r->prepass_stream));   // (joined into the main stream by every frame; after a failed frame they may not be)
+    for (hipStream_t ps : r->prepass_stream) HIPCHECK(r, hipStreamSynchronize(ps));   // (joined into the main stream by every frame; after a failed frame they may not be)
     HIPCHECK(r, hipStreamSynchronize(r->shadow_stream));
     if (r->comm_stream) HIPCHECK(r, hipStreamSynchronize(r->comm_stream));
     if (int ov = check_item_overflow(r)) return ov;
@@ -984,12 +993,13 @@ int arctic_render_frame_device(ArcticRenderer *r, const ArcticScene *scene, cons
     if (in_flight) {
         HIPCHECK(r, hipEventRecord(r->ev_released[r->cur], r->stream));   // everything that reads or writes the set being left is enqueued by now
         r->released_valid[r->cur] = true;
-        r->cur ^= 1;
+        r->cur = (r->cur + 1) % r->frames_in_flight;
         r->have_vis = r->have_gbuffer = false;                            // of the set entered: overwritten now
-        if (r->released_valid[r->cur]) HIPCHECK(r, hipStreamWaitEvent(r->prepass_stream, r->ev_released[r->cur], 0));
-        rc = pass_visibility(r, scene, r->prepass_stream);
-        HIPCHECK(r, hipEventRecord(r->ev_prepass, r->prepass_stream));
-        HIPCHECK(r, hipStreamWaitEvent(r->stream, r->ev_prepass, 0));
+        const int turn = r->prepass_turn ^= 1;                            // consecutive prepasses on alternate streams: with three sets they overlap
+        if (r->released_valid[r->cur]) HIPCHECK(r, hipStreamWaitEvent(r->prepass_stream[turn], r->ev_released[r->cur], 0));
+        rc = pass_visibility(r, scene, r->prepass_stream[turn]);
+        HIPCHECK(r, hipEventRecord(r->ev_prepass[turn], r->prepass_stream[turn]));
+        HIPCHECK(r, hipStreamWaitEvent(r->stream, r->ev_prepass[turn], 0));
     } else rc = vis_path ? pass_visibility(r, scene, r->stream) : pass_gbuffer(r, scene);
     if (beside) HIPCHECK(r, hipStreamWaitEvent(r->stream, r->ev_shadow, 0));   // the map and its table are complete
     if (rc != ARCTIC_OK) return rc;
@@ -1232,7 +1242,15 @@ int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value) {
     case ARCTIC_OPT_HDR16: r->hdr16 = value != 0; break;
     case ARCTIC_OPT_VISBUFFER: r->visbuffer = value != 0; break;
     case ARCTIC_OPT_FRAMES_IN_FLIGHT:
-        if (value < 1 || value > 2) return r->fail(ARCTIC_E_INVALID, "set_option: frames in flight must be 1 or 2");
+        if (value < 0 || value > 3) return r->fail(ARCTIC_E_INVALID, "set_option: frames in flight must be 0 (the library's choice), 1, 2 or 3");
+        r->frames_in_flight_opt = (int)value;
+        if (value == 0) value = (uint64_t)r->rows() * r->width < 3000000ull ? 3 : 2;
+        if ((int)value != r->frames_in_flight) {   // the sets change roles: nothing may be in flight, and `cur` must name a set that exists
+            HIPCHECK(r, hipStreamSynchronize(r->stream));
+            for (hipStream_t ps : r->prepass_stream) HIPCHECK(r, hipStreamSynchronize(ps));
+            if (r->cur >= (int)value) { r->cur = 0; r->have_vis = r->have_gbuffer = false; }
+            r->released_valid[0] = r->released_valid[1] = r->released_valid[2] = false;
+        }
         r->frames_in_flight = (int)value;
         break;
     case ARCTIC_OPT_MARKERS:
@@ -1245,7 +1263,7 @@ int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value) {
         break;
     case ARCTIC_OPT_ITEM_TABLE_FLOOR:
         if (value < 64 || value > 0x7FFFFFF0ll) return r->fail(ARCTIC_E_INVALID, "set_option: item table floor out of range");
-        r->item_cap_floor = (uint32_t)value; r->geo[0].item_cap = r->geo[1].item_cap = r->geo[2].item_cap = 0;
+        r->item_cap_floor = (uint32_t)value; r->geo[0].item_cap = r->geo[1].item_cap = r->geo[2].item_cap = r->geo[3].item_cap = 0;
         break;
     case ARCTIC_OPT_TILES_PER_WAVE:
         if (value < 0 || value > 64) return r->fail(ARCTIC_E_INVALID, "set_option: tiles per wave must be 0 (default) .. 64");

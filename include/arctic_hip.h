@@ -274,9 +274,10 @@ int arctic_stats(ArcticRenderer *r, uint64_t *out, uint32_t n);
                                         R16G16B16A16_FLOAT colour target (forward_pass.cpp:149, renderer.cpp:128-144); default 0 = fp32 */
 #define ARCTIC_OPT_SHADOW_CACHE      9 /* 1 (default) = arctic_render_frame redraws the shadow map only when the sun, the objects or the mesh list changed
                                           (byte-compared); 0 = every frame like the reference (renderer.cpp:300-337).  Same image either way. */
-#define ARCTIC_OPT_FRAMES_IN_FLIGHT  15 /* 2 (default) = arctic_render_frame runs the visibility prepass of a frame on a second stream, into a second set of
-                                          tables (and, when the shadow map is redrawn, into a second map), beside the shading of the frame before it (the reference keeps
-                                          3 frames in flight, rhi.hpp:25); every call
+#define ARCTIC_OPT_FRAMES_IN_FLIGHT  15 /* 2 = arctic_render_frame runs the visibility prepass of a frame on a second stream, into a second set of
+                                          tables (and, when the shadow map is redrawn, into a second map), beside the shading of the frame before it; 3 (what the
+                                          reference keeps, rhi.hpp:25) = three sets, consecutive prepasses on two streams, so that two prepasses overlap as well -- for
+                                          small targets, whose prepass is the longer chain; 0 (default) = the library's choice: 3 below 3 Mpx, 2 above; every call
                                           still enqueues one whole frame and the output is complete after arctic_flush / in stream order on the main
                                           stream.  1 = one frame at a time on one stream.  Same images. */
 #define ARCTIC_OPT_VISBUFFER        10 /* 1 (default) = arctic_render_frame shades straight from the visibility plane, no 76 B/px G-buffer round trip

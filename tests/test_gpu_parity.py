@@ -382,8 +382,10 @@ def test_render_frame_redraws_the_shadow_map_only_when_its_inputs_change(pkg, or
     cached.close(); plain.close(); serial.close(); o.close()
 
 
-def test_frames_in_flight_give_the_same_frames(pkg, oracle, hip):
-    """ARCTIC_OPT_FRAMES_IN_FLIGHT = 2 (default): the visibility prepass of a frame runs on its own stream, into the other set of
+@pytest.mark.parametrize("in_flight", [2, 3])
+def test_frames_in_flight_give_the_same_frames(pkg, oracle, hip, in_flight):
+    """ARCTIC_OPT_FRAMES_IN_FLIGHT = 2 (default) or 3 (the reference's count, rhi.hpp:25: three sets, consecutive prepasses on two
+    streams): the visibility prepass of a frame runs on its own stream, into the other set of
     tables (and, when the map is redrawn, the other shadow map), beside the shading of the frame before.  A run of frames whose camera
     moves every frame and whose objects and sun move now and then -- each frame enqueued without waiting for the one before -- must equal the same run with one frame at a time, byte for
     byte, also with pass-level calls (which see the latest frame's set) and G-buffer read-backs in between."""
@@ -391,6 +393,7 @@ def test_frames_in_flight_give_the_same_frames(pkg, oracle, hip):
     import torch
     sc = pkg.scenes.config3(scale=0.25)
     two = sc.upload(hip.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights))
+    two.set_option("frames_in_flight", in_flight)
     one = sc.upload(hip.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights))
     one.set_option("frames_in_flight", 1)
     n = 12
