@@ -711,10 +711,13 @@ ArcticRenderer *arctic_create(const ArcticCreateInfo *info, char *err, uint64_t 
     if ((e = hipEventCreateWithFlags(&r->ev_fork, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&r->ev_shadow, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&r->ev_shadow_scratch, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
-    for (int k = 0; k < 2; ++k) {
-        if ((e = hipStreamCreateWithFlags(&r->prepass_stream[k], hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    // The HIP runtime deals its hardware queues (4 by default, GPU_MAX_HW_QUEUES) to streams in the order they are created, and two
+    // streams on one queue do not overlap: the handle's own stream, the shadow stream and the first prepass stream are created here, in
+    // that order (with a caller's stream that makes four); the second prepass stream, which only three frames in flight use, is the
+    // handle's own stream when the caller brought one (it is idle then), else created when first needed (second_prepass_stream)
+    if ((e = hipStreamCreateWithFlags(&r->prepass_stream[0], hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    for (int k = 0; k < 2; ++k)
         if ((e = hipEventCreateWithFlags(&r->ev_prepass[k], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
-    }
     for (hipEvent_t &ev : r->ev_released)
         if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     for (hipEvent_t &ev : r->ev_shadow_released)
@@ -793,7 +796,8 @@ int arctic_flush(ArcticRenderer *r) {
     int rc = select_device(r);
     if (rc) return rc;
     HIPCHECK(r, hipStreamSynchronize(r->stream));
-    for (hipStream_t ps : r->prepass_stream) HIPCHECK(r, hipStreamSynchronize(ps));   // (joined into the main stream by every frame; after a failed frame they may not be)
+    for (hipStream_t ps : r->prepass_stream) if (ps) HIPCHECK(r, hipStreamSynchronize(ps));   // (joined into the main stream by every frame; after a failed frame they may not be)
+    if (r->stream != r->own_stream) HIPCHECK(r, hipStreamSynchronize(r->own_stream));        // (the second prepass stream of a handle on a caller's stream)
     HIPCHECK(r, hipStreamSynchronize(r->shadow_stream));
     if (r->comm_stream) HIPCHECK(r, hipStreamSynchronize(r->comm_stream));
     if (int ov = check_item_overflow(r)) return ov;
@@ -805,6 +809,7 @@ int arctic_set_stream(ArcticRenderer *r, void *hip_stream) {
     int rc = select_device(r);
     if (rc) return rc;
     HIPCHECK(r, hipStreamSynchronize(r->stream));
+    HIPCHECK(r, hipStreamSynchronize(r->own_stream));   // (it may be the second prepass stream of the frames in flight)
     r->stream = static_cast<hipStream_t>(hip_stream);   // NULL = the default stream
     return ARCTIC_OK;
 }
@@ -814,6 +819,7 @@ int arctic_use_own_stream(ArcticRenderer *r) {
     int rc = select_device(r);
     if (rc) return rc;
     HIPCHECK(r, hipStreamSynchronize(r->stream));
+    HIPCHECK(r, hipStreamSynchronize(r->own_stream));
     r->stream = r->own_stream;
     return ARCTIC_OK;
 }
@@ -995,10 +1001,16 @@ int arctic_render_frame_device(ArcticRenderer *r, const ArcticScene *scene, cons
         r->released_valid[r->cur] = true;
         r->cur = (r->cur + 1) % r->frames_in_flight;
         r->have_vis = r->have_gbuffer = false;                            // of the set entered: overwritten now
-        const int turn = r->prepass_turn ^= 1;                            // consecutive prepasses on alternate streams: with three sets they overlap
-        if (r->released_valid[r->cur]) HIPCHECK(r, hipStreamWaitEvent(r->prepass_stream[turn], r->ev_released[r->cur], 0));
-        rc = pass_visibility(r, scene, r->prepass_stream[turn]);
-        HIPCHECK(r, hipEventRecord(r->ev_prepass[turn], r->prepass_stream[turn]));
+        // consecutive prepasses on alternate streams when there are three sets (they overlap then); with two, one stream as before
+        const int turn = r->frames_in_flight >= 3 ? (r->prepass_turn ^= 1) : 0;
+        hipStream_t ps = r->prepass_stream[0];
+        if (turn) {
+            if (r->stream != r->own_stream) ps = r->own_stream;
+            else { if (!r->prepass_stream[1]) HIPCHECK(r, hipStreamCreateWithFlags(&r->prepass_stream[1], hipStreamNonBlocking)); ps = r->prepass_stream[1]; }
+        }
+        if (r->released_valid[r->cur]) HIPCHECK(r, hipStreamWaitEvent(ps, r->ev_released[r->cur], 0));
+        rc = pass_visibility(r, scene, ps);
+        HIPCHECK(r, hipEventRecord(r->ev_prepass[turn], ps));
         HIPCHECK(r, hipStreamWaitEvent(r->stream, r->ev_prepass[turn], 0));
     } else rc = vis_path ? pass_visibility(r, scene, r->stream) : pass_gbuffer(r, scene);
     if (beside) HIPCHECK(r, hipStreamWaitEvent(r->stream, r->ev_shadow, 0));   // the map and its table are complete
@@ -1247,7 +1259,8 @@ int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value) {
         if (value == 0) value = (uint64_t)r->rows() * r->width < 3000000ull ? 3 : 2;
         if ((int)value != r->frames_in_flight) {   // the sets change roles: nothing may be in flight, and `cur` must name a set that exists
             HIPCHECK(r, hipStreamSynchronize(r->stream));
-            for (hipStream_t ps : r->prepass_stream) HIPCHECK(r, hipStreamSynchronize(ps));
+            for (hipStream_t ps : r->prepass_stream) if (ps) HIPCHECK(r, hipStreamSynchronize(ps));
+            if (r->stream != r->own_stream) HIPCHECK(r, hipStreamSynchronize(r->own_stream));
             if (r->cur >= (int)value) { r->cur = 0; r->have_vis = r->have_gbuffer = false; }
             r->released_valid[0] = r->released_valid[1] = r->released_valid[2] = false;
         }

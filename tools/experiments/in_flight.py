@@ -3,11 +3,17 @@ usage: python tools/experiments/in_flight.py [config[:scale] ...]"""
 import sys, os, time, copy
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 import __graft_entry__ as e
+TORCH_STREAM = os.environ.get("ARCTIC_USE_TORCH_STREAM") == "1"   # the caller brings its stream (what bench.py does): the handle's own stream is idle
+if TORCH_STREAM:
+    import torch
+    torch.cuda.set_device(0); torch.zeros(1, device="cuda")   # (torch first, as in bench.py)
 pkg = e.load_package()
 for arg in sys.argv[1:] or ("3", "2", "1"):
     cfg, scale = (int(arg.split(":")[0]), float(arg.split(":")[1])) if ":" in arg else (int(arg), 1.0)
     sc = pkg.scenes.CONFIGS[cfg](scale=scale)
     r = sc.upload(pkg.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights))
+    if TORCH_STREAM:
+        r.set_stream(torch.cuda.current_stream().cuda_stream)
     moving = [copy.deepcopy(sc.desc) for _ in range(2)]
     moving[1].sun = dict(moving[1].sun, rotation=(moving[1].sun["rotation"][0] - 1.5, moving[1].sun["rotation"][1] + 4.0))
     def timed(fn, n):
