@@ -220,6 +220,7 @@ struct ArcticRenderer {
     Rccl::Comm comm = nullptr;
     int comm_rank = 0, comm_world = 1;
     hipStream_t comm_stream = nullptr;
+    bool comm_stream_borrowed = false;   // the communication stream is the handle's own stream, idle because the caller brought its stream (one stream -- one hardware queue -- fewer)
     hipEvent_t ev_main = nullptr;
     struct InFlight { const void *ptr = nullptr; hipEvent_t done = nullptr; } inflight[4];   // gathers that still read a shard buffer
     std::vector<uint32_t> peer_rows, peer_ranges;    // rows of every rank's shard; [begin, end) of every rank (row-range shards)
@@ -1423,7 +1424,11 @@ int arctic_comm_init(ArcticRenderer *r, const void *id_bytes, int rank, int worl
     // handle is never left half initialised (comm set, no layout) and arctic_comm_init can be called again.
     DevBuf tmp;
     const auto finish = [&]() -> int {
-        if (!r->comm_stream) HIPCHECK(r, hipStreamCreateWithFlags(&r->comm_stream, hipStreamNonBlocking));
+        if (!r->comm_stream) {
+            // (the runtime deals few hardware queues to many streams, and two streams on one queue do not overlap: DESIGN.md 4.3)
+            if (r->stream != r->own_stream) { r->comm_stream = r->own_stream; r->comm_stream_borrowed = true; }
+            else HIPCHECK(r, hipStreamCreateWithFlags(&r->comm_stream, hipStreamNonBlocking));
+        }
         if (!r->ev_main) HIPCHECK(r, hipEventCreateWithFlags(&r->ev_main, hipEventDisableTiming));
         for (auto &f : r->inflight) if (!f.done) HIPCHECK(r, hipEventCreateWithFlags(&f.done, hipEventDisableTiming));
         // every rank's shard layout: {row_begin, row_end, rows, band_rows} all-gathered once (the root places shards of unequal size)
@@ -1456,7 +1461,7 @@ int arctic_comm_destroy(ArcticRenderer *r) {
     if (r->layout_from_comm) { r->layout_world = 0; r->layout_from_comm = false; }
     for (auto &f : r->inflight) { if (f.done) (void)hipEventDestroy(f.done); f.done = nullptr; f.ptr = nullptr; }
     if (r->ev_main) { (void)hipEventDestroy(r->ev_main); r->ev_main = nullptr; }
-    if (r->comm_stream) { (void)hipStreamDestroy(r->comm_stream); r->comm_stream = nullptr; }
+    if (r->comm_stream) { if (!r->comm_stream_borrowed) (void)hipStreamDestroy(r->comm_stream); r->comm_stream = nullptr; r->comm_stream_borrowed = false; }
     return ARCTIC_OK;
 }
 

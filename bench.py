@@ -181,6 +181,9 @@ def main():
         r = sc.upload(pkg.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights, device=local, band_rows=BAND, shard=(rank, world)))
     else:
         r = sc.upload(pkg.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights, device=local))
+    # the library launches on torch's stream (torch events see its kernels) -- set before the communicator is made: the exchange then
+    # runs on the handle's own stream, idle from here on, instead of a stream more (hardware queues are few: DESIGN.md 4.3)
+    r.set_stream(torch.cuda.current_stream().cuda_stream)
     cabi = False
     if world > 1 and backend == "nccl" and os.environ.get("ARCTIC_BENCH_EXCHANGE", "cabi") == "cabi":
         # The exchange below Python: an RCCL communicator owned by the handle; the 128-byte id travels over torch.distributed.

@@ -70,10 +70,14 @@ def test_assemble_row_ranges(scene, hip, full_frame):
     r.close()
 
 
-def test_one_rank_communicator_end_to_end(scene, hip, full_frame):
+@pytest.mark.parametrize("callers_stream", [False, True], ids=["own-stream", "callers-stream"])
+def test_one_rank_communicator_end_to_end(scene, hip, full_frame, callers_stream):
+    """(callers-stream: the host brings its stream, as bench.py does: the exchange then runs on the handle's own, idle stream)"""
     import torch
     sc = scene
     r = sc.upload(hip.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights, band_rows=16, shard=(0, 1)))
+    if callers_stream:
+        r.set_stream(torch.cuda.current_stream().cuda_stream)
     with pytest.raises(hip.ArcticError):
         r.gather_frame(None, 1, 0)                       # no communicator yet
     uid = hip.Renderer.comm_unique_id()
