@@ -1,5 +1,7 @@
 """Edge cases through the C-ABI (GPU): empty and degenerate inputs, extreme sizes, ragged frames -- each still compared
 with the oracle under the same bars as tests/test_gpu_parity.py."""
+import copy
+
 import numpy as np
 import pytest
 
@@ -263,3 +265,25 @@ def test_tiles_per_wave_is_placement_only(pkg, hip, scale):
         np.testing.assert_array_equal(frame, outs[0][0])
         np.testing.assert_array_equal(passed, outs[0][1])
     np.testing.assert_array_equal(outs[0][0], outs[0][1])
+
+
+def test_resize_across_the_librarys_thresholds(pkg, hip):
+    """Renderer::resize (renderer.hpp:116): one handle taken through sizes on either side of the library's own switches -- block
+    owners in the forward raster from 4 Mpx, three frames in flight and one tile per wave below 3 Mpx -- renders, after every
+    resize, what a fresh handle of that size renders; frames are enqueued back to back (in flight) before each comparison."""
+    sc = pkg.scenes.config3(scale=0.25)
+    sizes = [(960, 536), (2560, 1600), (640, 360), (2048, 1200), (960, 536)]      # 0.5, 4.1, 0.2, 2.5, 0.5 Mpx
+    r = sc.upload(hip.Renderer(*sizes[0], sc.shadow_size, sc.max_lights))
+    for w, h in sizes:
+        r.resize(w, h)
+        d = copy.deepcopy(sc.desc)
+        d.camera["aspect"] = w / h
+        for k in range(4):
+            d.camera["rotation"] = (-15.0 + k, 7.0 * k)
+            img = r.render_frame(d, sc.settings)
+        fresh = sc.upload(hip.Renderer(w, h, sc.shadow_size, sc.max_lights))
+        np.testing.assert_array_equal(img, fresh.render_frame(d, sc.settings))
+        for a, b in zip(r.read_gbuffer(), fresh.read_gbuffer()):
+            np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+        fresh.close()
+    r.close()
