@@ -316,11 +316,11 @@ def main():
         step()
     ev1.record()
     drain()
-    r.flush()
-    torch.cuda.synchronize()
+    torch.cuda.synchronize()   # (every stream of the device: the library's too)
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t_start
+    r.flush()                  # the library's own synchronising call reports what a pass may have flagged (outside the timed region: it adds nothing to wait for)
     kernel_ms = ev0.elapsed_time(ev1) / args.steps   # HIP events on the launch stream around the K timed launches
     kernel_ms_source = "HIP events on the launch stream around the K timed steps / K"
     if world > 1:   # there the span between the events includes the waits for the gathers that free the shard buffers: not kernel time
