@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stddef.h>
 
 namespace arctic {
 
@@ -199,35 +200,56 @@ static_assert(sizeof(TexDesc) == 32, "TexDesc layout (tex_desc loads it with one
 constexpr uint32_t TEX_INTERLEAVED = 0x80000000u;
 
 // point light as uploaded (scene.hpp:88-94): float3 pos, pad, float3 color, pad = 2 x float4
+// The kernels' argument block.  The fields are ordered by WHEN a wave of k_material needs them, in 64-byte blocks, so that each
+// phase of a tile is ONE batch of scalar loads behind one wait (shade.hip: args_a / args_b / args_c / args_d) instead of a scalar-cache
+// round trip per field at its point of use:
+//   block A  before a tile's first bytes can be asked for: the G-buffer planes, the tile grid, the dispatch order
+//   block B  while those bytes are in flight: what turns them into texel and shadow-table addresses, and the target
+//   block C  while the texels are in flight: the epilogue's constants, the lit pixels' constants
+//   block D  lit tiles only: sun, light list
+// Everything behind block D is read at its point of use (cold paths: general tile, skybox, statistics, visibility plane).
 struct ShadeParams {
-    GBuffer g;
-    const TexDesc *tex;          // 3 * n_materials
+    // ---- block A, byte 0
+    GBuffer g;                   // 5 plane pointers
+    uint32_t tiles_x, tiles_y;   // tile grid of the shard
+    uint32_t tiles_per_wave;     // tiles a wave of k_material shades one after the other (filled by launch_shade)
+    uint32_t group_stride;       // ... 8 * group_stride tile rows apart: ceil(groups of 8 tile rows / tiles_per_wave) (filled by launch_shade)
+    int32_t debug;               // timing experiments only: 1 skip material textures, 2 skip shadow test, ... (ARCTIC_OPT_DEBUG)
     uint32_t n_materials;
-    const float *srgb_lut;       // 256 floats, sRGB8 -> linear
-    const float *shadow_map;     // S*S floats row-major, or null
-    uint32_t shadow_size;
+    // ---- block B, byte 64
+    const TexDesc *tex;          // 3 * n_materials
     const float2 *shadow_bounds; // conservative (min, max) of the map per 4x4-aligned 8x8 texel block (k_shadow_bounds), or null
+    const float *shadow_map;     // S*S floats row-major, or null
+    uint8_t *out_rgba8;          // rows*width*4, row-major
+    uint32_t shadow_size;
     uint32_t bounds_pitch;       // entries per row of shadow_bounds = shadow_bounds_pitch(S)
-    const float4 *lights;        // 2 float4 per light
-    const float4 *light_pairs;   // the same lights as pairs, 3 float4 per pair {x0,x1,y0,y1} {z0,z1,r0,r1} {g0,g1,b0,b1}; an odd count is padded with a black light
-    uint32_t n_lights;
-    float eye[3];
-    float sun_dir[3];
-    float sun_color[3];
-    float ambient;
-    int32_t tm_method;
-    float inv_gamma;
-    float exposure;
     uint32_t width;              // frame width in pixels
     uint32_t rows;               // rows of this shard
     uint32_t row0_in_tile;       // row_begin - tile_y0*8: offset of the shard's first row inside its first tile row
-    uint32_t tiles_x, tiles_y;   // tile grid of the shard
-    uint8_t *out_rgba8;          // rows*width*4, row-major
+    int32_t culling;
+    int32_t hdr16;               // 1: round ps_main's colour through binary16 like the reference's RGBA16F target
+    int32_t tm_method;
+    // ---- block C, byte 128
+    float ambient;
+    float inv_gamma;
+    float exposure;
+    uint32_t pad_c0;
     float *out_ldr;              // optional rows*width*3
     float *out_hdr;              // optional rows*width*3
+    float eye[3];                // (byte 160: from here to the end of block D is what a lit tile loads in one batch)
+    uint32_t n_lights;
+    const float4 *light_pairs;   // the lights as pairs, 3 float4 per pair {x0,x1,y0,y1} {z0,z1,r0,r1} {g0,g1,b0,b1}; an odd count is padded with a black light
+    const float4 *lights;        // 2 float4 per light, as uploaded
+    // ---- block D, byte 192
+    float sun_dir[3];
+    uint32_t pad_d0;
+    float sun_color[3];
+    uint32_t pad_d1;
+    // ---- the rest: read at the point of use
+    const float *srgb_lut;       // 256 floats, sRGB8 -> linear
     unsigned long long *stats;   // STATS kernels only: [0] point-light evaluations, [1] lit pixels, [2] evaluations with n.wi > 0,
                                  // [3] (tile, light) pairs with n.wi <= 0 in every lit lane, [4] tiles with a lit pixel
-    int32_t culling;
+    unsigned long long *trace;   // ARCTIC_OPT_TILE_TRACE: 4 x u64 per tile (shade.hip: trace_end), or null
     // whole frames without a G-buffer (k_material_vis): the visibility plane and what the prepass left behind
     const unsigned long long *vis; const SetupRec *recs; const RasterRec *rrecs; const uint32_t *rec_of; const ObjectRec *objs; const XVert *xv;
     // skybox (skybox.hlsl:61-90): environment map for pixels without geometry; env == null -> black
@@ -236,12 +258,10 @@ struct ShadeParams {
     float sky_fwd[3], sky_right[3], sky_up[3];   // ray through ndc (x,y) = fwd + x*right + y*up (right/up scaled by the frustum)
     float ndc_sx, ndc_sy;               // 2/width, 2/height of the whole frame
     int32_t band_tiles, shard_index, shard_count, tile_y0;   // local tile row -> global row (see row_global)
-    int32_t hdr16;                      // 1: round ps_main's colour through binary16 like the reference's RGBA16F target
     int32_t compact_tables;             // 1: the record, vertex and object tables are below 4 GiB each: k_material_vis addresses them with 32-bit byte offsets
-    int32_t debug;                      // timing experiments only: 1 skip material textures, 2 skip shadow test
-    unsigned long long *trace;          // ARCTIC_OPT_TILE_TRACE: 4 x u64 per tile (shade.hip: trace_end), or null
-    uint32_t tiles_per_wave;            // tiles a wave of k_material shades one after the other (filled by launch_shade)
 };
+static_assert(offsetof(ShadeParams, tex) == 64 && offsetof(ShadeParams, ambient) == 128 && offsetof(ShadeParams, sun_dir) == 192 &&
+              offsetof(ShadeParams, srgb_lut) == 224, "ShadeParams: the blocks k_material loads in one batch each");
 struct ShadeLaunch {
     hipStream_t stream;
     uint32_t loop;       // 1: scalar light loop; 2: two lights at a time in packed fp32 (both read the lights through the scalar cache)

@@ -589,7 +589,7 @@ int fill_shade_params(ArcticRenderer *r, const ArcticScene *sc, const ArcticSett
         sp.trace = r->d_tile_trace.as<unsigned long long>();
     }
     sp.culling = r->culling;
-    sp.debug = r->debug;
+    sp.debug = r->debug | (sp.trace ? (1 << 30) : 0);   // bit 30: the kernels learn of the trace from the first block of their arguments
     sp.hdr16 = r->hdr16;
     sp.env = r->env_w ? r->d_env.as<float4>() : nullptr; sp.env_w = r->env_w; sp.env_h = r->env_h;
     camera_sky_basis(sc->camera.rotation, sc->camera.aspect, sc->camera.fov_y, sp.sky_fwd, sp.sky_right, sp.sky_up);

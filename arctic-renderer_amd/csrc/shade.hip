@@ -43,6 +43,57 @@ namespace {
 typedef const ShadeParams __attribute__((address_space(4))) &SP;
 typedef const ShadeParams __attribute__((address_space(4))) *KernArgs;
 
+// The argument block in BATCHES (round 4).  Read field by field at the point of use, a tile's wave paid a scalar-cache round trip per
+// field -- some twenty of them one after the other, five between the arrival of the tile's first bytes and the texel loads that depend
+// on them.  ShadeParams is laid out in the order a tile needs its fields (common.h), each phase reads its block into registers at ONE
+// place, behind the vector loads of the phase before, and an empty asm statement that "modifies" all of them pins them there: the
+// compiler merges the adjacent scalar loads and waits once, in the shadow of memory traffic that is in flight anyway.
+struct ArgsA { const float4 *ga; const float *gb; uint32_t tiles_x, tiles_y, T, stride; int32_t debug; uint32_t n_materials; };
+__device__ __forceinline__ ArgsA args_a(KernArgs a) {   // before a tile's first bytes can be asked for
+    ArgsA r = {a->g.a, a->g.b, a->tiles_x, a->tiles_y, a->tiles_per_wave, a->group_stride, a->debug, a->n_materials};
+    asm volatile("" : "+s"(r.ga), "+s"(r.gb), "+s"(r.tiles_x), "+s"(r.tiles_y), "+s"(r.T), "+s"(r.stride), "+s"(r.debug), "+s"(r.n_materials));
+    return r;
+}
+// ... and, for a wave's first tile, two more pointers in the same batch: the sRGB table, and the visibility plane (k_material_vis)
+__device__ __forceinline__ ArgsA args_a_first(KernArgs a, const float *&srgb_lut, const unsigned long long *&vis) {
+    ArgsA r = {a->g.a, a->g.b, a->tiles_x, a->tiles_y, a->tiles_per_wave, a->group_stride, a->debug, a->n_materials};
+    srgb_lut = a->srgb_lut; vis = a->vis;
+    asm volatile("" : "+s"(r.ga), "+s"(r.gb), "+s"(r.tiles_x), "+s"(r.tiles_y), "+s"(r.T), "+s"(r.stride), "+s"(r.debug), "+s"(r.n_materials), "+s"(srgb_lut), "+s"(vis));
+    return r;
+}
+constexpr int32_t DEBUG_TRACE = 1 << 30;   // ShadeParams::debug: the host asked for a tile trace (ShadeParams::trace is set)
+struct ShadowArgs { const float *map; const float2 *bounds; uint32_t S, pitch; };   // calculate_shadow's inputs
+struct ArgsB { const TexDesc *tex; ShadowArgs sh; uint8_t *out; uint32_t width, rows, row0_in_tile; int32_t culling, hdr16, tm; };
+__device__ __forceinline__ ArgsB args_b(KernArgs a) {   // while the head of the tile is in flight
+    ArgsB r = {a->tex, {a->shadow_map, a->shadow_bounds, a->shadow_size, a->bounds_pitch}, a->out_rgba8, a->width, a->rows, a->row0_in_tile, a->culling, a->hdr16, a->tm_method};
+    asm volatile("" : "+s"(r.tex), "+s"(r.sh.map), "+s"(r.sh.bounds), "+s"(r.sh.S), "+s"(r.sh.pitch), "+s"(r.out), "+s"(r.width), "+s"(r.rows),
+                 "+s"(r.row0_in_tile), "+s"(r.culling), "+s"(r.hdr16), "+s"(r.tm));
+    return r;
+}
+// what post_process + the store need (store_pixel)
+struct StoreArgs { int32_t hdr16, debug, tm; float exposure, inv_gamma; float *out_ldr, *out_hdr; };
+struct ArgsC { float ambient; StoreArgs st; const float4 *gc, *gd, *ge; };
+__device__ __forceinline__ ArgsC args_c(KernArgs a, const ArgsA &A, const ArgsB &B) {   // while the texels and the shadow-table entry are in flight
+    ArgsC r = {a->ambient, {B.hdr16, A.debug, B.tm, a->exposure, a->inv_gamma, a->out_ldr, a->out_hdr}, a->g.c, a->g.d, a->g.e};
+    asm volatile("" : "+s"(r.ambient), "+s"(r.st.exposure), "+s"(r.st.inv_gamma), "+s"(r.st.out_ldr), "+s"(r.st.out_hdr), "+s"(r.gc), "+s"(r.gd), "+s"(r.ge));
+    return r;
+}
+__device__ __forceinline__ ShadowArgs shadow_args(SP sp) { ShadowArgs r = {sp.shadow_map, sp.shadow_bounds, sp.shadow_size, sp.bounds_pitch}; return r; }
+__device__ __forceinline__ StoreArgs store_args(SP sp) { StoreArgs r = {sp.hdr16, sp.debug, sp.tm_method, sp.exposure, sp.inv_gamma, sp.out_ldr, sp.out_hdr}; return r; }
+// the lit pixels' constants: eye and the light list (in front of the light loop), the sun (where it is evaluated: behind the packed loop)
+struct LightArgs { float eye[3]; uint32_t n_lights; const float4 *pairs, *lights; };
+__device__ __forceinline__ LightArgs light_args(SP sp) {
+    LightArgs r = {{sp.eye[0], sp.eye[1], sp.eye[2]}, sp.n_lights, sp.light_pairs, sp.lights};
+    asm volatile("" : "+s"(r.eye[0]), "+s"(r.eye[1]), "+s"(r.eye[2]), "+s"(r.n_lights), "+s"(r.pairs), "+s"(r.lights));
+    return r;
+}
+struct SunArgs { float dir[3], color[3]; };
+__device__ __forceinline__ SunArgs sun_args(SP sp) {
+    SunArgs r = {{sp.sun_dir[0], sp.sun_dir[1], sp.sun_dir[2]}, {sp.sun_color[0], sp.sun_color[1], sp.sun_color[2]}};
+    asm volatile("" : "+s"(r.dir[0]), "+s"(r.dir[1]), "+s"(r.dir[2]), "+s"(r.color[0]), "+s"(r.color[1]), "+s"(r.color[2]));
+    return r;
+}
+
 struct f3 { float x, y, z; };
 __device__ __forceinline__ f3 mk(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
 __device__ __forceinline__ f3 operator+(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
@@ -270,10 +321,10 @@ __device__ __forceinline__ int wave_min_i32(int v) {
     return v;
 }
 // returns true when the wave's undecided lanes were handled here (lit updated); false: the caller takes the register path
-__device__ __forceinline__ bool shadow_lds_tile(SP sp, float *tile /* this wave's SHADOW_TILE^2 floats */, uint32_t lane, bool undecided,
+__device__ __forceinline__ bool shadow_lds_tile(const ShadowArgs &sa, float *tile /* this wave's SHADOW_TILE^2 floats */, uint32_t lane, bool undecided,
                                                 const float px, const float py, const float pz, float &lit) {
 #pragma clang fp contract(off)
-    const uint32_t S = sp.shadow_size;
+    const uint32_t S = sa.S;
     const float Sf = (float)S;
     const int bx = floor_to_int((px + -0.0002f) * Sf - 0.5f), by = floor_to_int((py + -0.0002f) * Sf - 0.5f);
     const int ex = floor_to_int((px + 0.0002f) * Sf - 0.5f) + 1, ey = floor_to_int((py + 0.0002f) * Sf - 0.5f) + 1;   // last texel a tap reads
@@ -287,7 +338,7 @@ __device__ __forceinline__ bool shadow_lds_tile(SP sp, float *tile /* this wave'
     // stage rows y0 .. y1, texels x0 .. x1: two rows per step (lanes 0-31 / 32-63), coalesced along x
     for (int r = (int)(lane >> 5); r < H; r += 2) {
         const int c = (int)(lane & 31);
-        if (c < W) tile[r * SHADOW_TILE + c] = sp.shadow_map[(size_t)(y0 + r) * S + (size_t)(x0 + c)];
+        if (c < W) tile[r * SHADOW_TILE + c] = sa.map[(size_t)(y0 + r) * S + (size_t)(x0 + c)];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // same wave: LDS operations complete in order
     if (undecided) {
@@ -322,32 +373,46 @@ __device__ __forceinline__ void shadow_coords(float lsx, float lsy, float lsz, f
     p.py = 1.0f - p.py;
 }
 // the bounds-table entry that covers all 25 taps of p (byte offset into sp.shadow_bounds), or false: outside the table's reach
-__device__ __forceinline__ bool shadow_table_entry(SP sp, const ShadowPos &p, uint32_t &offset) {
+__device__ __forceinline__ bool shadow_table_entry(const ShadowArgs &sa, const ShadowPos &p, uint32_t &offset) {
 #pragma clang fp contract(off)
     // first texel of tap 0 (u_0 = px - 2e-4) per axis.  0 <= bx < S - 3 means: inside the map with three more texels after it,
     // so 0 < px < 1, no tap wraps, and -- the taps spanning 4e-4 S < 2 texels -- every texel a tap reads lies in [bx, bx + 3]
-    const uint32_t S = sp.shadow_size;
+    const uint32_t S = sa.S;
     const float Sf = (float)S;
     const int bx = floor_to_int((p.px + -0.0002f) * Sf - 0.5f), by = floor_to_int((p.py + -0.0002f) * Sf - 0.5f);
-    offset = (((uint32_t)by >> 2) * sp.bounds_pitch + ((uint32_t)bx >> 2)) * 8u;
+    offset = (((uint32_t)by >> 2) * sa.pitch + ((uint32_t)bx >> 2)) * 8u;
     return (uint32_t)bx < S - 3u && (uint32_t)by < S - 3u && !(p.pz > 1.0f);
 }
-__device__ __forceinline__ bool shadow_quick(SP sp, float lsx, float lsy, float lsz, float lsw, ShadowPos &p, float &lit) {
-    lit = 1.0f;
-    if (sp.shadow_map == nullptr) return true;
+// in two steps, so that a caller can put other work (a batch of scalar loads) between the table load and its use:
+//   shadow_quick_issue   coordinates + the load of the table entry; returns whether the pixel is within the table's reach
+//   shadow_quick_decide  lit = 0 / 1 where the entry (or the map's border rule) decides; false: the pixel needs shadow_slow
+__device__ __forceinline__ bool shadow_quick_issue(const ShadowArgs &sa, float lsx, float lsy, float lsz, float lsw, ShadowPos &p, float2 &mm) {
+    mm = make_float2(0.0f, 0.0f);
+    if (sa.map == nullptr) return false;
     shadow_coords(lsx, lsy, lsz, lsw, p);
     uint32_t offset;
-    if (sp.shadow_bounds != nullptr && shadow_table_entry(sp, p, offset)) {   // (a table only for S <= 4900: shadow_bounds_pitch)
-        const float2 mm = gload_f2(sp.shadow_bounds, offset);
+    const bool in_table = sa.bounds != nullptr && shadow_table_entry(sa, p, offset);   // (a table only for S <= 4900: shadow_bounds_pitch)
+    if (in_table) mm = gload_f2(sa.bounds, offset);
+    return in_table;
+}
+__device__ __forceinline__ bool shadow_quick_decide(const ShadowArgs &sa, bool in_table, const ShadowPos &p, float2 mm, float &lit) {
+    lit = 1.0f;
+    if (sa.map == nullptr) return true;
+    if (in_table) {
         if (p.pz > mm.y) { lit = 0.0f; return true; }
         return !(p.pz > mm.x);
     }
     // outside the map: no shadow (forward.hlsl:75-77); everything else takes the slow path
     return p.pz > 1.0f || p.px < 0.0f || p.py < 0.0f || p.px > 1.0f || p.py > 1.0f;
 }
-__device__ __forceinline__ float shadow_slow(SP sp, const ShadowPos &p) {
-    const uint32_t S = sp.shadow_size;
-    return 1.0f - (S <= 5000u ? shadow_window(sp.shadow_map, S, p.px, p.py, p.pz) : shadow_generic(sp.shadow_map, S, p.px, p.py, p.pz));
+__device__ __forceinline__ bool shadow_quick(const ShadowArgs &sa, float lsx, float lsy, float lsz, float lsw, ShadowPos &p, float &lit) {
+    float2 mm;
+    const bool in_table = shadow_quick_issue(sa, lsx, lsy, lsz, lsw, p, mm);
+    return shadow_quick_decide(sa, in_table, p, mm, lit);
+}
+__device__ __forceinline__ float shadow_slow(const ShadowArgs &sa, const ShadowPos &p) {
+    const uint32_t S = sa.S;
+    return 1.0f - (S <= 5000u ? shadow_window(sa.map, S, p.px, p.py, p.pz) : shadow_generic(sa.map, S, p.px, p.py, p.pz));
 }
 
 // ---- forward.hlsl:126-193 -----------------------------------------------------------------------
@@ -609,10 +674,10 @@ struct TileHead { float4 a; float b0, b1, b2; };   // a = uv.xy, ls.xy; b = ls.z
 typedef float f3v __attribute__((ext_vector_type(3), aligned(4)));
 typedef float f4a __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 gload_f4(const void *base, uint32_t o) { const f4a v = *(const f4a __attribute__((address_space(1))) *)((gchar)base + o); return make_float4(v.x, v.y, v.z, v.w); }
-__device__ __forceinline__ TileHead load_head(SP sp, size_t tile /* wave-uniform */, uint32_t lane) {
+__device__ __forceinline__ TileHead load_head(const float4 *ga, const float *gb, size_t tile /* wave-uniform */, uint32_t lane) {
     TileHead t;
-    t.a = gload_f4(sp.g.a + tile * 64, lane * 16u);
-    const f3v b = *(const f3v __attribute__((address_space(1))) *)((gchar)(sp.g.b + tile * 192) + lane * 12u);
+    t.a = gload_f4(ga + tile * 64, lane * 16u);
+    const f3v b = *(const f3v __attribute__((address_space(1))) *)((gchar)(gb + tile * 192) + lane * 12u);
     t.b0 = b.x; t.b1 = b.y; t.b2 = b.z;
     return t;
 }
@@ -625,22 +690,22 @@ __device__ __forceinline__ float through_half(float x) { return (float)(_Float16
 // or the target itself), o = the pixel's index behind it (32-bit: targets are at most 16384^2 pixels); po = the pixel's index
 // in the whole target, for the optional float planes of the tests.  The uniform options are real branches (an empty volatile asm
 // keeps the compiler from turning them into conversions + selects executed by every pixel).
-__device__ __forceinline__ void store_pixel(SP sp, const uint8_t *out, uint32_t o, uint32_t po, f3 color) {
-    if (sp.hdr16) { asm volatile(""); color = mk(through_half(color.x), through_half(color.y), through_half(color.z)); }
+__device__ __forceinline__ void store_pixel(const StoreArgs &sa, const uint8_t *out, uint32_t o, uint32_t po, f3 color) {
+    if (sa.hdr16) { asm volatile(""); color = mk(through_half(color.x), through_half(color.y), through_half(color.z)); }
     uint32_t word;
     f3 g = mk(0.0f, 0.0f, 0.0f);
-    if (sp.debug & 4) { asm volatile(""); word = rgba8_word(color); }   // bit 2: timing only, no post_process
+    if (sa.debug & 4) { asm volatile(""); word = rgba8_word(color); }   // bit 2: timing only, no post_process
     else {
-        g = gamma_exponent(tonemap(color, sp.tm_method, sp.exposure), sp.inv_gamma);
+        g = gamma_exponent(tonemap(color, sa.tm, sa.exposure), sa.inv_gamma);
         word = rgba8_word_of_exponents(g);
     }
     *(uint32_t __attribute__((address_space(1))) *)((char __attribute__((address_space(1))) *)out + o * 4u) = word;
-    if (sp.out_ldr) {
+    if (sa.out_ldr) {
         asm volatile("");
-        const f3 l = (sp.debug & 4) ? color : mk(__builtin_amdgcn_exp2f(g.x), __builtin_amdgcn_exp2f(g.y), __builtin_amdgcn_exp2f(g.z));
-        sp.out_ldr[(size_t)po * 3] = l.x; sp.out_ldr[(size_t)po * 3 + 1] = l.y; sp.out_ldr[(size_t)po * 3 + 2] = l.z;
+        const f3 l = (sa.debug & 4) ? color : mk(__builtin_amdgcn_exp2f(g.x), __builtin_amdgcn_exp2f(g.y), __builtin_amdgcn_exp2f(g.z));
+        sa.out_ldr[(size_t)po * 3] = l.x; sa.out_ldr[(size_t)po * 3 + 1] = l.y; sa.out_ldr[(size_t)po * 3 + 2] = l.z;
     }
-    if (sp.out_hdr) { asm volatile(""); sp.out_hdr[(size_t)po * 3] = color.x; sp.out_hdr[(size_t)po * 3 + 1] = color.y; sp.out_hdr[(size_t)po * 3 + 2] = color.z; }
+    if (sa.out_hdr) { asm volatile(""); sa.out_hdr[(size_t)po * 3] = color.x; sa.out_hdr[(size_t)po * 3 + 1] = color.y; sa.out_hdr[(size_t)po * 3 + 2] = color.z; }
 }
 
 // ---- skybox.hlsl:61-90: pixels without geometry take the environment map along their view ray --------------------------
@@ -687,7 +752,8 @@ __device__ __forceinline__ f3 lit_radiance(SP sp, uint32_t lane, float nr, float
     const float r = snorm_of_bytes(nr), g = -snorm_of_bytes(ng), b = snorm_of_bytes(nb);   // (1 - g) * 2 - 1 = -(2 g - 1); nr, ng, nb on the 0..255 scale
     const f3 n = normalize(mk(fm(ge.y, b, fm(gd.z, g, gc.w * r)), fm(ge.z, b, fm(gd.w, g, gd.x * r)), fm(ge.w, b, fm(ge.x, g, gd.y * r))));
     const f3 world = mk(gc.x, gc.y, gc.z);
-    const f3 wo = normalize(mk(sp.eye[0], sp.eye[1], sp.eye[2]) - world);
+    const LightArgs la = light_args(sp);   // one batch of scalar loads, in the shadow of the tile's second wave of vector loads
+    const f3 wo = normalize(mk(la.eye[0], la.eye[1], la.eye[2]) - world);
     // metalness is only needed after the light loop; left alone the compiler filters it there, and keeps the footprint's texels and
     // weights (12 registers) alive through the loop for it.  The empty asm pins the filtered value in front of the loop.
     asm volatile("" : "+v"(metal));
@@ -699,16 +765,17 @@ __device__ __forceinline__ f3 lit_radiance(SP sp, uint32_t lane, float nr, float
     if (LOOP == 1) {
         Sums S;
         {   // the sun: wi = -sun_dir, radiance = sun_color (forward.hlsl:221-222)
-            const f3 d = mk(-sp.sun_dir[0], -sp.sun_dir[1], -sp.sun_dir[2]);
+            const SunArgs sun = sun_args(sp);
+            const f3 d = mk(-sun.dir[0], -sun.dir[1], -sun.dir[2]);
             float s1, s2, s3;
             light_scalars<false>(px, d, dot(n, d), s1, s2, s3);
-            for (int k = 0; k < 3; ++k) { S.a[k] = sp.sun_color[k] * s1; S.b[k] = sp.sun_color[k] * s2; S.c[k] = sp.sun_color[k] * s3; }
+            for (int k = 0; k < 3; ++k) { S.a[k] = sun.color[k] * s1; S.b[k] = sun.color[k] * s2; S.c[k] = sun.color[k] * s3; }
         }
-        for (uint32_t i = 0; i < sp.n_lights; ++i) {
+        for (uint32_t i = 0; i < la.n_lights; ++i) {
             // wave-uniform, read through the CONSTANT address space: scalar loads whatever the compiler thinks may have written
             // to global memory before (the volatile asm statements above count as writes, and a plain load would then be a vector load)
             typedef const f4v __attribute__((address_space(4))) *const_f4;
-            const f4v lp = ((const_f4)sp.lights)[2 * i], lc = ((const_f4)sp.lights)[2 * i + 1];
+            const f4v lp = ((const_f4)la.lights)[2 * i], lc = ((const_f4)la.lights)[2 * i + 1];
             const f3 dl = mk(lp.x, lp.y, lp.z) - world;
             const float ndl = dot(n, dl);
             if (STATS) { const unsigned long long mk_ = __ballot(ndl > 0.0f); contributing += __popcll(mk_); wave_zero += mk_ == 0ull ? 1 : 0; }
@@ -723,17 +790,17 @@ __device__ __forceinline__ f3 lit_radiance(SP sp, uint32_t lane, float nr, float
     } else {
         Sums2 S;
         for (int k = 0; k < 3; ++k) { S.a[k] = (v2){0.0f, 0.0f}; S.b[k] = (v2){0.0f, 0.0f}; S.c[k] = (v2){0.0f, 0.0f}; }
-        const uint32_t n_pairs = (sp.n_lights + 1) >> 1;
+        const uint32_t n_pairs = (la.n_lights + 1) >> 1;
         const PackedPix pk = pack_pix(px);
         // The light pairs (3 x 16 bytes per pair: {x0,x1,y0,y1} {z0,z1,r0,r1} {g0,g1,b0,b1}) come through the scalar cache into two
         // sets of SGPRs used alternately: the loads of pair p + 1 are issued before pair p is evaluated (one s_waitcnt per pair,
         // hundreds of cycles after its loads).  Written as asm because the compiler's own version addresses every dword separately
         // (40 scalar instructions per trip) and waits right after issuing.
-        const char *lp = reinterpret_cast<const char *>(sp.light_pairs);
+        const char *lp = reinterpret_cast<const char *>(la.pairs);
         auto finish = [&](v2 dx, v2 dy, v2 dz, const f4v &Bq, const f4v &C, uint32_t p) {
             const v2 nd = accumulate_pair(pk, dx, dy, dz, (v2){Bq.z, Bq.w}, (v2){C.x, C.y}, (v2){C.z, C.w}, S);
             if (STATS) {
-                const bool second = 2 * p + 1 < sp.n_lights;
+                const bool second = 2 * p + 1 < la.n_lights;
                 const unsigned long long m0 = __ballot(nd.x > 0.0f), m1 = second ? __ballot(nd.y > 0.0f) : ~0ull;
                 contributing += __popcll(m0) + (second ? __popcll(m1) : 0);
                 wave_zero += (m0 == 0ull ? 1 : 0) + (m1 == 0ull ? 1 : 0);
@@ -756,13 +823,14 @@ __device__ __forceinline__ f3 lit_radiance(SP sp, uint32_t lane, float nr, float
         }
         float A[3], Bs[3], Cs[3];
         {   // the sun joins the sums
-            const f3 d = mk(-sp.sun_dir[0], -sp.sun_dir[1], -sp.sun_dir[2]);
+            const SunArgs sun = sun_args(sp);
+            const f3 d = mk(-sun.dir[0], -sun.dir[1], -sun.dir[2]);
             float s1, s2, s3;
             light_scalars<false>(px, d, dot(n, d), s1, s2, s3);
             for (int k = 0; k < 3; ++k) {
-                A[k] = __builtin_fmaf(sp.sun_color[k], s1, S.a[k].x + S.a[k].y);
-                Bs[k] = __builtin_fmaf(sp.sun_color[k], s2, S.b[k].x + S.b[k].y);
-                Cs[k] = __builtin_fmaf(sp.sun_color[k], s3, S.c[k].x + S.c[k].y);
+                A[k] = __builtin_fmaf(sun.color[k], s1, S.a[k].x + S.a[k].y);
+                Bs[k] = __builtin_fmaf(sun.color[k], s2, S.b[k].x + S.b[k].y);
+                Cs[k] = __builtin_fmaf(sun.color[k], s3, S.c[k].x + S.c[k].y);
             }
         }
         Lo = resolve_sums(tp, A, Bs, Cs);
@@ -770,7 +838,7 @@ __device__ __forceinline__ f3 lit_radiance(SP sp, uint32_t lane, float nr, float
     if (STATS) {
         const unsigned long long active = __ballot(1);
         if (lane == (uint32_t)__ffsll((long long)active) - 1) {
-            atomicAdd(sp.stats, (unsigned long long)__popcll(active) * sp.n_lights);   // point-light evaluations of lit pixels
+            atomicAdd(sp.stats, (unsigned long long)__popcll(active) * la.n_lights);   // point-light evaluations of lit pixels
             atomicAdd(sp.stats + 1, (unsigned long long)__popcll(active));            // lit pixels
             atomicAdd(sp.stats + 2, contributing);                                     // ... of which n.wi > 0
             atomicAdd(sp.stats + 3, wave_zero);                                        // (tile, light) pairs with n.wi <= 0 in every lit lane
@@ -786,37 +854,39 @@ __device__ __forceinline__ f3 lit_radiance(SP sp, uint32_t lane, float nr, float
 // code with wave-uniform branches only -- material descriptor in SGPRs, the footprint as two 16-byte loads, the RGBA8 target
 // addressed from a scalar base -- except for the lit pixels' part.  Returns false, having stored nothing, when the tile is not of
 // that kind (decided wave-wide; the texel loads already issued are then dropped): the caller shades it with shade_tile.
-// `second(gc, gd, ge)` delivers the lit pixels' remaining attributes (world position + tangent frame, packed like the
+// `second(pc, pd, pe, gc, gd, ge)` delivers the lit pixels' remaining attributes (world position + tangent frame, packed like the
 // G-buffer planes c, d, e): loaded from the G-buffer, or interpolated on the spot by the visibility-buffer kernel.
 template <int LOOP, bool STATS, class Second>
-__device__ __forceinline__ bool shade_tile_fast(SP sp, const float *lut, uint32_t ty, uint32_t tx, uint32_t lane, const TileHead &cur, Second second) {
-    const int32_t row0 = (int32_t)(ty * 8) - (int32_t)sp.row0_in_tile;   // the tile's first pixel row in the target (wave-uniform)
-    if ((sp.debug & (1 | 2 | 4 | 256)) != 0 || tx * 8 + 8 > sp.width || row0 < 0 || row0 + 8 > (int32_t)sp.rows) return false;
-    if (sp.shadow_map != nullptr && sp.shadow_bounds == nullptr) return false;
+__device__ __forceinline__ bool shade_tile_fast(SP sp, KernArgs args, const ArgsA &A, const float *lut, uint32_t ty, uint32_t tx, uint32_t lane, const TileHead &cur, Second second) {
+    const ArgsB B = args_b(args);   // (the head of the tile is in flight)
+    const int32_t row0 = (int32_t)(ty * 8) - (int32_t)B.row0_in_tile;   // the tile's first pixel row in the target (wave-uniform)
+    if ((A.debug & (1 | 2 | 4 | 256)) != 0 || tx * 8 + 8 > B.width || row0 < 0 || row0 + 8 > (int32_t)B.rows) return false;
+    if (B.sh.map != nullptr && B.sh.bounds == nullptr) return false;
     const uint32_t mat = __float_as_uint(cur.b2);
     const uint32_t m0 = __builtin_amdgcn_readfirstlane(mat);
-    if (m0 >= sp.n_materials || __ballot(mat != m0) != 0ull) return false;
-    const TexS d0 = tex_desc(sp.tex, m0 * 3);
+    if (m0 >= A.n_materials || __ballot(mat != m0) != 0ull) return false;
+    const TexS d0 = tex_desc(B.tex, m0 * 3);
     if (!d0.packed) return false;
     // ---- A: material fetch, forward.hlsl:98-124: the two 16-byte texel loads stay in flight over the shadow test
     Taps pt;
     fetch_taps_packed(d0, cur.a.x, cur.a.y, pt);
-    // ---- B: shadow test, forward.hlsl:68-96, from the bounds table alone
-    float lit = 1.0f;
-    {
-        ShadowPos spos;
-        const bool decided = shadow_quick(sp, cur.a.z, cur.a.w, cur.b0, cur.b1, spos, lit);
-        if (__ballot(!decided) != 0ull) return false;   // a tile on a shadow edge (or at the map's border)
-    }
+    // ---- B: shadow test, forward.hlsl:68-96, from the bounds table alone: the entry's load goes out, the next batch of arguments
+    // arrives in its shadow
+    ShadowPos spos;
+    float2 mm;
+    const bool in_table = shadow_quick_issue(B.sh, cur.a.z, cur.a.w, cur.b0, cur.b1, spos, mm);
+    const ArgsC C = args_c(args, A, B);
+    float lit;
+    if (__ballot(!shadow_quick_decide(B.sh, in_table, spos, mm, lit)) != 0ull) return false;   // a tile on a shadow edge (or at the map's border)
     // exact culling: Lo of ps_main is a sum of terms each multiplied by (1 - shadow) (point lights too: forward.hlsl:222,
     // 230), so a fully shadowed pixel is ambient * base and needs neither the sun, nor any point light, nor its normal,
     // tangent frame, position, metalness or roughness.
-    const bool live = sp.culling ? lit != 0.0f : true;
+    const bool live = B.culling ? lit != 0.0f : true;
     float4 gc, gd, ge;
-    if (live) second(gc, gd, ge);   // second wave of loads: lit pixels only (48 B / pixel, whole 128-byte tile rows)
+    if (live) second(C.gc, C.gd, C.ge, gc, gd, ge);   // second wave of loads: lit pixels only (48 B / pixel, whole 128-byte tile rows)
     // ---- C: base colour
     const f3 base = mk(filt_srgb<0>(pt, lut), filt_srgb<1>(pt, lut), filt_srgb<2>(pt, lut));
-    f3 color = base * sp.ambient;
+    f3 color = base * C.ambient;
     // ---- D: the lights
     if (live) {
         const f3 Lo = lit_radiance<LOOP, STATS>(sp, lane, filt_bytes<0, 3>(pt), filt_bytes<1, 0>(pt), filt_bytes<1, 1>(pt),
@@ -825,9 +895,9 @@ __device__ __forceinline__ bool shade_tile_fast(SP sp, const float *lut, uint32_
         color = mk(__builtin_fmaf(Lo.x, lit, color.x), __builtin_fmaf(Lo.y, lit, color.y), __builtin_fmaf(Lo.z, lit, color.z));
     }
     // ---- E: post_process + store: the tile's first pixel is a scalar address, the lane adds (lane >> 3) rows + (lane & 7)
-    const uint32_t tile_px = (uint32_t)row0 * sp.width + tx * 8;
-    const uint32_t o = __umul24(lane >> 3, sp.width) + (lane & 7u);   // (width <= 16384)
-    store_pixel(sp, sp.out_rgba8 + (size_t)tile_px * 4u, o, tile_px + o, color);
+    const uint32_t tile_px = (uint32_t)row0 * B.width + tx * 8;
+    const uint32_t o = __umul24(lane >> 3, B.width) + (lane & 7u);   // (width <= 16384)
+    store_pixel(C.st, B.out + (size_t)tile_px * 4u, o, tile_px + o, color);
     return true;
 }
 
@@ -888,10 +958,11 @@ __device__ __forceinline__ void shade_tile(SP sp, const float *lut, float *shado
     float lit = 1.0f;
     if (!(sp.debug & 2)) {
         ShadowPos spos;
-        const bool decided = !covered || shadow_quick(sp, cur.a.z, cur.a.w, cur.b0, cur.b1, spos, lit);
+        const ShadowArgs sh = shadow_args(sp);
+        const bool decided = !covered || shadow_quick(sh, cur.a.z, cur.a.w, cur.b0, cur.b1, spos, lit);
         if (__ballot(!decided) != 0ull) {   // a tile on a shadow edge (or at the map's border)
-            const bool staged = LDS_SHADOW && sp.shadow_size <= 5000u && shadow_lds_tile(sp, shadow_tile, lane, !decided, spos.px, spos.py, spos.pz, lit);
-            if (!staged && !decided) lit = shadow_slow(sp, spos);
+            const bool staged = LDS_SHADOW && sh.S <= 5000u && shadow_lds_tile(sh, shadow_tile, lane, !decided, spos.px, spos.py, spos.pz, lit);
+            if (!staged && !decided) lit = shadow_slow(sh, spos);
             // the 25-tap path is what sets the kernel's register count: the texels fetched above are dropped across it and
             // fetched again (cache hits; such tiles are few) instead of being kept alive through it
             fetch_material();
@@ -900,7 +971,7 @@ __device__ __forceinline__ void shade_tile(SP sp, const float *lut, float *shado
     // exact culling: see shade_tile_fast
     const bool live = covered && (sp.culling ? lit != 0.0f : true);
     float4 gc, gd, ge;
-    if (live) second(gc, gd, ge);   // second wave of loads: lit pixels only (48 B / pixel, whole 128-byte tile rows)
+    if (live) second(sp.g.c, sp.g.d, sp.g.e, gc, gd, ge);   // second wave of loads: lit pixels only (48 B / pixel, whole 128-byte tile rows)
 
     // ---- C: base colour; pixels without geometry: the skybox -----------------------------------------------------------
     if (covered && !plain) base = mk(filt_srgb<0>(pt, lut), filt_srgb<1>(pt, lut), filt_srgb<2>(pt, lut));
@@ -942,7 +1013,7 @@ __device__ __forceinline__ void shade_tile(SP sp, const float *lut, float *shado
     }
 
     // ---- E: post_process + store ---------------------------------------------------------------------------------------
-    if (in_frame) store_pixel(sp, sp.out_rgba8, o, o, color);
+    if (in_frame) store_pixel(store_args(sp), sp.out_rgba8, o, o, color);
 }
 
 // ARCTIC_OPT_TILE_TRACE (a measuring aid, off by default: one wave-uniform branch at either end of a tile): when and where every tile
@@ -950,14 +1021,14 @@ __device__ __forceinline__ void shade_tile(SP sp, const float *lut, float *shado
 // wave's work, HW_ID | XCC_ID << 32 (which XCD / SE / CU / SIMD / wave slot) | reference-clock ticks between the kernel's entry and the start << 40, and 1 = the fast tile | shader-clock ticks (s_memtime)
 // between start and end << 8.  tools/experiments/tile_trace.py turns it into per-SIMD timelines.
 struct TraceStart { unsigned long long entry, real, core; };
-__device__ __forceinline__ unsigned long long trace_entry(SP sp) { return sp.trace ? __builtin_amdgcn_s_memrealtime() : 0ull; }   // first thing in the kernel
-__device__ __forceinline__ TraceStart trace_begin(SP sp, unsigned long long entry) {   // behind the head loads' wait and the LDS barrier
-    TraceStart t = {entry, 0ull, 0ull};
+__device__ __forceinline__ unsigned long long trace_entry() { return __builtin_amdgcn_s_memrealtime(); }   // first thing in the kernel (unconditional: asking whether anyone traces would be a scalar round trip in front of everything)
+__device__ __forceinline__ TraceStart trace_begin(SP sp, unsigned long long entry) {   // in front of a tile's work (the pointer's load: in the shadow of the tile's first bytes.
+    TraceStart t = {entry, 0ull, 0ull};                                                  //  Asking ArgsA::debug instead trips the compiler: "illegal VGPR to SGPR copy" in the scalar-loop kernels)
     if (sp.trace) { t.real = __builtin_amdgcn_s_memrealtime(); t.core = __builtin_amdgcn_s_memtime(); }
     return t;
 }
-__device__ __forceinline__ void trace_end(SP sp, size_t tile, uint32_t lane, TraceStart t0, bool fast) {
-    if (!sp.trace) return;
+__device__ __forceinline__ void trace_end(SP sp, const ArgsA &A, size_t tile, uint32_t lane, TraceStart t0, bool fast) {
+    if (!(A.debug & DEBUG_TRACE)) return;
     const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long hw = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);   // HW_REG_HW_ID, HW_REG_XCC_ID
     if (lane == 0) { unsigned long long *o = sp.trace + tile * 4; o[0] = t0.real; o[1] = r1; o[2] = hw | ((t0.real - t0.entry) << 40); o[3] = (fast ? 1ull : 0ull) | ((c1 - t0.core) << 8); }
@@ -966,8 +1037,13 @@ __device__ __forceinline__ void trace_end(SP sp, size_t tile, uint32_t lane, Tra
 // the kernel's argument block (its only parameter, at offset 0 of the kernarg segment)
 __device__ __forceinline__ KernArgs kernel_args() { return (KernArgs)__builtin_amdgcn_kernarg_segment_ptr(); }
 
-// LDS: the sRGB LUT
-__device__ __forceinline__ void stage_lds(SP sp, float *lut) { lut[threadIdx.x] = sp.srgb_lut[threadIdx.x]; }
+// LDS: the sRGB LUT, 1 KiB per workgroup.  EVERY wave writes all of it (16 bytes per lane: the four waves of a workgroup store the same
+// values to the same addresses) and reads it back only behind its own stores -- LDS operations of one wave complete in order -- so no
+// barrier stands between a wave's launch and its first tile, and the table's load travels beside the tile's first bytes instead of in
+// front of them (round 3: argument loads -> table load -> barrier -> head loads, 1.1-1.4 us of every wave's life).
+struct LutRegs { float4 v; };
+__device__ __forceinline__ LutRegs lut_load(const float *srgb_lut, uint32_t lane) { LutRegs r; r.v = gload_f4(srgb_lut, lane * 16u); return r; }
+__device__ __forceinline__ void lut_store(float *lut, uint32_t lane, const LutRegs &r) { reinterpret_cast<float4 *>(lut)[lane] = r.v; }
 
 // ---- the shading pass over a resident G-buffer ------------------------------------------------------------------------
 // Which tiles a wave shades.  Lit regions (ALU-bound tiles: ~8000 issue cycles each at 64 lights) and shadowed ones (latency-bound:
@@ -982,34 +1058,46 @@ __device__ __forceinline__ void stage_lds(SP sp, float *lut) { lut[threadIdx.x] 
 // A workgroup = 4 horizontally adjacent tiles (they share texture and shadow-map lines), T times; XCD x takes the tile rows
 // y = x (mod 8), walking each row left to right.  grid = (8 x workgroups per tile row, 1 / T of the groups of 8 tile rows): the
 // linear block id advances along x first, so id % 8 = x % 8.  (Placement is a speed matter only; surplus blocks exit.)
+// tile row of the wave's k-th tile, or false: none
+__device__ __forceinline__ bool tile_row(const ArgsA &A, uint32_t k, uint32_t &ty) {
+    const uint32_t g = blockIdx.y + k * A.stride;   // the block's groups of 8 tile rows: blockIdx.y + k stride
+    ty = g * 8 + (blockIdx.x & 7u);
+    return g < ((A.tiles_y + 7u) >> 3) && ty < A.tiles_y;
+}
 template <int LOOP, bool STATS, bool LDS_SHADOW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_material(const ShadeParams sp_by_value) {
     __shared__ float lut[256];
     __shared__ float shadow_tiles[LDS_SHADOW ? 4 : 1][LDS_SHADOW ? SHADOW_TILE * SHADOW_TILE : 1];   // one per wave (the LDS variant of the PCF slow path)
     KernArgs args = kernel_args();
-    const unsigned long long t_entry = trace_entry(*args);
+    const unsigned long long t_entry = trace_entry();
     uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t groups = (args->tiles_y + 7u) >> 3, tx = (blockIdx.x >> 3) * 4 + wave;
-    const uint32_t T = args->tiles_per_wave, stride = (groups + T - 1u) / T;   // the block's groups of 8 tile rows: blockIdx.y + k stride
-    stage_lds(*args, lut);
-    __syncthreads();
-    if (tx >= args->tiles_x) return;
+    const uint32_t tx = (blockIdx.x >> 3) * 4 + wave;
+    const float *srgb_lut;
+    const unsigned long long *vis_unused;
+    ArgsA A = args_a_first(args, srgb_lut, vis_unused);
+    uint32_t ty;
+    if (tx >= A.tiles_x || !tile_row(A, 0, ty)) return;
+    const LutRegs lr = lut_load(srgb_lut, lane);                                           // an L2 hit: back first ...
+    TileHead cur = load_head(A.ga, A.gb, (size_t)ty * A.tiles_x + tx, lane);              // ... while the tile's first bytes travel
+    lut_store(lut, lane, lr);
 #pragma nounroll
-    for (uint32_t k = 0; k < T; ++k) {
-        const uint32_t g = blockIdx.y + k * stride, ty = g * 8 + (blockIdx.x & 7u);
-        if (g >= groups || ty >= args->tiles_y) break;
+    for (uint32_t k = 0;;) {
         asm volatile("" : "+s"(args), "+v"(lane));   // see SP
         SP sp = *args;
         const TraceStart t0 = trace_begin(sp, t_entry);
-        const size_t tile = (size_t)ty * sp.tiles_x + tx;   // wave-uniform
-        const TileHead cur = load_head(sp, tile, lane);
-        const auto second = [&](float4 &gc, float4 &gd, float4 &ge) {
-            gc = gload_f4(sp.g.c + tile * 64, lane * 16u); gd = gload_f4(sp.g.d + tile * 64, lane * 16u); ge = gload_f4(sp.g.e + tile * 64, lane * 16u);
+        const size_t tile = (size_t)ty * A.tiles_x + tx;   // wave-uniform
+        const auto second = [&](const float4 *pc, const float4 *pd, const float4 *pe, float4 &gc, float4 &gd, float4 &ge) {
+            gc = gload_f4(pc + tile * 64, lane * 16u); gd = gload_f4(pd + tile * 64, lane * 16u); ge = gload_f4(pe + tile * 64, lane * 16u);
         };
-        const bool fast = shade_tile_fast<LOOP, STATS>(sp, lut, ty, tx, lane, cur, second);
+        const bool fast = shade_tile_fast<LOOP, STATS>(sp, args, A, lut, ty, tx, lane, cur, second);
         if (!fast) shade_tile<LOOP, STATS, LDS_SHADOW>(sp, lut, shadow_tiles[LDS_SHADOW ? wave : 0], ty, tx, lane, cur, second);
-        trace_end(sp, tile, lane, t0, fast);
+        trace_end(sp, A, tile, lane, t0, fast);
+        if (++k >= A.T) break;
+        asm volatile("" : "+s"(args));
+        A = args_a(args);                      // (nothing of the block stays in registers across a tile)
+        if (!tile_row(A, k, ty)) break;
+        cur = load_head(A.ga, A.gb, (size_t)ty * A.tiles_x + tx, lane);
     }
 }
 
@@ -1024,22 +1112,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     __shared__ float lut[256];
     __shared__ float shadow_tiles[LDS_SHADOW ? 4 : 1][LDS_SHADOW ? SHADOW_TILE * SHADOW_TILE : 1];   // one per wave (the LDS variant of the PCF slow path)
     KernArgs args = kernel_args();
-    const unsigned long long t_entry = trace_entry(*args);
+    const unsigned long long t_entry = trace_entry();
     uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t groups = (args->tiles_y + 7u) >> 3, tx = (blockIdx.x >> 3) * 4 + wave;   // XCD-aware order, T tiles per wave: see k_material
-    const uint32_t T = args->tiles_per_wave, stride = (groups + T - 1u) / T;
-    stage_lds(*args, lut);
-    __syncthreads();
-    if (tx >= args->tiles_x) return;
+    const uint32_t tx = (blockIdx.x >> 3) * 4 + wave;   // XCD-aware order, T tiles per wave, the LUT without a barrier: see k_material
+    const float *srgb_lut;
+    const unsigned long long *vis_plane;
+    ArgsA A = args_a_first(args, srgb_lut, vis_plane);
+    uint32_t ty;
+    if (tx >= A.tiles_x || !tile_row(A, 0, ty)) return;
+    const LutRegs lr = lut_load(srgb_lut, lane);
+    unsigned long long key = vis_plane[((size_t)ty * A.tiles_x + tx) * 64 + lane];
+    lut_store(lut, lane, lr);
 #pragma nounroll
-    for (uint32_t k = 0; k < T; ++k) {
-    const uint32_t g = blockIdx.y + k * stride, ty = g * 8 + (blockIdx.x & 7u);
-    if (g >= groups || ty >= args->tiles_y) break;
+    for (uint32_t k = 0;;) {
     asm volatile("" : "+s"(args), "+v"(lane));   // see SP
     SP sp = *args;
     const TraceStart t0 = trace_begin(sp, t_entry);
-    const unsigned long long key = sp.vis[((size_t)ty * sp.tiles_x + tx) * 64 + lane];
     const int32_t px = (int32_t)(tx * 8 + (lane & 7));
     const int32_t py = (row_global((int)ty, sp.band_tiles, sp.shard_count, sp.shard_index) + sp.tile_y0) * 8 + (int32_t)(lane >> 3);
     TileHead cur;
@@ -1101,7 +1190,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         cur.b0 = interpolate_attr(B, A0, A1, A2, 16); cur.b1 = interpolate_attr(B, A0, A1, A2, 17);
         cur.b2 = __uint_as_float(ob.material);
     }
-    const auto second = [&](float4 &gc, float4 &gd, float4 &ge) {
+    const auto second = [&](const float4 *, const float4 *, const float4 *, float4 &gc, float4 &gd, float4 &ge) {
         // attribute order (XVert::attr): uv 0-1, t 2-4, b 5-7, n 8-10, world 11-13, light space 14-17; planes as gbuffer_pack
         const auto mix = [&](float x0, float x1, float x2) {
 #pragma clang fp contract(off)
@@ -1122,9 +1211,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             ge = make_float4(interpolate_attr(B, A0, A1, A2, 7), interpolate_attr(B, A0, A1, A2, 8), interpolate_attr(B, A0, A1, A2, 9), interpolate_attr(B, A0, A1, A2, 10));
         }
     };
-    const bool fast = shade_tile_fast<LOOP, STATS>(sp, lut, ty, tx, lane, cur, second);
+    const bool fast = shade_tile_fast<LOOP, STATS>(sp, args, A, lut, ty, tx, lane, cur, second);
     if (!fast) shade_tile<LOOP, STATS, LDS_SHADOW>(sp, lut, shadow_tiles[LDS_SHADOW ? wave : 0], ty, tx, lane, cur, second);
-    trace_end(sp, (size_t)ty * sp.tiles_x + tx, lane, t0, fast);
+    trace_end(sp, A, (size_t)ty * A.tiles_x + tx, lane, t0, fast);
+    if (++k >= A.T) break;
+    asm volatile("" : "+s"(args));
+    A = args_a(args);
+    if (!tile_row(A, k, ty)) break;
+    key = args->vis[((size_t)ty * A.tiles_x + tx) * 64 + lane];
     }
 }
 
@@ -1187,7 +1281,8 @@ hipError_t launch_shade(const ShadeParams &sp_in, const ShadeLaunch &L) {
     // 0.104 ms and 0.142 against 0.153 with T = 2)
     sp.tiles_per_wave = L.tiles_per_wave ? L.tiles_per_wave : (n_tiles < SMALL_FRAME_TILES ? 1u : DEFAULT_TILES_PER_WAVE);
     const uint32_t bpr = (sp.tiles_x + 3) / 4, groups = (sp.tiles_y + 7) / 8;
-    const dim3 grid(8 * bpr, (groups + sp.tiles_per_wave - 1) / sp.tiles_per_wave);   // a block shades tiles_per_wave groups of 8 tile rows
+    sp.group_stride = (groups + sp.tiles_per_wave - 1) / sp.tiles_per_wave;
+    const dim3 grid(8 * bpr, sp.group_stride);   // a block shades tiles_per_wave groups of 8 tile rows, group_stride groups apart
     if (sp.debug & 16)   // A/B only: the 25-tap path staged through LDS (a separate instantiation: it costs the default kernels nothing)
         return L.loop == 2 ? launch_variant<2, false, true>(sp, L, grid) : launch_variant<1, false, true>(sp, L, grid);
     if (L.loop == 2) return L.stats ? launch_variant<2, true, false>(sp, L, grid) : launch_variant<2, false, false>(sp, L, grid);

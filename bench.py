@@ -78,20 +78,47 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def count_gpus_without_hip():
+    """GPUs this process may use, WITHOUT a HIP call (the launcher must not initialise the GPU): the *_VISIBLE_DEVICES lists when set,
+    else the KFD topology's nodes that have SIMDs (CPU nodes have none; no KFD at all: 0).  None when the topology cannot be read:
+    the ranks then fail by themselves, loudly, if a device is missing."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    if not os.path.isdir("/sys/class/kfd"):
+        return 0        # no amdgpu compute driver on this machine at all
+    try:
+        n = 0
+        for node in os.listdir(base):
+            with open(os.path.join(base, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+        return n
+    except OSError:
+        return None
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment): start the N ranks here -- one child
     process per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set the way torch.distributed.run sets them --
-    BEFORE this process has made any GPU call (it never makes one: a process that has initialised the GPU must not fork + exec
-    on this pool).  Rank 0's stdout (the one JSON line) is relayed; the exit code is non-zero when any rank fails, and the
+    BEFORE this process has made any GPU call (it never makes one, not even to count the devices -- count_gpus_without_hip: a
+    process that has initialised the GPU must not fork + exec on this pool; under a profiler, whose preloaded library has
+    initialised it already, the launcher refuses).  Rank 0's stdout (the one JSON line) is relayed; the exit code is non-zero when any rank fails, and the
     other ranks are then stopped by their exact pids (they may be blocked in a collective)."""
     import socket
     import subprocess
     import threading
     share = os.environ.get("ARCTIC_BENCH_SHARE_GPU") == "1"
+    if any("rocprof" in os.environ.get(v, "") for v in ("LD_PRELOAD", "HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES")) or any(k.startswith("ROCPROF") for k in os.environ):
+        # under rocprofv3 the profiler's preloaded library has initialised the GPU before this program started: starting the ranks
+        # from here would be a fork + exec from a GPU-initialised process (refused on this pool)
+        raise SystemExit("bench.py --gpus N under a profiler: profile ONE rank directly (RANK / WORLD_SIZE / MASTER_* set by hand), not the launcher")
     if not share:
-        import torch
-        have = torch.cuda.device_count()      # counts devices without initialising them (no HIP context in this process)
-        if have < n:
+        have = count_gpus_without_hip()
+        if have is not None and have < n:
             raise SystemExit(f"bench.py --gpus {n}: this node shows {have} HIP device(s); the multi-GPU leg needs one GPU per rank "
                              f"(a rehearsal of the N-rank code path on one GPU: ARCTIC_BENCH_BACKEND=gloo ARCTIC_BENCH_SHARE_GPU=1)")
     port = os.environ.get("MASTER_PORT")
@@ -244,8 +271,14 @@ def main():
     perm = torch.as_tensor(dest, device="cuda") if staging is not None else None
     out_ptrs = [o.data_ptr() for o in outs]
     r.set_stream(torch.cuda.current_stream().cuda_stream)   # the library launches on torch's stream: torch events see its kernels
-    state = {"k": 0}
-    shade = r.prepared_pass_shade(sc.desc, sc.settings)
+    state = {"k": 0, "launches": 0, "t_first": None}   # launches: passes enqueued by this process so far (a profiled run's kernel trace is cut with it)
+    shade_raw = r.prepared_pass_shade(sc.desc, sc.settings)
+
+    def shade(ptr):
+        if state["t_first"] is None:
+            state["t_first"] = time.perf_counter()
+        state["launches"] += 1
+        shade_raw(ptr)
 
     def step():
         b = state["k"] % n_buf
@@ -289,6 +322,43 @@ def main():
             raise SystemExit("multi-rank frame differs from the single-device frame")
         verified = True
 
+    def timed_region(k_steps, w_steps):
+        """W untimed steps, then exactly K steps between barrier + synchronize on both sides; returns (wall seconds, HIP-event ms, index of
+        the first timed launch)"""
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(w_steps):
+            step()
+        drain()
+        r.flush()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        first = state["launches"]
+        t_start = time.perf_counter()
+        e0.record()
+        for _ in range(k_steps):
+            step()
+        e1.record()
+        drain()
+        torch.cuda.synchronize()   # (every stream of the device: the library's too)
+        if world > 1:
+            dist.barrier()
+        wall = time.perf_counter() - t_start
+        r.flush()                  # the library's own synchronising call reports what a pass may have flagged (outside the timed region: it adds nothing to wait for)
+        return wall, e0.elapsed_time(e1), first, t_start
+
+    # COLD figure first (rounds 1-2 measured this way; kept so that rounds stay comparable from the driver's record alone): the same
+    # W + K steps straight after set-up, before the device has been kept busy for any length of time.
+    cold = None
+    if os.environ.get("ARCTIC_BENCH_COLD", "1") != "0":
+        c_wall, c_ev, _, _ = timed_region(args.steps, args.warmup)
+        if world > 1:
+            t = torch.tensor([c_wall], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            c_wall = float(t.item())
+        cold = {"ms_per_step": round(c_wall / args.steps * 1e3, 4), "kernel_ms": round(c_ev / args.steps, 4),
+                "note": f"the same {args.warmup} + {args.steps} steps timed the same way straight after set-up, BEFORE the settle loop (how rounds 1-2 were measured)"}
+
     # A device that has been idle runs its first ~100 ms of work at other clocks than the ones it sustains (measured on this pool:
     # the same pass 0.22 ms in the first 20 ms of load, 0.19 ms after 70 ms, then stable to 0.3 %): the pass is repeated, untimed,
     # for SETTLE_MS before anything is measured.  The timed region below is still exactly W warm-up steps + K steps.
@@ -301,27 +371,12 @@ def main():
     # isolated launches, each between its own pair of HIP events (p10/p50/p90 in the line)
     iters = max(10, min(args.steps, 50))
     ms = r.time_shade(sc.desc, sc.settings, warmup=20, iters=iters)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    state["launches"] += 20 + iters
 
-    for _ in range(args.warmup):
-        step()
-    drain()
-    r.flush()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t_start = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        step()
-    ev1.record()
-    drain()
-    torch.cuda.synchronize()   # (every stream of the device: the library's too)
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t_start
-    r.flush()                  # the library's own synchronising call reports what a pass may have flagged (outside the timed region: it adds nothing to wait for)
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps   # HIP events on the launch stream around the K timed launches
+    dt, ev_ms, first_timed, t_start = timed_region(args.steps, args.warmup)
+    warmup_effective = {"launches": first_timed, "ms": round((t_start - (state["t_first"] or t_start)) * 1e3, 1),
+                        "note": "passes this process had enqueued, and wall time since the first of them, when the timed region began: cold region + settle loop + isolated launches + --warmup"}
+    kernel_ms = ev_ms / args.steps   # HIP events on the launch stream around the K timed launches
     kernel_ms_source = "HIP events on the launch stream around the K timed steps / K"
     if world > 1:   # there the span between the events includes the waits for the gathers that free the shard buffers: not kernel time
         kernel_ms = float(np.median(ms))
@@ -428,6 +483,9 @@ def main():
                 "kernel": f"k_material<{2 if n_lights > 12 else 1}> (the whole pass in one launch: material fetch, shadow test, "
                           f"{'packed' if n_lights > 12 else 'scalar'} light loop, tonemap, store; two tiles per wave)",
                 "settle_ms_before_measuring": SETTLE_MS,
+                "warmup_effective": warmup_effective,
+                "timed_launches": [first_timed, first_timed + args.steps],
+                "cold": None if cold is None else dict(cold, frac=round(shaded_local * BYTES_PER_PIXEL / (cold["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)),
                 "kernel_ms": round(kernel_ms, 4),
                 "kernel_ms_source": kernel_ms_source,
                 "isolated_launch_ms_p10_p50_p90": [round(float(np.percentile(ms, q)), 4) for q in (10, 50, 90)],

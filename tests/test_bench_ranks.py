@@ -32,15 +32,28 @@ def test_launcher_starts_ranks_and_fails_loudly_without_a_gpu():
     assert out.stdout.strip() == ""          # no result line from a failed run
 
 
-def test_launcher_refuses_more_ranks_than_devices():
+@pytest.mark.parametrize("visible", [None, "0"])
+def test_launcher_refuses_more_ranks_than_devices(visible):
+    """the launcher counts the devices without a HIP call (the KFD topology, or the *_VISIBLE_DEVICES list when one is set)"""
     import torch
-    if torch.cuda.device_count() >= 2:
+    if visible is None and torch.cuda.device_count() >= 2:
         pytest.skip("node has 2+ devices")
     env = dict(os.environ)
-    for k in ("WORLD_SIZE", "RANK", "ARCTIC_BENCH_SHARE_GPU"):
+    for k in ("WORLD_SIZE", "RANK", "ARCTIC_BENCH_SHARE_GPU", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         env.pop(k, None)
+    if visible is not None:
+        env["HIP_VISIBLE_DEVICES"] = visible
     out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode != 0 and "one GPU per rank" in out.stderr and out.stdout.strip() == ""
+
+
+def test_launcher_refuses_to_start_ranks_under_a_profiler():
+    """under rocprofv3 the preloaded tool library has initialised the GPU before bench.py starts: no fork + exec from there"""
+    env = dict(os.environ, ROCPROFILER_REGISTER_FORCE_LOAD="1")
+    for k in ("WORLD_SIZE", "RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode != 0 and "under a profiler" in out.stderr and out.stdout.strip() == ""
 
 
 @pytest.mark.gpu

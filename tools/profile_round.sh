@@ -25,3 +25,7 @@ cd "$ROOT"
 python3 tools/pmc_summary.py "$OUT" "$TAG"
 cp "$OUT"/kt/*/*kernel_stats.csv "profiles/${TAG}_kernel_stats_bench_command.csv" 2>/dev/null || cp $(find "$OUT/kt" -name "*kernel_stats.csv" | head -1) "profiles/${TAG}_kernel_stats_bench_command.csv"
 cp "$OUT/bench.json" "profiles/${TAG}_bench_under_rocprof.json"
+# the same trace cut to the K timed launches of that run (the stats file above averages every launch of the process: cold region, settle
+# loop, isolated launches): the figure that has to agree with the line's ms_per_step
+python3 tools/kernel_times.py "$OUT/kt" --timed "$OUT/bench.json" > "profiles/${TAG}_kernel_trace_timed_launches.json"
+cat "profiles/${TAG}_kernel_trace_timed_launches.json"
