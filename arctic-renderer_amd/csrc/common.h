@@ -40,6 +40,15 @@ __host__ __device__ inline void gbuffer_pack(const float *v /*18 attrs in VSOut 
     E = make_float4(v[7], v[8], v[9], v[10]);
 }
 
+// what k_resolve needs to leave a COST CLASS per tile next to the G-buffer (a dispatch hint for the shading pass, never a result):
+// the shadow map's min/max table as the shading kernel's first shadow test reads it
+struct TileHint {
+    uint8_t *tile_class;     // one byte per tile of the shard: 1 = a pixel of the tile can be lit / takes the environment lookup; null: no hint wanted
+    const float2 *bounds;    // ShadeParams::shadow_bounds, or null (no map, no table): every covered pixel counts as costly
+    uint32_t S, pitch;       // shadow-map size, entries per table row
+    uint32_t sky;            // 1: an environment map is set, pixels without geometry are costly too
+};
+
 // transformed vertex (the reference's VSOut), 96 B
 struct XVert {
     float clip[4];
@@ -250,6 +259,9 @@ struct ShadeParams {
     unsigned long long *stats;   // STATS kernels only: [0] point-light evaluations, [1] lit pixels, [2] evaluations with n.wi > 0,
                                  // [3] (tile, light) pairs with n.wi <= 0 in every lit lane, [4] tiles with a lit pixel
     unsigned long long *trace;   // ARCTIC_OPT_TILE_TRACE: 4 x u64 per tile (shade.hip: trace_end), or null
+    const uint32_t *tile_order;  // the pass's dispatch order (k_tile_order: strips of 4 tiles, ty << 16 | strip column), n_jobs entries; null: the geometric order
+    uint32_t n_jobs;
+    uint32_t pad_o;
     // whole frames without a G-buffer (k_material_vis): the visibility plane and what the prepass left behind
     const unsigned long long *vis; const SetupRec *recs; const RasterRec *rrecs; const uint32_t *rec_of; const ObjectRec *objs; const XVert *xv;
     // skybox (skybox.hlsl:61-90): environment map for pixels without geometry; env == null -> black
@@ -297,7 +309,10 @@ hipError_t launch_raster_depth(const SetupRec *recs, const RasterRec *rrecs, con
 hipError_t launch_raster_owned(bool depth_only, const RasterRec *rrecs, const uint2 *items, uint2 *left /*what the bins did not take: counters[4] entries*/, uint32_t item_cap, uint32_t *counters, const BinTables &B,
                                const GeomParams &gp, unsigned long long *vis, uint32_t *depth_bits, hipStream_t s);
 hipError_t launch_resolve(const unsigned long long *vis, const SetupRec *recs, const RasterRec *rrecs, const uint32_t *rec_of, const ObjectRec *objs, const XVert *xv,
-                          const GeomParams &gp, uint32_t n_tiles, GBuffer g, hipStream_t s);
+                          const GeomParams &gp, uint32_t n_tiles, GBuffer g, const TileHint &hint, hipStream_t s);
+// the shading pass's dispatch order (ShadeParams::tile_order) from the cost classes k_resolve left: lists = scratch of 2 N words, order = N words,
+// N = ceil(tiles_x / 4) * tiles_y strips; tail_permille: the last part of the order that holds cheap strips only
+hipError_t launch_tile_order(const uint8_t *tile_class, uint32_t tiles_x, uint32_t tiles_y, uint32_t tail_permille, uint32_t *lists, uint32_t *order, hipStream_t s);
 hipError_t launch_fill_u64(unsigned long long *p, unsigned long long v, size_t n, hipStream_t s);
 hipError_t launch_fill_u32(uint32_t *p, uint32_t v, size_t n, hipStream_t s);
 hipError_t launch_shade(const ShadeParams &sp, const ShadeLaunch &L);

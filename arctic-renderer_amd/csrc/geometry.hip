@@ -29,6 +29,7 @@
 // (the parity tests require bit equality with the CPU oracle).  fmaf() only where written.
 #include "common.h"
 #include "edges.h"
+#include "shadow_coords.h"
 
 namespace arctic {
 
@@ -901,7 +902,7 @@ __global__ __launch_bounds__(256) void k_raster_owned(const RasterRec *__restric
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_resolve(const unsigned long long *__restrict__ vis, const SetupRec *__restrict__ recs, const RasterRec *__restrict__ rrecs,
                                                  const uint32_t *__restrict__ rec_of, const ObjectRec *__restrict__ objs, const XVert *__restrict__ xv,
-                                                 const GeomParams gp, uint32_t n_tiles, GBuffer g) {
+                                                 const GeomParams gp, uint32_t n_tiles, GBuffer g, const TileHint hint) {
     uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tile >= n_tiles) return;
     uint32_t lane = threadIdx.x & 63;
@@ -933,6 +934,77 @@ __global__ __launch_bounds__(256) void k_resolve(const unsigned long long *__res
         gbuffer_pack(a, mat, A, B3, C, D, E);
         g.a[idx] = A; g.c[idx] = C; g.d[idx] = D; g.e[idx] = E;
         g.b[idx * 3] = B3[0]; g.b[idx * 3 + 1] = B3[1]; g.b[idx * 3 + 2] = B3[2];
+    }
+    // The tile's COST CLASS, a hint for the shading pass's dispatch order (k_tile_order; results never depend on it): 1 when a pixel
+    // of the tile can be lit at all -- covered, and not decided "every tap shadowed" by the shadow map's min/max table, the first
+    // test of the shading kernel itself (shade.hip: shadow_quick) -- or takes the environment lookup; such a tile runs the light loop,
+    // tens of times the work of a tile in full shadow.  The light-space position is in registers here: the hint costs one 8-byte load.
+    if (hint.tile_class) {
+        bool costly = mat != NO_MATERIAL || hint.sky != 0;
+        if (mat != NO_MATERIAL && hint.bounds) {
+            ShadowPos p;
+            shadow_coords(a[14], a[15], a[16], a[17], p);
+            uint32_t offset;
+            if (shadow_table_offset(hint.S, hint.pitch, p, offset)) {
+                const float2 mm = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(hint.bounds) + offset);
+                costly = !(p.pz > mm.y);
+            }
+        }
+        const unsigned long long any = __ballot(costly);
+        if (lane == 0) hint.tile_class[tile] = any ? 1 : 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// the shading pass's dispatch order from the tiles' cost classes (ONE workgroup; 32 k strips at 4K)
+// ---------------------------------------------------------------------------------------------
+// A job of the shading pass = a STRIP of 4 horizontally adjacent tiles (one workgroup, a wave per tile), coded ty << 16 | strip
+// column.  A strip is costly when one of its tiles is.  The order deals the costly strips evenly over the first (1 - tail) of the
+// list, in raster order, and fills everything else with the cheap ones, in raster order: whatever part of the frame the light
+// falls on, every stretch of the dispatch carries the frame's own mix of ALU-bound and latency-bound work (so the two hide behind
+// each other on every SIMD from the first wave on), and the last workgroups dispatched are all short (no tail of lit tiles on a
+// draining chip).  Position p holds a costly strip iff cnt(p + 1) > cnt(p), cnt(p) = ceil(p nL / span) = costly strips in front of p.
+__device__ __forceinline__ uint32_t costly_before(uint32_t p, uint32_t nL, uint32_t span) {
+    const unsigned long long c = ((unsigned long long)p * nL + span - 1) / span;
+    return c < nL ? (uint32_t)c : nL;
+}
+__global__ __launch_bounds__(1024) void k_tile_order(const uint8_t *__restrict__ tile_class, uint32_t tiles_x, uint32_t tiles_y, uint32_t tail_permille,
+                                                     uint32_t *__restrict__ lists /* 2 N: costly strips, then cheap strips */, uint32_t *__restrict__ order /* N */) {
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t total;
+    const uint32_t bpr = (tiles_x + 3) / 4, N = bpr * tiles_y;
+    const uint32_t per = (N + 1023) / 1024, s0 = min(N, threadIdx.x * per), s1 = min(N, s0 + per);
+    const auto costly = [&](uint32_t s) {
+        const uint32_t ty = s / bpr, x0 = (s % bpr) * 4, x1 = min(tiles_x, x0 + 4);
+        uint32_t c = 0;
+        for (uint32_t x = x0; x < x1; ++x) c |= tile_class[(size_t)ty * tiles_x + x];
+        return c != 0 ? 1u : 0u;
+    };
+    uint32_t mine = 0;
+    for (uint32_t s = s0; s < s1; ++s) mine += costly(s);
+    part[threadIdx.x] = mine;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {   // inclusive scan, Hillis-Steele (ten steps; the kernel is a few microseconds)
+        const uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    if (threadIdx.x == 1023) total = part[1023];
+    uint32_t l = part[threadIdx.x] - mine;   // costly strips in front of s0
+    for (uint32_t s = s0; s < s1; ++s) {
+        const uint32_t code = ((s / bpr) << 16) | (s % bpr);
+        if (costly(s)) lists[l++] = code;
+        else lists[N + (s - l)] = code;
+    }
+    __threadfence_block();
+    __syncthreads();
+    const uint32_t nL = total;
+    const uint32_t tail = (uint32_t)((unsigned long long)N * tail_permille / 1000);
+    const uint32_t span = max(max(nL, N - min(N, tail)), 1u);
+    for (uint32_t p = s0; p < s1; ++p) {
+        const uint32_t c = costly_before(p, nL, span);
+        order[p] = costly_before(p + 1, nL, span) > c ? lists[c] : lists[N + (p - c)];
     }
 }
 
@@ -1042,9 +1114,14 @@ hipError_t launch_raster_depth(const SetupRec *recs, const RasterRec *rrecs, con
 }
 
 hipError_t launch_resolve(const unsigned long long *vis, const SetupRec *recs, const RasterRec *rrecs, const uint32_t *rec_of, const ObjectRec *objs, const XVert *xv,
-                          const GeomParams &gp, uint32_t n_tiles, GBuffer g, hipStream_t s) {
+                          const GeomParams &gp, uint32_t n_tiles, GBuffer g, const TileHint &hint, hipStream_t s) {
     if (n_tiles == 0) return hipSuccess;
-    k_resolve<<<div_up(n_tiles, 4), 256, 0, s>>>(vis, recs, rrecs, rec_of, objs, xv, gp, n_tiles, g);
+    k_resolve<<<div_up(n_tiles, 4), 256, 0, s>>>(vis, recs, rrecs, rec_of, objs, xv, gp, n_tiles, g, hint);
+    return hipGetLastError();
+}
+hipError_t launch_tile_order(const uint8_t *tile_class, uint32_t tiles_x, uint32_t tiles_y, uint32_t tail_permille, uint32_t *lists, uint32_t *order, hipStream_t s) {
+    if (tiles_x == 0 || tiles_y == 0) return hipSuccess;
+    k_tile_order<<<1, 1024, 0, s>>>(tile_class, tiles_x, tiles_y, tail_permille, lists, order);
     return hipGetLastError();
 }
 

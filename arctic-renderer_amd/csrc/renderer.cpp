@@ -74,7 +74,13 @@ struct Rccl {
             tried = true;
             // an RCCL the process has loaded already (a host that also runs torch.distributed: PyTorch-ROCm brings its own librccl.so.1)
             // is the one to use -- ONE library instance with two communicators, not two RCCL builds side by side on the same devices
-            void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+            // ARCTIC_RCCL_LIB (honoured only when set): the library that provides the nccl* entry points instead -- the test suite's
+            // loopback communicator (tests/cpp/loopback_rccl.cpp: ranks = threads of one process on one GPU, where RCCL refuses two
+            // ranks per device), so that the R > 1 branch of the exchange runs where no second GPU exists.  No fallback when it is set.
+            const char *override_lib = std::getenv("ARCTIC_RCCL_LIB");
+            const bool overridden = override_lib && *override_lib;
+            void *h = overridden ? dlopen(override_lib, RTLD_NOW | RTLD_LOCAL) : dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+            if (overridden && !h) return false;
             if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
             if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
             if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
@@ -207,6 +213,13 @@ struct ArcticRenderer {
     uint64_t light_stats[2] = {0, 0};   // stats[8], [9]: (tile, light) pairs with n.wi <= 0 in every lit lane; tiles with a lit pixel
     int keep_float = 0, count_evals = 0, culling = 1, debug = 0, hdr16 = 0, tile_trace = 0;
     uint32_t tiles_per_wave = 0;     // ARCTIC_OPT_TILES_PER_WAVE (0 = the library's default)
+    // The shading pass's dispatch order (round 4): k_resolve leaves a cost class per tile next to the G-buffer (can a pixel of the tile be
+    // lit at all?), k_tile_order turns the classes into the order in which arctic_pass_shade hands out its strips of 4 tiles.  A hint:
+    // a stale or missing order changes the pass's time, never its image.
+    DevBuf d_tile_class, d_order_lists, d_tile_order;
+    bool have_order = false;         // d_tile_order belongs to the G-buffer in place
+    int tile_order = 1;              // ARCTIC_OPT_TILE_ORDER: 0 = the geometric order of round 3
+    uint32_t order_tail = 60;        // ARCTIC_OPT_ORDER_TAIL: the last part of the order (per mille) that holds cheap strips only
     DevBuf d_tile_trace;             // ARCTIC_OPT_TILE_TRACE: 4 x u64 per tile of the latest shading pass
     int raster_owner = -1;           // ARCTIC_OPT_RASTER_OWNER: bit 0 forward pass, bit 1 shadow pass: the blocks of the target are written once by owner waves
                                      // (k_bin + k_raster_owned) instead of per-pixel atomics; -1: the library's choice
@@ -221,6 +234,10 @@ struct ArcticRenderer {
     int comm_rank = 0, comm_world = 1;
     hipStream_t comm_stream = nullptr;
     bool comm_stream_borrowed = false;   // the communication stream is the handle's own stream, idle because the caller brought its stream (one stream -- one hardware queue -- fewer)
+    // ONE role per stream: own_stream is the main stream, or -- the caller brought its own -- EITHER the exchange's stream (borrowed by
+    // arctic_comm_init) OR the second prepass stream of three frames in flight, never both: a gather queued in front of a prepass would
+    // stall it behind the other ranks, and synchronising a prepass stream must never wait for an unmatched collective.
+    bool own_stream_is_prepass() const { return stream != own_stream && !comm_stream_borrowed; }
     hipEvent_t ev_main = nullptr;
     struct InFlight { const void *ptr = nullptr; hipEvent_t done = nullptr; } inflight[4];   // gathers that still read a shard buffer
     std::vector<uint32_t> peer_rows, peer_ranges;    // rows of every rank's shard; [begin, end) of every rank (row-range shards)
@@ -296,7 +313,7 @@ int alloc_targets(ArcticRenderer *r) {
     HIPCHECK(r, r->d_rgba8.ensure(out_px * 4));
     HIPCHECK(r, r->d_counter.ensure(8 * N_SHADE_STATS));
     HIPCHECK(r, r->d_geo_counters.ensure(4 * N_GEO_COUNTERS * 4));   // N_GEO_COUNTERS words per table set
-    r->have_gbuffer = r->have_output = r->have_vis = false;
+    r->have_gbuffer = r->have_output = r->have_vis = r->have_order = false;
     return ARCTIC_OK;
 }
 
@@ -521,7 +538,7 @@ int pass_shadow_map(ArcticRenderer *r, const ArcticScene *sc, hipStream_t stream
 // visibility only: vertex -> setup -> raster of the camera view
 int pass_visibility(ArcticRenderer *r, const ArcticScene *sc, hipStream_t stream) {
     Range zone("Forward Pass: visibility");
-    r->have_gbuffer = false;
+    r->have_gbuffer = false; r->have_order = false;
     int rc = run_geometry(r, sc, false, stream);
     if (rc != ARCTIC_OK) return rc;
     r->have_vis = true;
@@ -533,9 +550,30 @@ int resolve_gbuffer(ArcticRenderer *r) {
     Range zone("Forward Pass: G-buffer");
     if (!r->have_vis)
         return r->fail(ARCTIC_E_STATE, "no G-buffer: no visibility plane to resolve it from (run arctic_pass_gbuffer)");
+    // the cost classes need the shadow map's min/max table as the shading pass will read it (rebuilt here if the map was written since)
+    TileHint hint = {nullptr, nullptr, 0, 0, 0};
+    const uint32_t bpr = (r->tiles_x + 3) / 4, n_jobs = bpr * r->tiles_y;
+    r->have_order = false;
+    if (r->tile_order && n_jobs) {
+        HIPCHECK(r, r->d_tile_class.ensure(r->n_tiles()));
+        HIPCHECK(r, r->d_order_lists.ensure((size_t)n_jobs * 8));
+        HIPCHECK(r, r->d_tile_order.ensure((size_t)n_jobs * 4));
+        hint.tile_class = r->d_tile_class.as<uint8_t>();
+        hint.sky = r->env_w ? 1u : 0u;
+        const uint32_t nb = shadow_bounds_pitch(r->shadow_size);
+        if (nb && !(r->debug & 8)) {
+            int rc = build_shadow_bounds(r, r->stream);
+            if (rc != ARCTIC_OK) return rc;
+            hint.bounds = r->d_shadow_bounds().as<float2>(); hint.S = r->shadow_size; hint.pitch = nb;
+        }
+    }
     HIPCHECK(r, launch_resolve(r->d_vis().as<unsigned long long>(), r->geo[r->fwd()].d_recs.as<SetupRec>(), r->geo[r->fwd()].d_rrecs.as<RasterRec>(), r->geo[r->fwd()].d_rec_of.as<uint32_t>(), r->tables[r->fwd()].objs,
-                               r->geo[r->fwd()].d_xverts.as<XVert>(), r->tables[r->fwd()].gp, (uint32_t)r->n_tiles(), r->gbuffer(),
+                               r->geo[r->fwd()].d_xverts.as<XVert>(), r->tables[r->fwd()].gp, (uint32_t)r->n_tiles(), r->gbuffer(), hint,
                                r->stream));
+    if (hint.tile_class) {
+        HIPCHECK(r, launch_tile_order(hint.tile_class, r->tiles_x, r->tiles_y, r->order_tail, r->d_order_lists.as<uint32_t>(), r->d_tile_order.as<uint32_t>(), r->stream));
+        r->have_order = true;
+    }
     r->have_gbuffer = true;
     return ARCTIC_OK;
 }
@@ -588,6 +626,7 @@ int fill_shade_params(ArcticRenderer *r, const ArcticScene *sc, const ArcticSett
         HIPCHECK(r, hipMemsetAsync(r->d_tile_trace.p, 0, bytes, r->stream));
         sp.trace = r->d_tile_trace.as<unsigned long long>();
     }
+    if (!from_vis && r->have_order && r->tile_order) sp.tile_order = r->d_tile_order.as<uint32_t>();   // (n_jobs: launch_shade)
     sp.culling = r->culling;
     sp.debug = r->debug | (sp.trace ? (1 << 30) : 0);   // bit 30: the kernels learn of the trace from the first block of their arguments
     sp.hdr16 = r->hdr16;
@@ -661,7 +700,7 @@ int check_item_overflow(ArcticRenderer *r) {
     const uint32_t need = std::max(r->h_counts[1], r->h_counts[3]);
     r->h_counts[4] = r->h_counts[5] = 0;
     r->recs_worst_case = true;   // whichever table it was: the record table takes its worst-case size from now on
-    r->have_gbuffer = false; r->have_output = false; r->have_vis = false; r->shadow_key.clear();
+    r->have_gbuffer = false; r->have_output = false; r->have_vis = false; r->have_order = false; r->shadow_key.clear();
     return r->fail(ARCTIC_E_CAPACITY, "a rasteriser table overflowed (%u work items needed, %u slots; or more than 2 records per source triangle): the last frame "
                    "is incomplete; the tables grow on the next pass -- render the frame again", need, std::max(r->geo[0].item_cap, r->geo[1].item_cap));
 }
@@ -798,7 +837,7 @@ int arctic_flush(ArcticRenderer *r) {
     if (rc) return rc;
     HIPCHECK(r, hipStreamSynchronize(r->stream));
     for (hipStream_t ps : r->prepass_stream) if (ps) HIPCHECK(r, hipStreamSynchronize(ps));   // (joined into the main stream by every frame; after a failed frame they may not be)
-    if (r->stream != r->own_stream) HIPCHECK(r, hipStreamSynchronize(r->own_stream));        // (the second prepass stream of a handle on a caller's stream)
+    if (r->own_stream_is_prepass()) HIPCHECK(r, hipStreamSynchronize(r->own_stream));         // (the second prepass stream of a handle on a caller's stream)
     HIPCHECK(r, hipStreamSynchronize(r->shadow_stream));
     if (r->comm_stream) HIPCHECK(r, hipStreamSynchronize(r->comm_stream));
     if (int ov = check_item_overflow(r)) return ov;
@@ -810,7 +849,9 @@ int arctic_set_stream(ArcticRenderer *r, void *hip_stream) {
     int rc = select_device(r);
     if (rc) return rc;
     HIPCHECK(r, hipStreamSynchronize(r->stream));
-    HIPCHECK(r, hipStreamSynchronize(r->own_stream));   // (it may be the second prepass stream of the frames in flight)
+    // (own_stream may be the second prepass stream of the frames in flight; when it carries the exchange instead -- borrowed as the
+    //  communication stream -- it is NOT waited for here: it may hold a collective the other ranks have not reached yet)
+    if (r->own_stream_is_prepass()) HIPCHECK(r, hipStreamSynchronize(r->own_stream));
     r->stream = static_cast<hipStream_t>(hip_stream);   // NULL = the default stream
     return ARCTIC_OK;
 }
@@ -820,7 +861,11 @@ int arctic_use_own_stream(ArcticRenderer *r) {
     int rc = select_device(r);
     if (rc) return rc;
     HIPCHECK(r, hipStreamSynchronize(r->stream));
-    HIPCHECK(r, hipStreamSynchronize(r->own_stream));
+    if (r->own_stream_is_prepass()) HIPCHECK(r, hipStreamSynchronize(r->own_stream));
+    if (r->comm_stream_borrowed) {   // one role per stream: the exchange moves to a stream of its own (what own_stream still holds of it stays ordered in front of the passes to come)
+        HIPCHECK(r, hipStreamCreateWithFlags(&r->comm_stream, hipStreamNonBlocking));
+        r->comm_stream_borrowed = false;
+    }
     r->stream = r->own_stream;
     return ARCTIC_OK;
 }
@@ -1001,12 +1046,12 @@ int arctic_render_frame_device(ArcticRenderer *r, const ArcticScene *scene, cons
         HIPCHECK(r, hipEventRecord(r->ev_released[r->cur], r->stream));   // everything that reads or writes the set being left is enqueued by now
         r->released_valid[r->cur] = true;
         r->cur = (r->cur + 1) % r->frames_in_flight;
-        r->have_vis = r->have_gbuffer = false;                            // of the set entered: overwritten now
+        r->have_vis = r->have_gbuffer = r->have_order = false;            // of the set entered: overwritten now
         // consecutive prepasses on alternate streams when there are three sets (they overlap then); with two, one stream as before
         const int turn = r->frames_in_flight >= 3 ? (r->prepass_turn ^= 1) : 0;
         hipStream_t ps = r->prepass_stream[0];
         if (turn) {
-            if (r->stream != r->own_stream) ps = r->own_stream;
+            if (r->own_stream_is_prepass()) ps = r->own_stream;
             else { if (!r->prepass_stream[1]) HIPCHECK(r, hipStreamCreateWithFlags(&r->prepass_stream[1], hipStreamNonBlocking)); ps = r->prepass_stream[1]; }
         }
         if (r->released_valid[r->cur]) HIPCHECK(r, hipStreamWaitEvent(ps, r->ev_released[r->cur], 0));
@@ -1129,6 +1174,7 @@ int arctic_write_gbuffer(ArcticRenderer *r, const float *attrs, const uint32_t *
     HIPCHECK(r, hipStreamSynchronize(r->stream));
     r->have_vis = false;
     r->have_gbuffer = true;
+    r->have_order = false;   // (a caller's G-buffer comes without cost classes: the geometric order)
     return ARCTIC_OK;
 }
 
@@ -1245,6 +1291,22 @@ int arctic_read_tile_trace(ArcticRenderer *r, uint64_t *out, uint64_t capacity_t
     return ARCTIC_OK;
 }
 
+int arctic_read_tile_order(ArcticRenderer *r, uint32_t *order, uint8_t *tile_class, uint64_t capacity_tiles, uint32_t *tiles_x, uint32_t *tiles_y) {
+    if (!r) return ARCTIC_E_INVALID;
+    if (tiles_x) *tiles_x = r->tiles_x;
+    if (tiles_y) *tiles_y = r->tiles_y;
+    const uint64_t n = (uint64_t)r->tiles_x * r->tiles_y, n_jobs = (uint64_t)((r->tiles_x + 3) / 4) * r->tiles_y;
+    if (!order && !tile_class) return ARCTIC_OK;   // size query
+    if (!r->have_order) return r->fail(ARCTIC_E_STATE, "read_tile_order: the G-buffer in place has no dispatch order (ARCTIC_OPT_TILE_ORDER, arctic_pass_gbuffer)");
+    if (capacity_tiles < n) return r->fail(ARCTIC_E_CAPACITY, "read_tile_order: %llu tiles, room for %llu", (unsigned long long)n, (unsigned long long)capacity_tiles);
+    int rc = select_device(r);
+    if (rc) return rc;
+    HIPCHECK(r, hipStreamSynchronize(r->stream));
+    if (order) HIPCHECK(r, hipMemcpy(order, r->d_tile_order.p, n_jobs * 4, hipMemcpyDeviceToHost));
+    if (tile_class) HIPCHECK(r, hipMemcpy(tile_class, r->d_tile_class.p, n, hipMemcpyDeviceToHost));
+    return ARCTIC_OK;
+}
+
 int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value) {
     if (!r) return ARCTIC_E_INVALID;
     switch (option) {
@@ -1261,8 +1323,8 @@ int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value) {
         if ((int)value != r->frames_in_flight) {   // the sets change roles: nothing may be in flight, and `cur` must name a set that exists
             HIPCHECK(r, hipStreamSynchronize(r->stream));
             for (hipStream_t ps : r->prepass_stream) if (ps) HIPCHECK(r, hipStreamSynchronize(ps));
-            if (r->stream != r->own_stream) HIPCHECK(r, hipStreamSynchronize(r->own_stream));
-            if (r->cur >= (int)value) { r->cur = 0; r->have_vis = r->have_gbuffer = false; }
+            if (r->own_stream_is_prepass()) HIPCHECK(r, hipStreamSynchronize(r->own_stream));
+            if (r->cur >= (int)value) { r->cur = 0; r->have_vis = r->have_gbuffer = r->have_order = false; }
             r->released_valid[0] = r->released_valid[1] = r->released_valid[2] = false;
         }
         r->frames_in_flight = (int)value;
@@ -1284,6 +1346,11 @@ int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value) {
         r->tiles_per_wave = (uint32_t)value;
         break;
     case ARCTIC_OPT_TILE_TRACE: r->tile_trace = value != 0; break;
+    case ARCTIC_OPT_TILE_ORDER: r->tile_order = value != 0; if (!r->tile_order) r->have_order = false; break;
+    case ARCTIC_OPT_ORDER_TAIL:
+        if (value < 0 || value > 1000) return r->fail(ARCTIC_E_INVALID, "set_option: order tail is per mille, 0..1000");
+        r->order_tail = (uint32_t)value;
+        break;
     case ARCTIC_OPT_RASTER_OWNER: r->raster_owner = value < 0 ? -1 : (int)(value & 3); r->shadow_key.clear(); break;
     case ARCTIC_OPT_SHADOW_CACHE: r->shadow_cache = value != 0; r->shadow_key.clear(); break;
     case ARCTIC_OPT_SHADOW_SHARDED: r->shadow_sharded = value != 0; r->shadow_key.clear(); break;

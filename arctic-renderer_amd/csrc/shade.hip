@@ -31,6 +31,14 @@
 // compared bit for bit).
 #include "common.h"
 #include "edges.h"
+#include "shadow_coords.h"
+
+#ifndef ARCTIC_WG_WAVES
+#define ARCTIC_WG_WAVES 4       // waves per workgroup of the shading kernels: 4 (a strip of 4 tiles per workgroup) or 1 (a tile per workgroup; A/B)
+#endif
+#ifndef ARCTIC_EDGE_IN_FAST
+#define ARCTIC_EDGE_IN_FAST 1   // A/B switch (build_tmp variants only): 0 = a tile on a shadow edge goes to the general tile, as in round 3
+#endif
 
 namespace arctic {
 
@@ -54,12 +62,23 @@ __device__ __forceinline__ ArgsA args_a(KernArgs a) {   // before a tile's first
     asm volatile("" : "+s"(r.ga), "+s"(r.gb), "+s"(r.tiles_x), "+s"(r.tiles_y), "+s"(r.T), "+s"(r.stride), "+s"(r.debug), "+s"(r.n_materials));
     return r;
 }
-// ... and, for a wave's first tile, two more pointers in the same batch: the sRGB table, and the visibility plane (k_material_vis)
-__device__ __forceinline__ ArgsA args_a_first(KernArgs a, const float *&srgb_lut, const unsigned long long *&vis) {
+// ... and, for a wave's first tile, more in the same batch: the sRGB table, the visibility plane (k_material_vis), the dispatch order
+typedef const uint32_t __attribute__((address_space(4))) *OrderList;   // (read with scalar loads)
+struct OrderArgs { OrderList order; uint32_t n_jobs; };
+__device__ __forceinline__ ArgsA args_a_first(KernArgs a, const float *&srgb_lut, const unsigned long long *&vis, OrderArgs &O) {
     ArgsA r = {a->g.a, a->g.b, a->tiles_x, a->tiles_y, a->tiles_per_wave, a->group_stride, a->debug, a->n_materials};
     srgb_lut = a->srgb_lut; vis = a->vis;
-    asm volatile("" : "+s"(r.ga), "+s"(r.gb), "+s"(r.tiles_x), "+s"(r.tiles_y), "+s"(r.T), "+s"(r.stride), "+s"(r.debug), "+s"(r.n_materials), "+s"(srgb_lut), "+s"(vis));
+    const uint32_t *order = a->tile_order; O.n_jobs = a->n_jobs;
+    asm volatile("" : "+s"(r.ga), "+s"(r.gb), "+s"(r.tiles_x), "+s"(r.tiles_y), "+s"(r.T), "+s"(r.stride), "+s"(r.debug), "+s"(r.n_materials), "+s"(srgb_lut), "+s"(vis),
+                 "+s"(order), "+s"(O.n_jobs));
+    O.order = (OrderList)order;
     return r;
+}
+__device__ __forceinline__ OrderArgs order_args(KernArgs a) {
+    const uint32_t *order = a->tile_order; uint32_t n = a->n_jobs;
+    asm volatile("" : "+s"(order), "+s"(n));
+    OrderArgs O = {(OrderList)order, n};
+    return O;
 }
 constexpr int32_t DEBUG_TRACE = 1 << 30;   // ShadeParams::debug: the host asked for a tile trace (ShadeParams::trace is set)
 struct ShadowArgs { const float *map; const float2 *bounds; uint32_t S, pitch; };   // calculate_shadow's inputs
@@ -76,6 +95,17 @@ struct ArgsC { float ambient; StoreArgs st; const float4 *gc, *gd, *ge; };
 __device__ __forceinline__ ArgsC args_c(KernArgs a, const ArgsA &A, const ArgsB &B) {   // while the texels and the shadow-table entry are in flight
     ArgsC r = {a->ambient, {B.hdr16, A.debug, B.tm, a->exposure, a->inv_gamma, a->out_ldr, a->out_hdr}, a->g.c, a->g.d, a->g.e};
     asm volatile("" : "+s"(r.ambient), "+s"(r.st.exposure), "+s"(r.st.inv_gamma), "+s"(r.st.out_ldr), "+s"(r.st.out_hdr), "+s"(r.gc), "+s"(r.gd), "+s"(r.ge));
+    return r;
+}
+// what the fast tile's epilogue needs (ambient term, post_process, the store), as ONE set of scalar registers: taken from the batches
+// above for a tile without a lit pixel, loaded again BEHIND the light loop for a tile with one -- so that none of it occupies scalar
+// registers through the loop.  (The SIMD's scalar register file decides the kernel's occupancy as much as the vector one does:
+// tools/experiments/occupancy2.hip -- 7 waves need <= 96 SGPRs, 8 waves <= 80, whatever the VGPR count allows.)
+struct EpiArgs { StoreArgs st; uint8_t *out; uint32_t width, row0_in_tile; float ambient; };
+__device__ __forceinline__ EpiArgs epi_args(KernArgs a) {
+    EpiArgs r = {{a->hdr16, a->debug, a->tm_method, a->exposure, a->inv_gamma, a->out_ldr, a->out_hdr}, a->out_rgba8, a->width, a->row0_in_tile, a->ambient};
+    asm volatile("" : "+s"(r.st.hdr16), "+s"(r.st.debug), "+s"(r.st.tm), "+s"(r.st.exposure), "+s"(r.st.inv_gamma), "+s"(r.st.out_ldr), "+s"(r.st.out_hdr), "+s"(r.out),
+                 "+s"(r.width), "+s"(r.row0_in_tile), "+s"(r.ambient));
     return r;
 }
 __device__ __forceinline__ ShadowArgs shadow_args(SP sp) { ShadowArgs r = {sp.shadow_map, sp.shadow_bounds, sp.shadow_size, sp.bounds_pitch}; return r; }
@@ -112,6 +142,10 @@ __device__ __forceinline__ float pow_fast(float x, float e) {   // x >= 0
     return __builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf(x));
 }
 
+// the lane's index in its wave, computed afresh wherever it is asked for (two instructions; volatile: never merged with an earlier one):
+// a lane index kept in a register lives through the light loop just to address the store behind it
+__device__ __forceinline__ uint32_t wave_lane() { uint32_t l; asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l)); return l; }
+
 // PI = 3.14159265 as written at forward.hlsl:1
 constexpr float INV_PI = 1.0f / 3.14159265f;
 
@@ -139,15 +173,30 @@ struct TexS { const uint8_t *texels; uint32_t w, h, packed; float wf, hf; uint32
 // of the waterfall loop, replaces the uniform m by the per-lane mat it equals there, and issues a vector load per lane.
 typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 typedef uint32_t u8v __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ TexS tex_desc(const TexDesc *tex, uint32_t i /* wave-uniform */) {
-    u8v v;
-    asm("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(tex + i));   // not volatile: a side-effecting asm would stop the compiler from using scalar loads for the lights
+__device__ __forceinline__ TexS tex_decode(const u8v &v) {
     TexS t;
     t.texels = reinterpret_cast<const uint8_t *>(((unsigned long long)v[1] << 32) | v[0]);
     t.w = v[2] & 0x7FFFFFFFu; t.h = v[3];
     t.packed = v[2] >> 31;   // TexDesc::w bit 31
     t.wf = __uint_as_float(v[4]); t.hf = __uint_as_float(v[5]); t.pitch = v[6];
     return t;
+}
+__device__ __forceinline__ TexS tex_desc(const TexDesc *tex, uint32_t i /* wave-uniform */) {
+    u8v v;
+    asm("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(tex + i));   // not volatile: a side-effecting asm would stop the compiler from using scalar loads for the lights
+    return tex_decode(v);
+}
+// The same in two steps, for the fast tile: the descriptor's load goes out as soon as the material is known and is waited for only
+// behind the shadow-coordinate arithmetic (some twenty vector instructions that do not need it), instead of a scalar-cache round trip
+// with nothing to do.  `before` / `after`: a value the work in between starts from / ends with, passed through the two statements so
+// that data flow, not the scheduler's mood, keeps that work between them.  tools/isa_lint.py checks that nothing touches the
+// destination registers before the wait.
+__device__ __forceinline__ void tex_desc_issue(const TexDesc *tex, uint32_t i /* wave-uniform */, u8v &v, float &before) {
+    asm volatile("s_load_dwordx8 %0, %2, 0x0" : "=&s"(v), "+v"(before) : "s"(tex + i));
+}
+__device__ __forceinline__ TexS tex_desc_wait(u8v &v, uint32_t &after) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v), "+v"(after));
+    return tex_decode(v);
 }
 
 // load through a WAVE-UNIFORM base pointer (SGPR pair) and a 32-bit per-lane byte offset: one global_load with the saddr
@@ -260,8 +309,6 @@ __device__ __noinline__ float shadow_generic(const float *__restrict__ map, uint
 //                  evaluates the 25 bilinear compares from registers in the oracle's operation order (horizontal lerps are
 //                  shared between taps, which does not change any tap's value).
 // Lanes near the map border (WRAP would engage) or with a wider footprint use shadow_generic.
-// floor and convert in one instruction (exact for |x| < 2^31)
-__device__ __forceinline__ int floor_to_int(float x) { int i; asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(i) : "v"(x)); return i; }
 
 __device__ __forceinline__ float shadow_window(const float *__restrict__ map, uint32_t S, float px, float py, float pz) {
 #pragma clang fp contract(off)
@@ -362,37 +409,19 @@ __device__ __forceinline__ bool shadow_lds_tile(const ShadowArgs &sa, float *til
 
 // 1 - shadow in two steps.  shadow_quick decides from the bounds table where it can (and for every pixel outside the map);
 // returns false for the lanes that need shadow_slow: tiles on a shadow edge, the map's border, maps above 5000^2.
-struct ShadowPos { float px, py, pz; };
-// light-space position -> shadow-map coordinates, forward.hlsl:69-74
-__device__ __forceinline__ void shadow_coords(float lsx, float lsy, float lsz, float lsw, ShadowPos &p) {
-#pragma clang fp contract(off)
-    if (__ballot(lsw != 1.0f) == 0ull) { p.px = lsx; p.py = lsy; p.pz = lsz; }   // orthographic sun: w == 1, x / 1 == x
-    else { p.px = lsx / lsw; p.py = lsy / lsw; p.pz = lsz / lsw; }
-    p.px = p.px * 0.5f + 0.5f;
-    p.py = p.py * 0.5f + 0.5f;
-    p.py = 1.0f - p.py;
-}
-// the bounds-table entry that covers all 25 taps of p (byte offset into sp.shadow_bounds), or false: outside the table's reach
-__device__ __forceinline__ bool shadow_table_entry(const ShadowArgs &sa, const ShadowPos &p, uint32_t &offset) {
-#pragma clang fp contract(off)
-    // first texel of tap 0 (u_0 = px - 2e-4) per axis.  0 <= bx < S - 3 means: inside the map with three more texels after it,
-    // so 0 < px < 1, no tap wraps, and -- the taps spanning 4e-4 S < 2 texels -- every texel a tap reads lies in [bx, bx + 3]
-    const uint32_t S = sa.S;
-    const float Sf = (float)S;
-    const int bx = floor_to_int((p.px + -0.0002f) * Sf - 0.5f), by = floor_to_int((p.py + -0.0002f) * Sf - 0.5f);
-    offset = (((uint32_t)by >> 2) * sa.pitch + ((uint32_t)bx >> 2)) * 8u;
-    return (uint32_t)bx < S - 3u && (uint32_t)by < S - 3u && !(p.pz > 1.0f);
-}
+// (ShadowPos, shadow_coords, shadow_table_offset: shadow_coords.h, shared with the prepass's cost hint)
+__device__ __forceinline__ bool shadow_table_entry(const ShadowArgs &sa, const ShadowPos &p, uint32_t &offset) { return shadow_table_offset(sa.S, sa.pitch, p, offset); }
 // in two steps, so that a caller can put other work (a batch of scalar loads) between the table load and its use:
 //   shadow_quick_issue   coordinates + the load of the table entry; returns whether the pixel is within the table's reach
 //   shadow_quick_decide  lit = 0 / 1 where the entry (or the map's border rule) decides; false: the pixel needs shadow_slow
-__device__ __forceinline__ bool shadow_quick_issue(const ShadowArgs &sa, float lsx, float lsy, float lsz, float lsw, ShadowPos &p, float2 &mm) {
+__device__ __forceinline__ bool shadow_quick_issue(const ShadowArgs &sa, float lsx, float lsy, float lsz, float lsw, ShadowPos &p, float2 &mm, uint32_t *offset_out = nullptr) {
     mm = make_float2(0.0f, 0.0f);
     if (sa.map == nullptr) return false;
     shadow_coords(lsx, lsy, lsz, lsw, p);
-    uint32_t offset;
+    uint32_t offset = 0;
     const bool in_table = sa.bounds != nullptr && shadow_table_entry(sa, p, offset);   // (a table only for S <= 4900: shadow_bounds_pitch)
     if (in_table) mm = gload_f2(sa.bounds, offset);
+    if (offset_out) *offset_out = offset;
     return in_table;
 }
 __device__ __forceinline__ bool shadow_quick_decide(const ShadowArgs &sa, bool in_table, const ShadowPos &p, float2 mm, float &lit) {
@@ -435,16 +464,26 @@ struct LoopPix {
     float a2, oma2, c4;   // roughness^4, 1 - roughness^4, -(1 - roughness^4) / 4
     float q2, q1, q0;
 };
+// What the tail needs of a pixel is kept through the light loop as FIVE values (base colour, metalness, num) and turned into the
+// per-channel factors F0, 1 - F0, kdb only behind the loop (tail_factors): nine registers fewer across it than the factors themselves
+// (round 4: with them the kernel spilled 8 bytes per lane around the loop, i.e. needed a scratch allocation for every wave).
 struct TailPix {
-    f3 F0, omF0, kdb;
-    float num;
+    f3 base;
+    float metal, num;
 };
+struct TailFactors { f3 F0, omF0, kdb; float num; };
+__device__ __forceinline__ TailFactors tail_factors(const TailPix &t) {
+    TailFactors f;
+    f.F0 = mk(fm(t.metal, t.base.x - 0.04f, 0.04f), fm(t.metal, t.base.y - 0.04f, 0.04f), fm(t.metal, t.base.z - 0.04f, 0.04f));   // lerp(0.04, base, metal) :181-182
+    f.omF0 = mk(1.0f - f.F0.x, 1.0f - f.F0.y, 1.0f - f.F0.z);
+    const float km = (1.0f - t.metal) * INV_PI;
+    f.kdb = mk(t.base.x * km, t.base.y * km, t.base.z * km);
+    f.num = t.num;
+    return f;
+}
 __device__ __forceinline__ void make_pix(f3 n, f3 wo, f3 world, f3 base, float metal, float rough, LoopPix &p, TailPix &t) {
     p.n = n; p.wo = wo; p.world = world;
-    t.F0 = mk(fm(metal, base.x - 0.04f, 0.04f), fm(metal, base.y - 0.04f, 0.04f), fm(metal, base.z - 0.04f, 0.04f));   // lerp(0.04, base, metal) :181-182
-    t.omF0 = mk(1.0f - t.F0.x, 1.0f - t.F0.y, 1.0f - t.F0.z);
-    const float km = (1.0f - metal) * INV_PI;
-    t.kdb = mk(base.x * km, base.y * km, base.z * km);
+    t.base = base; t.metal = metal;
     const float ndwo = fmaxf(dot(n, wo), 0.0f);
     const float a = rough * rough, a2 = a * a;
     p.a2 = a2; p.oma2 = 1.0f - a2; p.c4 = -0.25f * p.oma2;
@@ -539,7 +578,8 @@ __device__ __forceinline__ v2 rcp2_and_mul(v2 a, v2 x, v2 y, v2 &t) {           
 
 struct Sums { float a[3], b[3], c[3]; };                     // scalar loop
 struct Sums2 { v2 a[3], b[3], c[3]; };                       // packed loop: .x/.y = the two lights of a pair
-__device__ __forceinline__ f3 resolve_sums(const TailPix &t, const float A[3], const float B[3], const float C[3]) {
+__device__ __forceinline__ f3 resolve_sums(const TailPix &tp, const float A[3], const float B[3], const float C[3]) {
+    const TailFactors t = tail_factors(tp);
     return mk(fm(t.kdb.x * t.omF0.x, A[0], t.num * fm(t.F0.x, B[0], t.omF0.x * C[0])),
               fm(t.kdb.y * t.omF0.y, A[1], t.num * fm(t.F0.y, B[1], t.omF0.y * C[1])),
               fm(t.kdb.z * t.omF0.z, A[2], t.num * fm(t.F0.z, B[2], t.omF0.z * C[2])));
@@ -858,26 +898,50 @@ __device__ __forceinline__ f3 lit_radiance(SP sp, uint32_t lane, float nr, float
 // G-buffer planes c, d, e): loaded from the G-buffer, or interpolated on the spot by the visibility-buffer kernel.
 template <int LOOP, bool STATS, class Second>
 __device__ __forceinline__ bool shade_tile_fast(SP sp, KernArgs args, const ArgsA &A, const float *lut, uint32_t ty, uint32_t tx, uint32_t lane, const TileHead &cur, Second second) {
-    const ArgsB B = args_b(args);   // (the head of the tile is in flight)
+    ArgsB B = args_b(args);   // (the head of the tile is in flight)
     const int32_t row0 = (int32_t)(ty * 8) - (int32_t)B.row0_in_tile;   // the tile's first pixel row in the target (wave-uniform)
     if ((A.debug & (1 | 2 | 4 | 256)) != 0 || tx * 8 + 8 > B.width || row0 < 0 || row0 + 8 > (int32_t)B.rows) return false;
     if (B.sh.map != nullptr && B.sh.bounds == nullptr) return false;
     const uint32_t mat = __float_as_uint(cur.b2);
     const uint32_t m0 = __builtin_amdgcn_readfirstlane(mat);
     if (m0 >= A.n_materials || __ballot(mat != m0) != 0ull) return false;
-    const TexS d0 = tex_desc(B.tex, m0 * 3);
-    if (!d0.packed) return false;
-    // ---- A: material fetch, forward.hlsl:98-124: the two 16-byte texel loads stay in flight over the shadow test
-    Taps pt;
-    fetch_taps_packed(d0, cur.a.x, cur.a.y, pt);
-    // ---- B: shadow test, forward.hlsl:68-96, from the bounds table alone: the entry's load goes out, the next batch of arguments
-    // arrives in its shadow
+    u8v dv;
+    float lsx = cur.a.z;
+    tex_desc_issue(B.tex, m0 * 3, dv, lsx);   // the material's descriptor: in flight over the shadow coordinates
+    // ---- B: shadow test, forward.hlsl:68-96, from the bounds table alone: the entry's load goes out first (it decides whether the
+    // tile's second wave of loads is needed, and loads come back in the order they were asked for)
     ShadowPos spos;
     float2 mm;
-    const bool in_table = shadow_quick_issue(B.sh, cur.a.z, cur.a.w, cur.b0, cur.b1, spos, mm);
-    const ArgsC C = args_c(args, A, B);
+    uint32_t toff = 0;
+    const bool in_table = shadow_quick_issue(B.sh, lsx, cur.a.w, cur.b0, cur.b1, spos, mm, &toff);
+    // ---- A: material fetch, forward.hlsl:98-124: two 16-byte texel loads
+    TexS d0 = tex_desc_wait(dv, toff);
+    if (!d0.packed) return false;
+    Taps pt;
+    fetch_taps_packed(d0, cur.a.x, cur.a.y, pt);
+    ArgsC C = args_c(args, A, B);   // the next batch of arguments arrives in the shadow of those loads
     float lit;
-    if (__ballot(!shadow_quick_decide(B.sh, in_table, spos, mm, lit)) != 0ull) return false;   // a tile on a shadow edge (or at the map's border)
+    const bool decided = shadow_quick_decide(B.sh, in_table, spos, mm, lit);
+    if (__ballot(!decided) != 0ull) {   // a tile on a shadow edge (a tenth of the benchmark frame's tiles), or at the map's border
+        // Round 4: the 25 taps of the undecided pixels are taken here, with the texel loads above still in flight, instead of handing the
+        // tile to the general code, which started over (descriptor, texels, table entry -- three more memory round trips).
+#if !ARCTIC_EDGE_IN_FAST
+        return false;
+#endif
+        if (B.sh.S > 5000u) return false;   // (no 4x4 window for such maps: the general tile)
+        // the 25-tap code is what would set the kernel's register count: the footprint's texels are given up across it (an empty asm
+        // "writes" every component) and asked for again behind it -- cache hits, and such tiles are few
+        asm("" : "=v"(pt.r0.x), "=v"(pt.r0.y), "=v"(pt.r0.z), "=v"(pt.r0.w), "=v"(pt.r1.x), "=v"(pt.r1.y), "=v"(pt.r1.z), "=v"(pt.r1.w));
+        asm("" : "=v"(pt.w00), "=v"(pt.w10), "=v"(pt.w01), "=v"(pt.w11));
+        if (!decided) lit = 1.0f - shadow_window(B.sh.map, B.sh.S, spos.px, spos.py, spos.pz);
+        // ... and so are the argument batches and the descriptor (the 25 taps hold a dozen lane masks in scalar registers: with the
+        // batches alive across them the kernel would pass 96 SGPRs, i.e. lose a wave per SIMD): loaded again, two scalar round trips
+        asm volatile("" : "+s"(args));
+        B = args_b(args);
+        C = args_c(args, A, B);
+        d0 = tex_desc(B.tex, m0 * 3);
+        fetch_taps_packed(d0, cur.a.x, cur.a.y, pt);
+    }
     // exact culling: Lo of ps_main is a sum of terms each multiplied by (1 - shadow) (point lights too: forward.hlsl:222,
     // 230), so a fully shadowed pixel is ambient * base and needs neither the sun, nor any point light, nor its normal,
     // tangent frame, position, metalness or roughness.
@@ -886,18 +950,28 @@ __device__ __forceinline__ bool shade_tile_fast(SP sp, KernArgs args, const Args
     if (live) second(C.gc, C.gd, C.ge, gc, gd, ge);   // second wave of loads: lit pixels only (48 B / pixel, whole 128-byte tile rows)
     // ---- C: base colour
     const f3 base = mk(filt_srgb<0>(pt, lut), filt_srgb<1>(pt, lut), filt_srgb<2>(pt, lut));
-    f3 color = base * C.ambient;
-    // ---- D: the lights
-    if (live) {
-        const f3 Lo = lit_radiance<LOOP, STATS>(sp, lane, filt_bytes<0, 3>(pt), filt_bytes<1, 0>(pt), filt_bytes<1, 1>(pt),
-                                                filt_unorm<1, 2>(pt), filt_unorm<1, 3>(pt),   // metal-rough .g, .b (forward.hlsl:117,123)
-                                                base, gc, gd, ge);
-        color = mk(__builtin_fmaf(Lo.x, lit, color.x), __builtin_fmaf(Lo.y, lit, color.y), __builtin_fmaf(Lo.z, lit, color.z));
-    }
+    // ---- D: the lights.  (The ambient term is formed behind the light loop on either side of the branch: formed in front of it, it
+    // would occupy three registers through the loop.)
+    EpiArgs E = {C.st, B.out, B.width, B.row0_in_tile, C.ambient};
+    f3 color;
+    if (__ballot(live) != 0ull) {   // (wave-uniform: the epilogue's arguments stay scalar on either side)
+        if (live) {
+            const f3 Lo = lit_radiance<LOOP, STATS>(sp, lane, filt_bytes<0, 3>(pt), filt_bytes<1, 0>(pt), filt_bytes<1, 1>(pt),
+                                                    filt_unorm<1, 2>(pt), filt_unorm<1, 3>(pt),   // metal-rough .g, .b (forward.hlsl:117,123)
+                                                    base, gc, gd, ge);
+            color = Lo;
+        }
+        asm volatile("" : "+s"(args));
+        E = epi_args(args);
+        const f3 amb = base * E.ambient;
+        if (live) color = mk(__builtin_fmaf(color.x, lit, amb.x), __builtin_fmaf(color.y, lit, amb.y), __builtin_fmaf(color.z, lit, amb.z));
+        else color = amb;
+    } else color = base * E.ambient;
     // ---- E: post_process + store: the tile's first pixel is a scalar address, the lane adds (lane >> 3) rows + (lane & 7)
-    const uint32_t tile_px = (uint32_t)row0 * B.width + tx * 8;
-    const uint32_t o = __umul24(lane >> 3, B.width) + (lane & 7u);   // (width <= 16384)
-    store_pixel(C.st, B.out + (size_t)tile_px * 4u, o, tile_px + o, color);
+    const uint32_t tile_px = (ty * 8 - E.row0_in_tile) * E.width + tx * 8;   // (the tile is wholly inside the target: ty * 8 >= row0_in_tile)
+    const uint32_t l2 = wave_lane();
+    const uint32_t o = __umul24(l2 >> 3, E.width) + (l2 & 7u);   // (width <= 16384)
+    store_pixel(E.st, E.out + (size_t)tile_px * 4u, o, tile_px + o, color);
     return true;
 }
 
@@ -1020,18 +1094,19 @@ __device__ __forceinline__ void shade_tile(SP sp, const float *lut, float *shado
 // was shaded.  Per tile 4 x u64: s_memrealtime (the 100 MHz reference clock, the same on every XCD) at the start and the end of its
 // wave's work, HW_ID | XCC_ID << 32 (which XCD / SE / CU / SIMD / wave slot) | reference-clock ticks between the kernel's entry and the start << 40, and 1 = the fast tile | shader-clock ticks (s_memtime)
 // between start and end << 8.  tools/experiments/tile_trace.py turns it into per-SIMD timelines.
-struct TraceStart { unsigned long long entry, real, core; };
+// Nothing of it lives in registers across a tile (six scalar registers through the whole kernel, when it did): the start stamps go to the
+// trace buffer at once and trace_end reads them back.  `entry`: the wave's first tile only (0: a later tile of the wave).
 __device__ __forceinline__ unsigned long long trace_entry() { return __builtin_amdgcn_s_memrealtime(); }   // first thing in the kernel (unconditional: asking whether anyone traces would be a scalar round trip in front of everything)
-__device__ __forceinline__ TraceStart trace_begin(SP sp, unsigned long long entry) {   // in front of a tile's work (the pointer's load: in the shadow of the tile's first bytes.
-    TraceStart t = {entry, 0ull, 0ull};                                                  //  Asking ArgsA::debug instead trips the compiler: "illegal VGPR to SGPR copy" in the scalar-loop kernels)
-    if (sp.trace) { t.real = __builtin_amdgcn_s_memrealtime(); t.core = __builtin_amdgcn_s_memtime(); }
-    return t;
+__device__ __forceinline__ void trace_begin(SP sp, size_t tile, unsigned long long entry) {   // in front of a tile's work (the pointer's load: in the shadow of the tile's first bytes.
+    if (!sp.trace) return;                                                                       //  Asking ArgsA::debug instead trips the compiler: "illegal VGPR to SGPR copy" in the scalar-loop kernels)
+    const unsigned long long real = __builtin_amdgcn_s_memrealtime(), core = __builtin_amdgcn_s_memtime();
+    if (wave_lane() == 0) { unsigned long long *o = sp.trace + tile * 4; o[0] = real; o[2] = (entry ? real - entry : 0ull) << 40; o[3] = core; }
 }
-__device__ __forceinline__ void trace_end(SP sp, const ArgsA &A, size_t tile, uint32_t lane, TraceStart t0, bool fast) {
+__device__ __forceinline__ void trace_end(SP sp, const ArgsA &A, size_t tile, bool fast) {
     if (!(A.debug & DEBUG_TRACE)) return;
     const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long hw = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);   // HW_REG_HW_ID, HW_REG_XCC_ID
-    if (lane == 0) { unsigned long long *o = sp.trace + tile * 4; o[0] = t0.real; o[1] = r1; o[2] = hw | ((t0.real - t0.entry) << 40); o[3] = (fast ? 1ull : 0ull) | ((c1 - t0.core) << 8); }
+    if (wave_lane() == 0) { unsigned long long *o = sp.trace + tile * 4; o[1] = r1; o[2] |= hw; o[3] = (fast ? 1ull : 0ull) | ((c1 - o[3]) << 8); }
 }
 
 // the kernel's argument block (its only parameter, at offset 0 of the kernarg segment)
@@ -1058,46 +1133,79 @@ __device__ __forceinline__ void lut_store(float *lut, uint32_t lane, const LutRe
 // A workgroup = 4 horizontally adjacent tiles (they share texture and shadow-map lines), T times; XCD x takes the tile rows
 // y = x (mod 8), walking each row left to right.  grid = (8 x workgroups per tile row, 1 / T of the groups of 8 tile rows): the
 // linear block id advances along x first, so id % 8 = x % 8.  (Placement is a speed matter only; surplus blocks exit.)
-// tile row of the wave's k-th tile, or false: none
-__device__ __forceinline__ bool tile_row(const ArgsA &A, uint32_t k, uint32_t &ty) {
-    const uint32_t g = blockIdx.y + k * A.stride;   // the block's groups of 8 tile rows: blockIdx.y + k stride
-    ty = g * 8 + (blockIdx.x & 7u);
+// WITH A DISPATCH ORDER (round 4; ShadeParams::tile_order, written by the G-buffer prepass: geometry.hip k_tile_order) the grid is one-
+// dimensional and block b takes the jobs b T ... b T + T - 1 of the list, a job = a strip of 4 horizontally adjacent tiles: the
+// prepass knows which tiles can be lit at all, and deals those evenly over the dispatch, the last stretch excepted.
+// The wave's next tile from job k on: true with (tx, ty) and k = the job taken; false: no more work for this wave.
+// Workgroups of ONE wave (ARCTIC_WG_WAVES == 1): the four tiles of a strip are the blocks b, b + 8, b + 16, b + 24 of a group of 32 -- the
+// same XCD (blocks are dealt round-robin over the 8 XCDs), so what the strip's tiles share still meets in one L2 -- and the strip is
+// block (b >> 5) * 8 + (b & 7) of the 4-wave numbering below.
+struct BlockId { uint32_t x, y, wave; };
+__device__ __forceinline__ BlockId block_id() {
+    BlockId b;
+    if (ARCTIC_WG_WAVES == 1) { b.x = (blockIdx.x >> 5) * 8 + (blockIdx.x & 7u); b.wave = (blockIdx.x >> 3) & 3u; }
+    else { b.x = blockIdx.x; b.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
+    b.y = blockIdx.y;
+    return b;
+}
+__device__ __forceinline__ bool next_tile(const ArgsA &A, const OrderArgs &O, const BlockId &b, uint32_t &k, uint32_t &tx, uint32_t &ty) {
+    if (O.order) {
+        for (; k < A.T; ++k) {
+            const uint32_t j = b.x * A.T + k;
+            if (j >= O.n_jobs) return false;
+            const uint32_t e = O.order[j];
+            ty = e >> 16; tx = (e & 0xFFFFu) * 4 + b.wave;
+            if (tx < A.tiles_x && ty < A.tiles_y) return true;   // (a strip at the right edge may hold fewer than 4 tiles)
+        }
+        return false;
+    }
+    tx = (b.x >> 3) * 4 + b.wave;
+    if (k >= A.T || tx >= A.tiles_x) return false;
+    const uint32_t g = b.y + k * A.stride;   // the block's groups of 8 tile rows: blockIdx.y + k stride
+    ty = g * 8 + (b.x & 7u);
     return g < ((A.tiles_y + 7u) >> 3) && ty < A.tiles_y;
 }
 template <int LOOP, bool STATS, bool LDS_SHADOW>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_material(const ShadeParams sp_by_value) {
+__global__ __launch_bounds__(64 * ARCTIC_WG_WAVES) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_material(const ShadeParams sp_by_value) {
     __shared__ float lut[256];
-    __shared__ float shadow_tiles[LDS_SHADOW ? 4 : 1][LDS_SHADOW ? SHADOW_TILE * SHADOW_TILE : 1];   // one per wave (the LDS variant of the PCF slow path)
+    __shared__ float shadow_tiles[LDS_SHADOW ? ARCTIC_WG_WAVES : 1][LDS_SHADOW ? SHADOW_TILE * SHADOW_TILE : 1];   // one per wave (the LDS variant of the PCF slow path)
     KernArgs args = kernel_args();
-    const unsigned long long t_entry = trace_entry();
-    uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t tx = (blockIdx.x >> 3) * 4 + wave;
+    unsigned long long t_entry = trace_entry();
+    const BlockId blk = block_id();
+    const uint32_t wave = ARCTIC_WG_WAVES == 1 ? 0u : blk.wave;   // (of the workgroup: which LDS shadow tile is this wave's)
     const float *srgb_lut;
     const unsigned long long *vis_unused;
-    ArgsA A = args_a_first(args, srgb_lut, vis_unused);
-    uint32_t ty;
-    if (tx >= A.tiles_x || !tile_row(A, 0, ty)) return;
-    const LutRegs lr = lut_load(srgb_lut, lane);                                           // an L2 hit: back first ...
-    TileHead cur = load_head(A.ga, A.gb, (size_t)ty * A.tiles_x + tx, lane);              // ... while the tile's first bytes travel
-    lut_store(lut, lane, lr);
+    OrderArgs O;
+    ArgsA A = args_a_first(args, srgb_lut, vis_unused, O);
+    uint32_t tx, ty, k = 0;
+    if (!next_tile(A, O, blk, k, tx, ty)) return;
+    TileHead cur;
+    {
+        const uint32_t lane = wave_lane();
+        const LutRegs lr = lut_load(srgb_lut, lane);                                       // an L2 hit: back first ...
+        cur = load_head(A.ga, A.gb, (size_t)ty * A.tiles_x + tx, lane);                   // ... while the tile's first bytes travel
+        lut_store(lut, lane, lr);
+    }
 #pragma nounroll
-    for (uint32_t k = 0;;) {
-        asm volatile("" : "+s"(args), "+v"(lane));   // see SP
+    for (;;) {
+        asm volatile("" : "+s"(args));   // see SP
         SP sp = *args;
-        const TraceStart t0 = trace_begin(sp, t_entry);
+        const uint32_t lane = wave_lane();
         const size_t tile = (size_t)ty * A.tiles_x + tx;   // wave-uniform
+        trace_begin(sp, tile, t_entry);
+        t_entry = 0ull;
         const auto second = [&](const float4 *pc, const float4 *pd, const float4 *pe, float4 &gc, float4 &gd, float4 &ge) {
             gc = gload_f4(pc + tile * 64, lane * 16u); gd = gload_f4(pd + tile * 64, lane * 16u); ge = gload_f4(pe + tile * 64, lane * 16u);
         };
         const bool fast = shade_tile_fast<LOOP, STATS>(sp, args, A, lut, ty, tx, lane, cur, second);
         if (!fast) shade_tile<LOOP, STATS, LDS_SHADOW>(sp, lut, shadow_tiles[LDS_SHADOW ? wave : 0], ty, tx, lane, cur, second);
-        trace_end(sp, A, tile, lane, t0, fast);
+        trace_end(sp, A, tile, fast);
         if (++k >= A.T) break;
         asm volatile("" : "+s"(args));
         A = args_a(args);                      // (nothing of the block stays in registers across a tile)
-        if (!tile_row(A, k, ty)) break;
-        cur = load_head(A.ga, A.gb, (size_t)ty * A.tiles_x + tx, lane);
+        O = order_args(args);
+        if (!next_tile(A, O, blk, k, tx, ty)) break;
+        cur = load_head(A.ga, A.gb, (size_t)ty * A.tiles_x + tx, wave_lane());
     }
 }
 
@@ -1108,27 +1216,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
 // for the lit ones -- with the very operations of k_resolve (edges.h, fp contraction off), so the pixels are bit-identical
 // to the G-buffer path.  Everything after the attributes is shade_tile, shared.
 template <int LOOP, bool STATS, bool LDS_SHADOW>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_material_vis(const ShadeParams sp_by_value) {
+__global__ __launch_bounds__(64 * ARCTIC_WG_WAVES) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_material_vis(const ShadeParams sp_by_value) {
     __shared__ float lut[256];
-    __shared__ float shadow_tiles[LDS_SHADOW ? 4 : 1][LDS_SHADOW ? SHADOW_TILE * SHADOW_TILE : 1];   // one per wave (the LDS variant of the PCF slow path)
+    __shared__ float shadow_tiles[LDS_SHADOW ? ARCTIC_WG_WAVES : 1][LDS_SHADOW ? SHADOW_TILE * SHADOW_TILE : 1];   // one per wave (the LDS variant of the PCF slow path)
     KernArgs args = kernel_args();
-    const unsigned long long t_entry = trace_entry();
-    uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t tx = (blockIdx.x >> 3) * 4 + wave;   // XCD-aware order, T tiles per wave, the LUT without a barrier: see k_material
-    const float *srgb_lut;
+    unsigned long long t_entry = trace_entry();
+    const BlockId blk = block_id();
+    const uint32_t wave = ARCTIC_WG_WAVES == 1 ? 0u : blk.wave;
+    const float *srgb_lut;     // XCD-aware order or the prepass's dispatch order, T tiles per wave, the LUT without a barrier: see k_material
     const unsigned long long *vis_plane;
-    ArgsA A = args_a_first(args, srgb_lut, vis_plane);
-    uint32_t ty;
-    if (tx >= A.tiles_x || !tile_row(A, 0, ty)) return;
-    const LutRegs lr = lut_load(srgb_lut, lane);
-    unsigned long long key = vis_plane[((size_t)ty * A.tiles_x + tx) * 64 + lane];
-    lut_store(lut, lane, lr);
+    OrderArgs O;
+    ArgsA A = args_a_first(args, srgb_lut, vis_plane, O);
+    uint32_t tx, ty, k = 0;
+    if (!next_tile(A, O, blk, k, tx, ty)) return;
+    unsigned long long key;
+    {
+        const uint32_t lane = wave_lane();
+        const LutRegs lr = lut_load(srgb_lut, lane);
+        key = vis_plane[((size_t)ty * A.tiles_x + tx) * 64 + lane];
+        lut_store(lut, lane, lr);
+    }
 #pragma nounroll
-    for (uint32_t k = 0;;) {
-    asm volatile("" : "+s"(args), "+v"(lane));   // see SP
+    for (;;) {
+    asm volatile("" : "+s"(args));   // see SP
     SP sp = *args;
-    const TraceStart t0 = trace_begin(sp, t_entry);
+    const uint32_t lane = wave_lane();
+    trace_begin(sp, (size_t)ty * A.tiles_x + tx, t_entry);
+    t_entry = 0ull;
     const int32_t px = (int32_t)(tx * 8 + (lane & 7));
     const int32_t py = (row_global((int)ty, sp.band_tiles, sp.shard_count, sp.shard_index) + sp.tile_y0) * 8 + (int32_t)(lane >> 3);
     TileHead cur;
@@ -1213,12 +1327,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     };
     const bool fast = shade_tile_fast<LOOP, STATS>(sp, args, A, lut, ty, tx, lane, cur, second);
     if (!fast) shade_tile<LOOP, STATS, LDS_SHADOW>(sp, lut, shadow_tiles[LDS_SHADOW ? wave : 0], ty, tx, lane, cur, second);
-    trace_end(sp, A, (size_t)ty * A.tiles_x + tx, lane, t0, fast);
+    trace_end(sp, A, (size_t)ty * A.tiles_x + tx, fast);
     if (++k >= A.T) break;
     asm volatile("" : "+s"(args));
     A = args_a(args);
-    if (!tile_row(A, k, ty)) break;
-    key = args->vis[((size_t)ty * A.tiles_x + tx) * 64 + lane];
+    O = order_args(args);
+    if (!next_tile(A, O, blk, k, tx, ty)) break;
+    key = args->vis[((size_t)ty * A.tiles_x + tx) * 64 + wave_lane()];
     }
 }
 
@@ -1263,8 +1378,9 @@ __global__ __launch_bounds__(256) void k_post_process(const float4 *__restrict__
 
 template <int LOOP, bool STATS, bool LDS_SHADOW>
 hipError_t launch_variant(const ShadeParams &sp, const ShadeLaunch &L, dim3 grid) {
-    if (L.from_vis) k_material_vis<LOOP, STATS, LDS_SHADOW><<<grid, 256, 0, L.stream>>>(sp);
-    else k_material<LOOP, STATS, LDS_SHADOW><<<grid, 256, 0, L.stream>>>(sp);
+    if (ARCTIC_WG_WAVES == 1) grid.x = (grid.x + 7) / 8 * 32;   // (block_id: four one-wave blocks per strip, a strip's blocks on one XCD)
+    if (L.from_vis) k_material_vis<LOOP, STATS, LDS_SHADOW><<<grid, 64 * ARCTIC_WG_WAVES, 0, L.stream>>>(sp);
+    else k_material<LOOP, STATS, LDS_SHADOW><<<grid, 64 * ARCTIC_WG_WAVES, 0, L.stream>>>(sp);
     return hipGetLastError();
 }
 
@@ -1282,7 +1398,11 @@ hipError_t launch_shade(const ShadeParams &sp_in, const ShadeLaunch &L) {
     sp.tiles_per_wave = L.tiles_per_wave ? L.tiles_per_wave : (n_tiles < SMALL_FRAME_TILES ? 1u : DEFAULT_TILES_PER_WAVE);
     const uint32_t bpr = (sp.tiles_x + 3) / 4, groups = (sp.tiles_y + 7) / 8;
     sp.group_stride = (groups + sp.tiles_per_wave - 1) / sp.tiles_per_wave;
-    const dim3 grid(8 * bpr, sp.group_stride);   // a block shades tiles_per_wave groups of 8 tile rows, group_stride groups apart
+    dim3 grid(8 * bpr, sp.group_stride);   // a block shades tiles_per_wave groups of 8 tile rows, group_stride groups apart
+    if (sp.tile_order) {                   // ... or tiles_per_wave consecutive jobs of the prepass's dispatch order
+        sp.n_jobs = bpr * sp.tiles_y;
+        grid = dim3((sp.n_jobs + sp.tiles_per_wave - 1) / sp.tiles_per_wave, 1);
+    }
     if (sp.debug & 16)   // A/B only: the 25-tap path staged through LDS (a separate instantiation: it costs the default kernels nothing)
         return L.loop == 2 ? launch_variant<2, false, true>(sp, L, grid) : launch_variant<1, false, true>(sp, L, grid);
     if (L.loop == 2) return L.stats ? launch_variant<2, true, false>(sp, L, grid) : launch_variant<2, false, false>(sp, L, grid);

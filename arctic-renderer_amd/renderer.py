@@ -242,6 +242,16 @@ class Renderer:
         self._check(self.L.arctic_read_tile_trace(self.h, _ptr(out), tx.value * ty.value, C.byref(tx), C.byref(ty)))
         return out
 
+    def tile_order(self):
+        """(order, classes): the dispatch order arctic_pass_gbuffer left for the shading pass -- one uint32 per strip of 4 tiles,
+        ty << 16 | strip column -- and the (tiles_y, tiles_x) uint8 cost classes it was built from (arctic_read_tile_order)."""
+        tx, ty = C.c_uint32(0), C.c_uint32(0)
+        self._check(self.L.arctic_read_tile_order(self.h, None, None, 0, C.byref(tx), C.byref(ty)))
+        order = np.zeros(((tx.value + 3) // 4) * ty.value, np.uint32)
+        classes = np.zeros((ty.value, tx.value), np.uint8)
+        self._check(self.L.arctic_read_tile_order(self.h, _ptr(order), _ptr(classes), tx.value * ty.value, C.byref(tx), C.byref(ty)))
+        return order, classes
+
     def bin_counts(self, shadow_pass=False):
         """(blocks_y, blocks_x) uint32: work items per 16x16 block of the latest forward / shadow prepass drawn with block
         owners (arctic_read_bin_counts)."""

@@ -301,6 +301,12 @@ int arctic_stats(ArcticRenderer *r, uint64_t *out, uint32_t n);
                                          for the exact binary64 planes, go through the merging atomicMin rasteriser afterwards.  Bit clear = atomicMin rasteriser
                                          only (round 2; the shadow pass is instruction bound, not atomic bound: measured slower with owners).  Same visibility /
                                          shadow map, bit for bit (D3D12's fixed-function raster of forward_pass.cpp:137-151,212-224 / shadow_map_pass.cpp:96-97,157-167) */
+#define ARCTIC_OPT_TILE_ORDER        19 /* 1 (default) = arctic_pass_gbuffer leaves, next to the G-buffer, a cost class per 8x8 tile (can a pixel of it be lit at all,
+                                          by the shadow map's min/max table -- the shading kernel's own first test) and from the classes the ORDER in which
+                                          arctic_pass_shade hands out its work: lit tiles dealt evenly over the dispatch, shadowed ones in between, the end of
+                                          the list shadowed ones only.  A hint: images never depend on it.  0 = the geometric order (takes effect at the next
+                                          G-buffer pass; a G-buffer written by arctic_write_gbuffer has no order) */
+#define ARCTIC_OPT_ORDER_TAIL        20 /* per mille of the dispatch order, at its end, that holds cheap tiles only (default 60) */
 #define ARCTIC_OPT_MARKERS          13 /* 1 = roctx ranges around each pass, named like the reference's Tracy zones (process-wide; libroctx64 is loaded on demand) */
 int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value);
 
@@ -310,6 +316,14 @@ int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value);
    start and end << 8.  out == NULL only reports the grid.  Synchronises.  No counterpart in
    the reference (its GPU timing is Tracy zones per pass, renderer.cpp:285-357); tools/experiments/tile_trace.py reads it. */
 int arctic_read_tile_trace(ArcticRenderer *r, uint64_t *out, uint64_t capacity_tiles, uint32_t *tiles_x, uint32_t *tiles_y);
+
+/* The dispatch order arctic_pass_gbuffer left for arctic_pass_shade (ARCTIC_OPT_TILE_ORDER) and the cost classes it was built from:
+   order = ceil(tiles_x / 4) * tiles_y entries, one per strip of 4 horizontally adjacent tiles, ty << 16 | strip column, in the order
+   the shading pass hands them out; tile_class = one byte per tile, row-major over the handle's tile grid, 1 = a pixel of the tile
+   can be lit (or takes the environment lookup).  Either pointer may be NULL; both NULL only reports the grid; capacity_tiles >=
+   tiles_x * tiles_y.  Synchronises.  A hint for the pass's scheduling, never part of a result; no counterpart in the reference
+   (its pixel shader is scheduled by the GPU's fixed function, forward_pass.cpp:212-224). */
+int arctic_read_tile_order(ArcticRenderer *r, uint32_t *order, uint8_t *tile_class, uint64_t capacity_tiles, uint32_t *tiles_x, uint32_t *tiles_y);
 
 /* Work items per 16x16 block of the latest forward (shadow_pass = 0) or shadow (1) prepass drawn with block owners
    (ARCTIC_OPT_RASTER_OWNER): blocks_x x blocks_y counters, row-major over the whole target; a block's owner drew the first 32, the

@@ -362,6 +362,7 @@ struct Oracle {
     std::vector<float> env; uint32_t env_w = 0, env_h = 0;   // skybox environment map (RGBA32F); empty = black
     int hdr16 = 0;        // 1: ps_main's colour passes through binary16 (the reference's RGBA16F target) before post_process
     int precision = 64;   // arithmetic of the BRDF/tonemap: 64 = float64 (parity arbiter), 32 = literal fp32 (CPU baseline)
+    int sampler_mode = 0; // SAMPLER_* bits: variants of what the reference leaves to the D3D12 sampler hardware (default: none)
     std::string err;
     uint32_t rows() const { return row_end - row_begin; }
 };
@@ -473,19 +474,30 @@ void pass_gbuffer(Oracle &o, const Scene &sc) {
 // ----------------------------------------------------------------------------
 struct Footprint { int x0, x1, y0, y1; float fx, fy; };
 
-inline void wrap_axis(float u, uint32_t n, int &i0, int &i1, float &f) {
+// SAMPLER VARIANTS (oracle_set_sampler_mode; default 0 = the semantics above, what the HIP kernels implement).  They exist to BOUND
+// what the reference leaves to the D3D12 hardware (forward_pass.cpp:38-51 only names the filter), not as alternatives to ship:
+//   bit 0  material textures: texel coordinates in D3D's fixed point -- the scaled coordinate u W - 0.5 snapped to 1/256 texel
+//          (round to nearest) before it is split into texel index and weight: 8-bit filter weights, what the D3D11.3 functional
+//          specification (3.2.4.1 / 7.18.8) allows a sampler to do and most hardware does
+//   bit 1  sRGB textures: the four texels filtered as stored (non-linear) and the RESULT decoded, instead of decoding each texel
+//          first (D3D10+ asks for decode-before-filter; the variant bounds what a non-conformant path would change)
+//   bit 2  shadow map (R32_FLOAT through the same sampler, forward.hlsl:68-96): the same 8-bit weights for the 25 PCF taps
+constexpr int SAMPLER_Q8_MATERIAL = 1, SAMPLER_SRGB_AFTER_FILTER = 2, SAMPLER_Q8_SHADOW = 4;
+
+inline void wrap_axis(float u, uint32_t n, int &i0, int &i1, float &f, bool q8 = false) {
     float uw = u - std::floor(u);
     float x = uw * (float)n - 0.5f;
+    if (q8) x = std::floor(x * 256.0f + 0.5f) / 256.0f;   // 24.8 fixed point, round to nearest
     float xf = std::floor(x);
     f = x - xf;
     i0 = (int)xf; i1 = i0 + 1;
     if (i0 < 0) i0 += (int)n;
     if (i1 >= (int)n) i1 -= (int)n;
 }
-inline Footprint footprint(float u, float v, uint32_t w, uint32_t h) {
+inline Footprint footprint(float u, float v, uint32_t w, uint32_t h, bool q8 = false) {
     Footprint f;
-    wrap_axis(u, w, f.x0, f.x1, f.fx);
-    wrap_axis(v, h, f.y0, f.y1, f.fy);
+    wrap_axis(u, w, f.x0, f.x1, f.fx, q8);
+    wrap_axis(v, h, f.y0, f.y1, f.fy, q8);
     return f;
 }
 inline float bilerp(float t00, float t10, float t01, float t11, float fx, float fy) {
@@ -496,14 +508,14 @@ float srgb_to_linear(uint8_t c) {
     float x = (float)c / 255.0f;
     return x <= 0.04045f ? x / 12.92f : std::pow((x + 0.055f) / 1.055f, 2.4f);
 }
-float sample_r32(const float *map, uint32_t S, float u, float v) {
-    Footprint f = footprint(u, v, S, S);
+float sample_r32(const float *map, uint32_t S, float u, float v, bool q8 = false) {
+    Footprint f = footprint(u, v, S, S, q8);
     return bilerp(map[(size_t)f.y0 * S + f.x0], map[(size_t)f.y0 * S + f.x1],
                   map[(size_t)f.y1 * S + f.x0], map[(size_t)f.y1 * S + f.x1], f.fx, f.fy);
 }
 
 // forward.hlsl:68-96 calculate_shadow (the `normal` argument is unused there: bias = 0)
-float calculate_shadow(const float *map, uint32_t S, V4 ls) {
+float calculate_shadow(const float *map, uint32_t S, V4 ls, bool q8 = false) {
     if (map == nullptr || S == 0) return 0.0f;   // config 1: no shadow map == map cleared to 1.0
     float px = ls.x / ls.w, py = ls.y / ls.w, pz = ls.z / ls.w;
     px = px * 0.5f + 0.5f;
@@ -516,7 +528,7 @@ float calculate_shadow(const float *map, uint32_t S, V4 ls) {
     for (int i = -2; i <= 2; ++i)
         for (int j = -2; j <= 2; ++j) {
             float ox = (float)i * 0.0001f, oy = (float)j * 0.0001f;
-            float closest = sample_r32(map, S, px + ox, py + oy);
+            float closest = sample_r32(map, S, px + ox, py + oy, q8);
             shadow += (current - bias) > closest ? 1.0f : 0.0f;
         }
     shadow /= 25.0f;
@@ -605,15 +617,20 @@ template <class R> Vec3<R> calculate_outgoing_radiance(Vec3<R> n, Vec3<R> wo, Ve
 // filtered RGBA of one material texture; texel selection and weights in fp32 (shared with the HIP kernel), the
 // filter arithmetic in R
 template <class R> void sample_rgba8_r(const Oracle &o, const Texture &t, float u, float v, bool srgb, R out[4]) {
-    Footprint f = footprint(u, v, t.w, t.h);
+    Footprint f = footprint(u, v, t.w, t.h, (o.sampler_mode & SAMPLER_Q8_MATERIAL) != 0);
+    const bool after = srgb && (o.sampler_mode & SAMPLER_SRGB_AFTER_FILTER) != 0;
     const uint8_t *p00 = &t.px[((size_t)f.y0 * t.w + f.x0) * 4], *p10 = &t.px[((size_t)f.y0 * t.w + f.x1) * 4];
     const uint8_t *p01 = &t.px[((size_t)f.y1 * t.w + f.x0) * 4], *p11 = &t.px[((size_t)f.y1 * t.w + f.x1) * 4];
     for (int c = 0; c < 4; ++c) {
         R a, b, cc, d;
-        if (srgb && c < 3) { a = o.srgb_lut[p00[c]]; b = o.srgb_lut[p10[c]]; cc = o.srgb_lut[p01[c]]; d = o.srgb_lut[p11[c]]; }
+        if (srgb && c < 3 && !after) { a = o.srgb_lut[p00[c]]; b = o.srgb_lut[p10[c]]; cc = o.srgb_lut[p01[c]]; d = o.srgb_lut[p11[c]]; }
         else { a = (R)p00[c] / R(255); b = (R)p10[c] / R(255); cc = (R)p01[c] / R(255); d = (R)p11[c] / R(255); }
         R top = rlerp(a, b, (R)f.fx), bot = rlerp(cc, d, (R)f.fx);
         out[c] = rlerp(top, bot, (R)f.fy);
+        if (after && c < 3) {   // the IEC 61966-2-1 curve on the filtered value
+            const double x = (double)out[c];
+            out[c] = (R)(x <= 0.04045 ? x / 12.92 : std::pow((x + 0.055) / 1.055, 2.4));
+        }
     }
 }
 
@@ -647,7 +664,7 @@ template <class R> Vec3<R> ps_main(const Oracle &o, const float *attr, uint32_t 
     Vec3<R> world = vec3<R>(attr[11], attr[12], attr[13]);
     Vec3<R> wo = normalize(eye - world);
     Vec3<R> Lo = vec3<R>(0, 0, 0);
-    R shadow = calculate_shadow(shadow_map, o.shadow_size, V4{attr[14], attr[15], attr[16], attr[17]});   // always fp32: k/25
+    R shadow = calculate_shadow(shadow_map, o.shadow_size, V4{attr[14], attr[15], attr[16], attr[17]}, (o.sampler_mode & SAMPLER_Q8_SHADOW) != 0);   // always fp32: k/25
     R lit = R(1) - shadow;
     Lo = Lo + calculate_outgoing_radiance<R>(s.n, wo, vec3<R>(-sun_dir_f.x, -sun_dir_f.y, -sun_dir_f.z), sun_color, s.base, s.metal, s.rough) * lit;
     for (size_t i = 0; i < o.lights.size(); ++i) {
@@ -1026,6 +1043,13 @@ int oracle_set_precision(void *h, int bits) {
     Oracle *o = static_cast<Oracle *>(h);
     if (!o || (bits != 32 && bits != 64)) return -1;
     o->precision = bits;
+    return 0;
+}
+// variants of the sampler the reference leaves to the hardware (SAMPLER_* bits above); 0 = the semantics the build implements
+int oracle_set_sampler_mode(void *h, int mode) {
+    Oracle *o = static_cast<Oracle *>(h);
+    if (!o || mode < 0 || mode > 7) return -1;
+    o->sampler_mode = mode;
     return 0;
 }
 int oracle_hardware_threads(void) { return (int)std::thread::hardware_concurrency(); }

@@ -87,6 +87,7 @@ def lib():
         L.oracle_to_unorm8.argtypes = [f32]
         L.oracle_hardware_threads.restype = i32
         L.oracle_set_precision.argtypes = [vp, i32]
+        L.oracle_set_sampler_mode.argtypes = [vp, i32]
         L.oracle_set_hdr16.argtypes = [vp, i32]
         L.oracle_create_hdri.argtypes = [vp, vp, u32, u32]
         L.oracle_sky_ray.argtypes = [vp, C.POINTER(Camera), u32, u32, vp]
@@ -123,6 +124,12 @@ class Oracle:
         """64 (default): BRDF/tonemap in float64 = the parity arbiter; 32: literal fp32 restatement (CPU baseline)."""
         assert self.L.oracle_set_precision(self.h, bits) == 0
         return self
+
+    def set_sampler_mode(self, mode):
+        """variants of what the reference leaves to the D3D12 sampler hardware (arctic_oracle.cpp SAMPLER_*): bit 0 material textures
+        with 8-bit filter weights, bit 1 sRGB decoded after filtering, bit 2 the shadow map's taps with 8-bit weights.  0 (default) =
+        the semantics the HIP kernels implement.  Used to BOUND the unpinned-parity gap, never as the checker."""
+        assert self.L.oracle_set_sampler_mode(self.h, int(mode)) == 0
 
     def set_hdr16(self, on):
         """route ps_main's colour through binary16 like the reference's RGBA16F target (forward_pass.cpp:149)."""

@@ -73,6 +73,22 @@ def test_config3_4k_frame_whole_frame_against_oracle(pkg, oracle, hip):
     r.close(); o.close()
 
 
+def test_config1_512_no_shadow_map_against_oracle(pkg, oracle, hip):
+    """config 1 at its real 512 x 512 (the reference's own CPU-runnable case: one sphere, one directional light, no shadow map, Reinhard):
+    prepass bit for bit, every pixel of the image against the float64 oracle, and the frame path gives the same bytes"""
+    sc = pkg.scenes.config1(scale=1.0)
+    assert (sc.width, sc.height, sc.shadow_size, len(sc.lights)) == (512, 512, 0, 0)
+    o, r = prepass_pair(pkg, oracle, hip, sc)
+    assert_prepass_bit_exact(sc, o, r)
+    o.pass_shade(sc.desc, sc.settings, threads=oracle.hardware_threads())
+    r.pass_shade(sc.desc, sc.settings)
+    o_ldr, _, o_rgba = o.read_output()
+    h_ldr, _, h_rgba = (x.copy() for x in r.read_output())
+    assert_image_parity(o_ldr, o_rgba, h_ldr, h_rgba)
+    np.testing.assert_array_equal(r.render_frame(sc.desc, sc.settings), h_rgba)
+    r.close(); o.close()
+
+
 def test_config2_1080p_2048_shadow_against_oracle(pkg, oracle, hip):
     """config 2 at its real size: 1920x1080, 2048^2 shadow map, sun only, Reinhard; 40 % of the frame is background."""
     sc = pkg.scenes.config2(scale=1.0)

@@ -37,10 +37,12 @@ res = {s: [] for s in specs}
 for _ in range(reps):
     for s in specs:   # a spec = path to a library, optionally followed by ,option=value,...
         lib, *opts = s.split(",")
-        env = dict(os.environ, ARCTIC_HIP_LIBRARY=os.path.abspath(lib))
+        env = dict(os.environ, ARCTIC_HIP_LIBRARY=os.path.abspath(lib), ARCTIC_HIP_LIBRARY_OLDER="1")   # (an earlier round's build may lack this round's entry points)
         o = subprocess.run([sys.executable, os.path.abspath(__file__), "--worker"] + opts, env=env, capture_output=True, text=True).stdout
         line = [l for l in o.splitlines() if l.startswith("TIMES")]
         if line: res[s].append([float(x) for x in line[0].split()[1:]])
+        else: print(f"{s}: the worker printed no times:\n{o[-2000:]}", flush=True)
 for s in specs:
+    if not res[s]: continue
     a = np.array(res[s])
     print(f"{s}: " + "  ".join(f"{n} {np.median(a[:, i]):.4f} ms ({a[:, i].min():.4f}-{a[:, i].max():.4f})" for i, n in enumerate(NAMES)), flush=True)

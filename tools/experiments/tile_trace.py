@@ -34,7 +34,8 @@ for n in [int(a) for a in sys.argv[1:] if "=" not in a] or (64, 16, 0):
     print(f"   tiles per SIMD {np.bincount(inv).min()}..{np.bincount(inv).max()}; resident waves per SIMD (wave time / span): mean {busy.mean() / span:.2f}, min {busy.min() / span:.2f}, max {busy.max() / span:.2f}")
     print(f"   shader-clock ticks per tile: median {int(np.median(core))}; long tiles (> 3 x median, {lit.mean() * 100:.1f} %): median {int(np.median(core[lit])) if lit.any() else 0}; "
           f"fast-tile share {fast.mean() * 100:.1f} %, general tiles: median {int(np.median(core[~fast])) if (~fast).any() else 0}; ticks per 10 ns: {np.median(core[lit] / dur[lit]) if lit.any() else np.median(core / dur):.1f}")
-    print(f"   from kernel entry to the start of the tile's work (kernel arguments, head loads, LUT staging, barrier): median {int(np.median(pro)) * 10} ns, 90 % {int(np.percentile(pro, 90)) * 10} ns; "
+    pro = pro[pro > 0] if (pro > 0).any() else pro      # (recorded for a wave's first tile only)
+    print(f"   from kernel entry to the start of a wave's first tile (kernel arguments, order entry): median {int(np.median(pro)) * 10} ns, 90 % {int(np.percentile(pro, 90)) * 10} ns; "
           f"tile's work: median {int(np.median(dur)) * 10} ns, long tiles {int(np.median(dur[lit])) * 10 if lit.any() else 0} ns; wave slot ids in use: {np.bincount(hwid & 15).tolist()}")
     edges = np.linspace(0, span, 21)
     occ = lambda m: " ".join(f"{np.clip(np.minimum(t1[m], b) - np.maximum(t0[m], a), 0, None).sum() / (b - a) / len(uniq):.1f}" for a, b in zip(edges[:-1], edges[1:]))

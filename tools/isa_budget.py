@@ -26,8 +26,8 @@ def classify(op):
     if op.startswith("ds_"): return "lds"
     return "other"
 
-def max_vgpr_per_block(path, key):
-    """highest VGPR index touched per basic block: where the kernel's register count comes from"""
+def max_vgpr_per_block(path, key, kind="v"):
+    """highest VGPR (kind "s": SGPR) index touched per basic block: where the kernel's register count comes from"""
     txt = kernel_text(path, key)
     cur, out = "entry", []
     mx = -1
@@ -37,8 +37,8 @@ def max_vgpr_per_block(path, key):
             out.append((cur, mx)); cur = m.group(1); mx = -1; continue
         s = l.strip()
         if not s or s.startswith((";", ".")): continue
-        for a, b in re.findall(r"v\[(\d+):(\d+)\]", s): mx = max(mx, int(b))
-        for a in re.findall(r"\bv(\d+)\b", s): mx = max(mx, int(a))
+        for a, b in re.findall(kind + r"\[(\d+):(\d+)\]", s): mx = max(mx, int(b))
+        for a in re.findall(r"\b" + kind + r"(\d+)\b", s): mx = max(mx, int(a))
     out.append((cur, mx))
     return out
 
@@ -82,9 +82,10 @@ def main():
         import json
         print(json.dumps(census(path, key), indent=1))
         return
-    if "--vgpr" in sys.argv:
-        for name, mx in max_vgpr_per_block(path, key):
-            if mx >= 0: print(f"{name:12s} max v{mx}")
+    if "--vgpr" in sys.argv or "--sgpr" in sys.argv:
+        kind = "v" if "--vgpr" in sys.argv else "s"
+        for name, mx in max_vgpr_per_block(path, key, kind):
+            if mx >= 0: print(f"{name:12s} max {kind}{mx}")
         return
     dump = "--dump" in sys.argv
     txt = kernel_text(path, key)
