@@ -419,7 +419,7 @@ int run_geometry(ArcticRenderer *r, const ArcticScene *sc, bool shadow_pass, hip
     }
     gp.raster_flags = (r->debug & 32) ? 1 : 0;
     gp.tiles_y = shadow_pass ? (int32_t)((r->shadow_size + 7) / 8) : (int32_t)r->tiles_y;
-    // block ownership (ARCTIC_OPT_RASTER_OWNER, default on): the blocks are written once by their owners, so nothing is cleared
+    // block ownership (ARCTIC_OPT_RASTER_OWNER; default -1 = the choice below): the blocks are written once by their owners, so nothing is cleared
     // the library's choice: the forward pass of a handle that owns 4 Mpx or more -- three launches instead of one cost ~12 us of fixed
     // time, what the atomics cost grows with the pixels.  Whole frames with / without owners: 4K 0.283 / 0.304 ms, one rank of R = 2 at 4K
     // (4.1 Mpx) 0.178 / 0.184, of R = 4 0.136 / 0.130, of R = 8 0.106 / 0.102; config 3 at 1080p 0.113 / 0.114, config 2 (1080p, dense

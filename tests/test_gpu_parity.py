@@ -24,14 +24,18 @@ def build_pair(pkg, oracle, hip, sc, **kw):
     return o, r
 
 
-SCENES = [(1, 0.5), (2, 0.25), (3, 0.1), (3, 0.2), (4, 0.06), (5, 0.03)]   # configs 4/5: 256 and 1024 point lights
+# configs 4/5: 256 and 1024 point lights.  The last case runs the paths the library chooses by itself only for LARGE frames -- block owners in the
+# forward raster (from 4 Mpx), two tiles per wave (from ~3 Mpx) -- on a small one, so that they meet the oracle directly in this suite too
+SCENES = [(1, 0.5, {}), (2, 0.25, {}), (3, 0.1, {}), (3, 0.2, {}), (4, 0.06, {}), (5, 0.03, {}), (3, 0.15, {"raster_owner": 1, "tiles_per_wave": 2})]
 
 
-@pytest.fixture(scope="module", params=SCENES, ids=[f"config{c}-x{s}" for c, s in SCENES])
+@pytest.fixture(scope="module", params=SCENES, ids=[f"config{c}-x{s}" + ("-large-frame-defaults" if o else "") for c, s, o in SCENES])
 def pair(request, pkg, oracle, hip):
-    cfg, scale = request.param
+    cfg, scale, options = request.param
     sc = pkg.scenes.CONFIGS[cfg](scale=scale)
     o, r = build_pair(pkg, oracle, hip, sc)
+    for name, value in options.items():
+        r.set_option(name, value)
     o.pass_shadow_map(sc.desc)
     o.pass_gbuffer(sc.desc)
     r.pass_shadow_map(sc.desc)

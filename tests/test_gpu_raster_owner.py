@@ -2,8 +2,9 @@
 owner wave per block writing it once, the merging atomicMin rasteriser only for what the bins do not hold.  The D3D12 raster it
 stands in for (forward_pass.cpp:137-151,212-224, shadow_map_pass.cpp:96-97,157-167) has one answer per pixel, so the two
 rasterisers must agree bit for bit -- depth, winning triangle, shadow map -- on whole targets, ragged sizes, row-range and
-interleaved shards, bins that overflow, and records that take the integer path.  (Against the oracle the default -- owner on --
-is what every parity test of the suite runs.)"""
+interleaved shards, bins that overflow, and records that take the integer path.  (The library's own choice is owners only for
+handles that own 4 Mpx of the frame or more: against the ORACLE they run in the full-size tests -- 4K, 8K -- and in
+test_gpu_parity.py's `large-frame defaults` case, which forces them, with two tiles per wave, on a small frame.)"""
 import copy
 
 import numpy as np

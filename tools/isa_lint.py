@@ -3,6 +3,8 @@
       SGPRs are read or overwritten before the next s_waitcnt lgkmcnt(0);
   (b) a transcendental (v_rcp / v_rsq / v_sqrt / v_exp / v_log / v_sin / v_cos) whose result is read by the VALU instruction that
       immediately follows it (gfx950 needs one wait state there; the compiler inserts it for its own instructions only).
+The scan is LINEAR over the file: a label resets the transcendental check, but scalar loads pending at a branch are followed only along
+the fall-through path -- enough for shade.hip, whose asm loads and their waits sit in straight-line code by construction.
 usage: python tools/isa_lint.py <shade .s from `make -C arctic-renderer_amd/csrc asm`>   (exit code 1 when something is found)"""
 import re, sys
 
@@ -41,8 +43,8 @@ def lint(path):
             if line.endswith(":"): prev_trans = None   # a label: another path may enter here
             continue
         op, ops = split_ops(line)
-        if op == "s_waitcnt" and "lgkmcnt(0)" in line:
-            pending = {}
+        if op == "s_waitcnt" and (re.search(r"lgkmcnt\(\s*0\s*\)", line) or (ops and re.fullmatch(r"0(x0+)?", ops[0]))):
+            pending = {}      # any form of the instruction whose lgkmcnt field is 0: with other counters beside it, in any order, or the plain immediate 0
         elif op.startswith("s_load") and in_asm:
             for r in regs(ops[0], "s"): pending[r] = n
         elif pending:

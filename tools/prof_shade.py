@@ -4,7 +4,8 @@ import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__fil
 import __graft_entry__ as e
 pkg=e.load_package()
 mode=sys.argv[1] if len(sys.argv)>1 else "full"
-sc=pkg.scenes.CONFIGS[3](scale=1.0)
+cfg=int(sys.argv[2]) if len(sys.argv)>2 else 3      # BASELINE config number (default 3: the metric's)
+sc=pkg.scenes.CONFIGS[cfg](scale=1.0)
 r=sc.upload(pkg.Renderer(sc.width,sc.height,sc.shadow_size,sc.max_lights))
 r.pass_shadow_map(sc.desc); r.pass_gbuffer(sc.desc); r.flush()
 if mode=="nolights": r.update_lights(sc.lights[:0])
