@@ -3,8 +3,10 @@
       SGPRs are read or overwritten before the next s_waitcnt lgkmcnt(0);
   (b) a transcendental (v_rcp / v_rsq / v_sqrt / v_exp / v_log / v_sin / v_cos) whose result is read by the VALU instruction that
       immediately follows it (gfx950 needs one wait state there; the compiler inserts it for its own instructions only).
-The scan is LINEAR over the file: a label resets the transcendental check, but scalar loads pending at a branch are followed only along
-the fall-through path -- enough for shade.hip, whose asm loads and their waits sit in straight-line code by construction.
+The scan is per BASIC BLOCK: a label resets both checks.  A scalar load still pending at the end of its block is not followed further -- across
+a merge "pending" is only a maybe (the light loop's last trip issues no load and leaves through the same block as the trips that do), and the
+hazards this lint exists for are the certain ones: the compiler touching an asm load's destination right behind it (round 4 met exactly that:
+under an SGPR budget the register allocator SPILLED the freshly loaded light pair, v_writelane of registers whose data had not arrived).
 usage: python tools/isa_lint.py <shade .s from `make -C arctic-renderer_amd/csrc asm`>   (exit code 1 when something is found)"""
 import re, sys
 
@@ -29,8 +31,9 @@ def lint(path):
     prev_trans = None       # (dest VGPRs, line number) of the instruction just before, when it was a transcendental
     for n, raw in enumerate(open(path), 1):
         line = raw.split(";")[0].strip() if not raw.strip().startswith(";;#") else raw.strip()
-        if raw.startswith("_Z") and raw.rstrip().endswith(("E:", ":")) and "k_material" in raw:
-            kernel, pending, prev_trans = raw.split(":")[0], {}, None
+        label = raw.split(";")[0].rstrip()        # (the assembler prints `name: ; @name`)
+        if label.startswith("_Z") and label.endswith(":") and "k_material" in label:
+            kernel, pending, prev_trans = label[:-1], {}, None
             continue
         if kernel is None:
             continue
@@ -40,7 +43,9 @@ def lint(path):
         if line.startswith(";;#ASMSTART"): in_asm = True; continue
         if line.startswith(";;#ASMEND"): in_asm = False; continue
         if not line or line.startswith((".", ";")) or line.endswith(":"):
-            if line.endswith(":"): prev_trans = None   # a label: another path may enter here
+            if line.endswith(":"):   # a label: another path may enter here, so nothing is CERTAIN to be pending or to be the instruction before any more
+                prev_trans = None
+                pending = {}
             continue
         op, ops = split_ops(line)
         if op == "s_waitcnt" and (re.search(r"lgkmcnt\(\s*0\s*\)", line) or (ops and re.fullmatch(r"0(x0+)?", ops[0]))):

@@ -3,7 +3,7 @@ usage: python tools/kernel_times.py <dir>                       every kernel: ca
        python tools/kernel_times.py <dir> --timed <bench.json>  the shading pass cut to the TIMED launches of that bench.py run: the per-launch
                                                                 trace rows of k_material, in start order, [roofline.timed_launches) of the line
                                                                 bench.py printed -- the average that has to agree with its ms_per_step"""
-import csv, glob, json, sys
+import csv, glob, json, re, sys
 
 
 def short(name):
@@ -17,7 +17,7 @@ def timed_cut(directory, bench_json):
     for p in glob.glob(directory + "/**/*kernel_trace.csv", recursive=True):
         for r in csv.DictReader(open(p)):
             n = short(r["Kernel_Name"])
-            if n.startswith("void k_material<") or n.startswith("k_material<"):
+            if re.match(r"(void )?k_material(_many_lights|_few_lights|<)", n):   # the pass over a G-buffer (not k_material_vis)
                 rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), n))
     rows.sort()
     cut = rows[first:last]
