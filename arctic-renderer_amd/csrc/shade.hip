@@ -36,9 +36,6 @@
 #ifndef ARCTIC_WG_WAVES
 #define ARCTIC_WG_WAVES 4       // waves per workgroup of the shading kernels: 4 (a strip of 4 tiles per workgroup) or 1 (a tile per workgroup; A/B)
 #endif
-#ifndef ARCTIC_STAGGERED_LIGHT_LOADS
-#define ARCTIC_STAGGERED_LIGHT_LOADS 0   // A/B builds: the packed loop's light pairs with single-buffered positions (18 scalar registers instead of 24)
-#endif
 #ifndef ARCTIC_WINDOW_IN_LDS
 #define ARCTIC_WINDOW_IN_LDS 0  // A/B builds only: the fast tile's 25-tap path with the lane's 4x4 window in LDS (shadow_window_lds); measured slower
 #endif
@@ -661,14 +658,6 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void load_light_pair(const char *p /* wave-uniform */, f4v &A, f4v &B, f4v &C) {
     asm volatile("s_load_dwordx4 %0, %3, 0x0\n\ts_load_dwordx4 %1, %3, 0x10\n\ts_load_dwordx4 %2, %3, 0x20" : "=&s"(A), "=&s"(B), "=&s"(C) : "s"(p));
 }
-// ... or positions {x0,x1,y0,y1,z0,z1} and colours {r0,r1,g0,g1,b0,b1} of a pair separately (ARCTIC_STAGGERED_LIGHT_LOADS)
-typedef float f2s __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void load_light_positions(const char *p /* wave-uniform */, f4v &A, f2s &Bxy) {
-    asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dwordx2 %1, %2, 0x10" : "=&s"(A), "=&s"(Bxy) : "s"(p));
-}
-__device__ __forceinline__ void load_light_colours(const char *p /* wave-uniform */, f2s &Bzw, f4v &C) {
-    asm volatile("s_load_dwordx2 %0, %2, 0x18\n\ts_load_dwordx4 %1, %2, 0x20" : "=&s"(Bzw), "=&s"(C) : "s"(p));
-}
 // d = l - world for the three components of a light pair, behind the s_waitcnt that makes the pair's SGPRs valid: every
 // other use of the pair depends on d, so it is ordered after the wait by data flow
 __device__ __forceinline__ void wait_and_sub(v2 lx, v2 ly, v2 lz, v2 w_xy, v2 wz, v2 &dx, v2 &dy, v2 &dz) {
@@ -906,8 +895,8 @@ __device__ __forceinline__ f3 lit_radiance(SP sp, uint32_t lane, float nr, float
         // hundreds of cycles after its loads).  Written as asm because the compiler's own version addresses every dword separately
         // (40 scalar instructions per trip) and waits right after issuing.
         const char *lp = reinterpret_cast<const char *>(la.pairs);
-        auto finish = [&](v2 dx, v2 dy, v2 dz, v2 cr, v2 cg, v2 cb, uint32_t p) {
-            const v2 nd = accumulate_pair(pk, dx, dy, dz, cr, cg, cb, S);
+        auto finish = [&](v2 dx, v2 dy, v2 dz, const f4v &Bq, const f4v &C, uint32_t p) {
+            const v2 nd = accumulate_pair(pk, dx, dy, dz, (v2){Bq.z, Bq.w}, (v2){C.x, C.y}, (v2){C.z, C.w}, S);
             if (STATS) {
                 const bool second = 2 * p + 1 < la.n_lights;
                 const unsigned long long m0 = __ballot(nd.x > 0.0f), m1 = second ? __ballot(nd.y > 0.0f) : ~0ull;
@@ -916,40 +905,19 @@ __device__ __forceinline__ f3 lit_radiance(SP sp, uint32_t lane, float nr, float
             }
         };
         if (n_pairs) {
-#if ARCTIC_STAGGERED_LIGHT_LOADS
-            // Positions single-buffered, colours double-buffered (round 4: 18 scalar registers instead of 24).  A trip's three subtractions
-            // are the only readers of its positions, so the NEXT pair's positions go out right behind them, into the same registers; the
-            // colours are read by the trip's last nine instructions, so they alternate between two sets.  Every load is issued at the top of
-            // the trip before the one that needs it: one s_waitcnt per trip, a trip's worth of instructions behind its loads, as before.
-            f4v P; f2s Pz; f2s K0a, K1a; f4v K0b, K1b;
-            v2 dx, dy, dz;
-            load_light_positions(lp, P, Pz);
-            load_light_colours(lp, K0a, K0b);
-            for (uint32_t p = 0;;) {
-                wait_and_sub((v2){P.x, P.y}, (v2){P.z, P.w}, (v2){Pz.x, Pz.y}, pk.w_xy, pk.wz_a2, dx, dy, dz);
-                if (p + 1 < n_pairs) { load_light_positions(lp + 48 * (p + 1), P, Pz); load_light_colours(lp + 48 * (p + 1), K1a, K1b); }
-                finish(dx, dy, dz, (v2){K0a.x, K0a.y}, (v2){K0b.x, K0b.y}, (v2){K0b.z, K0b.w}, p);
-                if (++p == n_pairs) break;
-                wait_and_sub((v2){P.x, P.y}, (v2){P.z, P.w}, (v2){Pz.x, Pz.y}, pk.w_xy, pk.wz_a2, dx, dy, dz);
-                if (p + 1 < n_pairs) { load_light_positions(lp + 48 * (p + 1), P, Pz); load_light_colours(lp + 48 * (p + 1), K0a, K0b); }
-                finish(dx, dy, dz, (v2){K1a.x, K1a.y}, (v2){K1b.x, K1b.y}, (v2){K1b.z, K1b.w}, p);
-                if (++p == n_pairs) break;
-            }
-#else
             f4v A0, B0, C0, A1, B1, C1;
             v2 dx, dy, dz;
             load_light_pair(lp, A0, B0, C0);
             for (uint32_t p = 0;;) {
                 wait_and_sub((v2){A0.x, A0.y}, (v2){A0.z, A0.w}, (v2){B0.x, B0.y}, pk.w_xy, pk.wz_a2, dx, dy, dz);   // set 0 has landed
                 if (p + 1 < n_pairs) load_light_pair(lp + 48 * (p + 1), A1, B1, C1);                                  // set 1 in flight
-                finish(dx, dy, dz, (v2){B0.z, B0.w}, (v2){C0.x, C0.y}, (v2){C0.z, C0.w}, p);
+                finish(dx, dy, dz, B0, C0, p);
                 if (++p == n_pairs) break;
                 wait_and_sub((v2){A1.x, A1.y}, (v2){A1.z, A1.w}, (v2){B1.x, B1.y}, pk.w_xy, pk.wz_a2, dx, dy, dz);
                 if (p + 1 < n_pairs) load_light_pair(lp + 48 * (p + 1), A0, B0, C0);
-                finish(dx, dy, dz, (v2){B1.z, B1.w}, (v2){C1.x, C1.y}, (v2){C1.z, C1.w}, p);
+                finish(dx, dy, dz, B1, C1, p);
                 if (++p == n_pairs) break;
             }
-#endif
         }
         float A[3], Bs[3], Cs[3];
         {   // the sun joins the sums
@@ -1079,6 +1047,7 @@ __device__ __forceinline__ void shade_tile(SP sp, const float *lut, float *shado
     const bool in_frame = x < sp.width && y >= 0 && y < (int32_t)sp.rows;
     const uint32_t mat = __float_as_uint(cur.b2);
     const bool covered = in_frame && mat < sp.n_materials;
+    const uint32_t o = (uint32_t)y * sp.width + x;   // targets are at most 16384^2 pixels
     const float u = cur.a.x, v = cur.a.y;
 
     // ---- A: material fetch, forward.hlsl:98-124.  Texel loads of packed materials stay in flight over the shadow test.
@@ -1140,14 +1109,19 @@ __device__ __forceinline__ void shade_tile(SP sp, const float *lut, float *shado
     float4 gc, gd, ge;
     if (live) second(sp.g.c, sp.g.d, sp.g.e, gc, gd, ge);   // second wave of loads: lit pixels only (48 B / pixel, whole 128-byte tile rows)
 
-    // ---- C: base colour ------------------------------------------------------------------------------------------------------
+    // ---- C: base colour; pixels without geometry: the skybox -----------------------------------------------------------
     if (covered && !plain) base = mk(filt_srgb<0>(pt, lut), filt_srgb<1>(pt, lut), filt_srgb<2>(pt, lut));
+    f3 color = base * sp.ambient;
+    if (in_frame && !covered && sp.env) {
+        const int gy = (row_global((int)ty, sp.band_tiles, sp.shard_count, sp.shard_index) + sp.tile_y0) * 8 + (int)(lane >> 3);
+        const float nx = __builtin_fmaf((float)x + 0.5f, sp.ndc_sx, -1.0f), ny = __builtin_fmaf(-((float)gy + 0.5f), sp.ndc_sy, 1.0f);
+        color = sample_environment(sp.env, sp.env_w, sp.env_h,
+                                   __builtin_fmaf(sp.sky_up[0], ny, __builtin_fmaf(sp.sky_right[0], nx, sp.sky_fwd[0])),
+                                   __builtin_fmaf(sp.sky_up[1], ny, __builtin_fmaf(sp.sky_right[1], nx, sp.sky_fwd[1])),
+                                   __builtin_fmaf(sp.sky_up[2], ny, __builtin_fmaf(sp.sky_right[2], nx, sp.sky_fwd[2])));
+    }
 
     // ---- D: the lights ---------------------------------------------------------------------------------------------
-    // (Round 4: nothing but base, lit and the material id lives through the light loop -- the ambient term, the skybox lookup, the pixel's
-    //  place in the target and the frame test are formed BEHIND it, from a lane index asked for again: this tile's register count is the
-    //  kernel's.)
-    f3 Lo = mk(0.0f, 0.0f, 0.0f);
     if (live) {
         float nr, ng, nb, rough, metal;
         if (!plain) {
@@ -1170,28 +1144,12 @@ __device__ __forceinline__ void shade_tile(SP sp, const float *lut, float *shado
                 todo &= ~__ballot(mine);
             }
         }
-        Lo = lit_radiance<LOOP, STATS>(sp, lane, nr, ng, nb, rough, metal, base, gc, gd, ge);
+        const f3 Lo = lit_radiance<LOOP, STATS>(sp, lane, nr, ng, nb, rough, metal, base, gc, gd, ge);
+        color = mk(__builtin_fmaf(Lo.x, lit, color.x), __builtin_fmaf(Lo.y, lit, color.y), __builtin_fmaf(Lo.z, lit, color.z));
     }
 
-    // ---- E: ambient term / skybox, post_process + store ------------------------------------------------------------------------
-    const uint32_t l2 = wave_lane();
-    const uint32_t x2 = tx * 8 + (l2 & 7);
-    const int32_t y2 = (int32_t)(ty * 8 + (l2 >> 3)) - (int32_t)sp.row0_in_tile;
-    const bool in_frame2 = x2 < sp.width && y2 >= 0 && y2 < (int32_t)sp.rows;
-    const bool covered2 = in_frame2 && mat < sp.n_materials;
-    f3 color = base * sp.ambient;
-    if (in_frame2 && !covered2 && sp.env) {   // pixels without geometry: the skybox
-        const int gy = (row_global((int)ty, sp.band_tiles, sp.shard_count, sp.shard_index) + sp.tile_y0) * 8 + (int)(l2 >> 3);
-        const float nx = __builtin_fmaf((float)x2 + 0.5f, sp.ndc_sx, -1.0f), ny = __builtin_fmaf(-((float)gy + 0.5f), sp.ndc_sy, 1.0f);
-        color = sample_environment(sp.env, sp.env_w, sp.env_h,
-                                   __builtin_fmaf(sp.sky_up[0], ny, __builtin_fmaf(sp.sky_right[0], nx, sp.sky_fwd[0])),
-                                   __builtin_fmaf(sp.sky_up[1], ny, __builtin_fmaf(sp.sky_right[1], nx, sp.sky_fwd[1])),
-                                   __builtin_fmaf(sp.sky_up[2], ny, __builtin_fmaf(sp.sky_right[2], nx, sp.sky_fwd[2])));
-    }
-    if (covered2 && (sp.culling ? lit != 0.0f : true))   // (= live: the same lanes)
-        color = mk(__builtin_fmaf(Lo.x, lit, color.x), __builtin_fmaf(Lo.y, lit, color.y), __builtin_fmaf(Lo.z, lit, color.z));
-    const uint32_t o2 = (uint32_t)y2 * sp.width + x2;   // targets are at most 16384^2 pixels
-    if (in_frame2) store_pixel(store_args(sp), sp.out_rgba8, o2, o2, color);
+    // ---- E: post_process + store ---------------------------------------------------------------------------------------
+    if (in_frame) store_pixel(store_args(sp), sp.out_rgba8, o, o, color);
 }
 
 // ARCTIC_OPT_TILE_TRACE (a measuring aid, off by default: one wave-uniform branch at either end of a tile): when and where every tile
@@ -1269,9 +1227,8 @@ __device__ __forceinline__ bool next_tile(const ArgsA &A, const OrderArgs &O, co
     ty = g * 8 + (b.x & 7u);
     return g < ((A.tiles_y + 7u) >> 3) && ty < A.tiles_y;
 }
-// the pass's kernel body (two kernels below: the scalar register budget is an attribute, and attributes take no template arguments)
 template <int LOOP, bool STATS, bool LDS_SHADOW>
-__device__ __forceinline__ void material_pass() {
+__global__ __launch_bounds__(64 * ARCTIC_WG_WAVES) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_material(const ShadeParams sp_by_value) {
     __shared__ float lut[256];
     __shared__ float window[ARCTIC_WINDOW_IN_LDS ? ARCTIC_WG_WAVES : 1][ARCTIC_WINDOW_IN_LDS ? WINDOW_LDS_FLOATS : 1];   // one per wave: shadow_window_lds
     __shared__ float shadow_tiles[LDS_SHADOW ? ARCTIC_WG_WAVES : 1][LDS_SHADOW ? SHADOW_TILE * SHADOW_TILE : 1];   // one per wave (the LDS variant of the PCF slow path)
@@ -1304,14 +1261,7 @@ __device__ __forceinline__ void material_pass() {
             gc = gload_f4(pc + tile * 64, lane * 16u); gd = gload_f4(pd + tile * 64, lane * 16u); ge = gload_f4(pe + tile * 64, lane * 16u);
         };
         const bool fast = shade_tile_fast<LOOP, STATS>(sp, args, A, lut, window[ARCTIC_WINDOW_IN_LDS ? wave : 0], ty, tx, lane, cur, second);
-        if (!fast) {
-            // The general tile asks for the tile's head AGAIN (cache hits; 3 % of the tiles).  The compiler lays "shaded by the fast tile" and
-            // "not mine" out one behind the other with a flag between them, so whatever the general tile reads of earlier values is alive
-            // through the fast tile -- its light loop included: the head's seven registers were (round 4, from the ISA: tools/isa_budget.py).
-            asm volatile("" ::: "memory");
-            const TileHead again = load_head(A.ga, A.gb, tile, wave_lane());
-            shade_tile<LOOP, STATS, LDS_SHADOW>(sp, lut, shadow_tiles[LDS_SHADOW ? wave : 0], ty, tx, lane, again, second);
-        }
+        if (!fast) shade_tile<LOOP, STATS, LDS_SHADOW>(sp, lut, shadow_tiles[LDS_SHADOW ? wave : 0], ty, tx, lane, cur, second);
         trace_end(sp, A, tile, fast);
         if (++k >= A.T) break;
         asm volatile("" : "+s"(args));
@@ -1322,27 +1272,6 @@ __device__ __forceinline__ void material_pass() {
     }
 }
 
-// The scalar register file decides occupancy as much as the vector one (tools/experiments/occupancy2.hip, profiles/r4_occupancy_*): 7 waves
-// per SIMD need <= 96 SGPRs, 8 waves <= 80 (both counts include VCC and the like: 6), whatever the VGPR count allows -- and the compiler's
-// own count moved between 73 and 106 with unrelated edits of this file.  So the two kernels the pass runs by default state their budget:
-//   k_material_many_lights (the packed light loop, more than 12 point lights): 90 + 6, 62 VGPRs: 7 waves.  It must never have to spill a
-//     scalar register: under a budget of 74 the register allocator parked the freshly loaded light pair in a vector register's lanes BEFORE
-//     the loads' data had arrived (the asm loads are invisible to the compiler's own wait counting; tools/isa_lint.py reports it -- and did,
-//     for the counting variant, under this very budget of 90: the variants below keep the compiler's own count);
-//   k_material_few_lights (the scalar loop, up to 12 point lights -- the reference's own counts, and every sun-only configuration): 74 + 6,
-//     60 VGPRs: 8 waves.  No hand-written loads there; what does not fit the budget sits in the lanes of a vector register.
-__global__ __launch_bounds__(64 * ARCTIC_WG_WAVES) __attribute__((amdgpu_waves_per_eu(4, 8), amdgpu_num_sgpr(90))) void k_material_many_lights(const ShadeParams sp_by_value) {
-    material_pass<2, false, false>();
-}
-__global__ __launch_bounds__(64 * ARCTIC_WG_WAVES) __attribute__((amdgpu_waves_per_eu(4, 8), amdgpu_num_sgpr(74))) void k_material_few_lights(const ShadeParams sp_by_value) {
-    material_pass<1, false, false>();
-}
-// ... and the variants: light statistics (ARCTIC_OPT_COUNT_LIGHT_EVALS), the 25 taps through a per-wave LDS tile (an A/B build of round 2)
-template <int LOOP, bool STATS, bool LDS_SHADOW>
-__global__ __launch_bounds__(64 * ARCTIC_WG_WAVES) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_material(const ShadeParams sp_by_value) {
-    material_pass<LOOP, STATS, LDS_SHADOW>();
-}
-
 // ---- the same without a G-buffer (whole frames): the tile walk straight from the visibility plane ----------------------
 // arctic_render_frame has no use for the 76 B/pixel G-buffer between its own two kernels: writing it (k_resolve, 630 MB at
 // 4K) and reading it back costs more than interpolating again.  This variant reads the 8-byte visibility key, finds the
@@ -1350,7 +1279,7 @@ __global__ __launch_bounds__(64 * ARCTIC_WG_WAVES) __attribute__((amdgpu_waves_p
 // for the lit ones -- with the very operations of k_resolve (edges.h, fp contraction off), so the pixels are bit-identical
 // to the G-buffer path.  Everything after the attributes is shade_tile, shared.
 template <int LOOP, bool STATS, bool LDS_SHADOW>
-__device__ __forceinline__ void material_vis_pass() {
+__global__ __launch_bounds__(64 * ARCTIC_WG_WAVES) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_material_vis(const ShadeParams sp_by_value) {
     __shared__ float lut[256];
     __shared__ float window[ARCTIC_WINDOW_IN_LDS ? ARCTIC_WG_WAVES : 1][ARCTIC_WINDOW_IN_LDS ? WINDOW_LDS_FLOATS : 1];   // one per wave: shadow_window_lds
     __shared__ float shadow_tiles[LDS_SHADOW ? ARCTIC_WG_WAVES : 1][LDS_SHADOW ? SHADOW_TILE * SHADOW_TILE : 1];   // one per wave (the LDS variant of the PCF slow path)
@@ -1378,19 +1307,15 @@ __device__ __forceinline__ void material_vis_pass() {
     const uint32_t lane = wave_lane();
     trace_begin(sp, (size_t)ty * A.tiles_x + tx, t_entry);
     t_entry = 0ull;
-    const bool compact = sp.compact_tables != 0;
-    // the tile's head from its visibility keys: uv + light-space position + material of every covered pixel, and what `second` needs to
-    // interpolate the rest (barycentrics in the source triangle, its three transformed vertices).  A function of the key alone, so the
-    // general tile can ask for it AGAIN instead of keeping it alive through the fast tile (see k_material).
-    const auto head = [&](unsigned long long key, TileHead &cur, float (&B)[3], uint32_t &v0, uint32_t &v1, uint32_t &v2) {
-    const uint32_t hl = wave_lane();
-    const int32_t px = (int32_t)(tx * 8 + (hl & 7));
-    const int32_t py = (row_global((int)ty, sp.band_tiles, sp.shard_count, sp.shard_index) + sp.tile_y0) * 8 + (int32_t)(hl >> 3);
+    const int32_t px = (int32_t)(tx * 8 + (lane & 7));
+    const int32_t py = (row_global((int)ty, sp.band_tiles, sp.shard_count, sp.shard_index) + sp.tile_y0) * 8 + (int32_t)(lane >> 3);
+    TileHead cur;
     cur.a = make_float4(0.0f, 0.0f, 0.0f, 0.0f); cur.b0 = 0.0f; cur.b1 = 0.0f; cur.b2 = __uint_as_float(NO_MATERIAL);
-    B[0] = B[1] = B[2] = 0.0f;
-    v0 = v1 = v2 = 0;   // the source triangle's transformed vertices (indices, not pointers)
+    float B[3] = {0.0f, 0.0f, 0.0f};
+    uint32_t v0 = 0, v1 = 0, v2 = 0;   // the source triangle's transformed vertices (indices, not pointers: they stay live across the tile)
     // attribute k of transformed vertex v: XVert::attr at byte 16 + 4k of a 96-byte record.  With compact tables (below 4 GiB each, the
     // host says) every gather is a wave-uniform base + a 32-bit byte offset: no 64-bit multiply-adds per lane and load
+    const bool compact = sp.compact_tables != 0;
     if (key != ~0ull && compact) {
         const uint32_t ri = gload_u32(sp.rec_of, (uint32_t)key << 2);   // low word of the key = order id (k_setup)
         const uint32_t so = ri << 7;                                     // SetupRec and RasterRec are 128 bytes
@@ -1443,11 +1368,6 @@ __device__ __forceinline__ void material_vis_pass() {
         cur.b0 = interpolate_attr(B, A0, A1, A2, 16); cur.b1 = interpolate_attr(B, A0, A1, A2, 17);
         cur.b2 = __uint_as_float(ob.material);
     }
-    };
-    TileHead cur;
-    float B[3];
-    uint32_t v0, v1, v2;
-    head(key, cur, B, v0, v1, v2);
     const auto second = [&](const float4 *, const float4 *, const float4 *, float4 &gc, float4 &gd, float4 &ge) {
         // attribute order (XVert::attr): uv 0-1, t 2-4, b 5-7, n 8-10, world 11-13, light space 14-17; planes as gbuffer_pack
         const auto mix = [&](float x0, float x1, float x2) {
@@ -1470,12 +1390,7 @@ __device__ __forceinline__ void material_vis_pass() {
         }
     };
     const bool fast = shade_tile_fast<LOOP, STATS>(sp, args, A, lut, window[ARCTIC_WINDOW_IN_LDS ? wave : 0], ty, tx, lane, cur, second);
-    if (!fast) {   // (the general tile works its head out again: see k_material)
-        asm volatile("" ::: "memory");
-        const unsigned long long again = sp.vis[((size_t)ty * A.tiles_x + tx) * 64 + wave_lane()];
-        head(again, cur, B, v0, v1, v2);
-        shade_tile<LOOP, STATS, LDS_SHADOW>(sp, lut, shadow_tiles[LDS_SHADOW ? wave : 0], ty, tx, lane, cur, second);
-    }
+    if (!fast) shade_tile<LOOP, STATS, LDS_SHADOW>(sp, lut, shadow_tiles[LDS_SHADOW ? wave : 0], ty, tx, lane, cur, second);
     trace_end(sp, A, (size_t)ty * A.tiles_x + tx, fast);
     if (++k >= A.T) break;
     asm volatile("" : "+s"(args));
@@ -1484,19 +1399,6 @@ __device__ __forceinline__ void material_vis_pass() {
     if (!next_tile(A, O, blk, k, tx, ty)) break;
     key = args->vis[((size_t)ty * A.tiles_x + tx) * 64 + wave_lane()];
     }
-}
-
-// (register budgets as for k_material: 72 VGPRs and at most 96 SGPRs = 7 waves per SIMD for the two kernels whole frames run by default --
-//  round 3: 80 VGPRs, 6 waves --, the compiler's own counts for the variants)
-__global__ __launch_bounds__(64 * ARCTIC_WG_WAVES) __attribute__((amdgpu_waves_per_eu(7, 8), amdgpu_num_sgpr(90))) void k_material_vis_many_lights(const ShadeParams sp_by_value) {
-    material_vis_pass<2, false, false>();
-}
-__global__ __launch_bounds__(64 * ARCTIC_WG_WAVES) __attribute__((amdgpu_waves_per_eu(7, 8), amdgpu_num_sgpr(90))) void k_material_vis_few_lights(const ShadeParams sp_by_value) {
-    material_vis_pass<1, false, false>();
-}
-template <int LOOP, bool STATS, bool LDS_SHADOW>
-__global__ __launch_bounds__(64 * ARCTIC_WG_WAVES) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_material_vis(const ShadeParams sp_by_value) {
-    material_vis_pass<LOOP, STATS, LDS_SHADOW>();
 }
 
 // ---- shadow bounds: the conservative min/max table calculate_lit tests first -------------------------------------------
@@ -1541,11 +1443,7 @@ __global__ __launch_bounds__(256) void k_post_process(const float4 *__restrict__
 template <int LOOP, bool STATS, bool LDS_SHADOW>
 hipError_t launch_variant(const ShadeParams &sp, const ShadeLaunch &L, dim3 grid) {
     if (ARCTIC_WG_WAVES == 1) grid.x = (grid.x + 7) / 8 * 32;   // (block_id: four one-wave blocks per strip, a strip's blocks on one XCD)
-    if (L.from_vis && LOOP == 2 && !STATS && !LDS_SHADOW) k_material_vis_many_lights<<<grid, 64 * ARCTIC_WG_WAVES, 0, L.stream>>>(sp);
-    else if (L.from_vis && LOOP == 1 && !STATS && !LDS_SHADOW) k_material_vis_few_lights<<<grid, 64 * ARCTIC_WG_WAVES, 0, L.stream>>>(sp);
-    else if (L.from_vis) k_material_vis<LOOP, STATS, LDS_SHADOW><<<grid, 64 * ARCTIC_WG_WAVES, 0, L.stream>>>(sp);
-    else if (LOOP == 1 && !STATS && !LDS_SHADOW) k_material_few_lights<<<grid, 64 * ARCTIC_WG_WAVES, 0, L.stream>>>(sp);
-    else if (LOOP == 2 && !STATS && !LDS_SHADOW) k_material_many_lights<<<grid, 64 * ARCTIC_WG_WAVES, 0, L.stream>>>(sp);
+    if (L.from_vis) k_material_vis<LOOP, STATS, LDS_SHADOW><<<grid, 64 * ARCTIC_WG_WAVES, 0, L.stream>>>(sp);
     else k_material<LOOP, STATS, LDS_SHADOW><<<grid, 64 * ARCTIC_WG_WAVES, 0, L.stream>>>(sp);
     return hipGetLastError();
 }

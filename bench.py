@@ -24,7 +24,7 @@ work is fixed -> "scaling": "strong".  torch.distributed only carries the 128-by
 the timing barriers (ARCTIC_BENCH_EXCHANGE=torch keeps the round-1 path: dist.gather + index_copy_).
 
 The JSON line also carries
-  roofline     the dominant kernel = the pass itself (ONE launch: k_material_many_lights / k_material_few_lights): achieved = 80 B x shaded pixels /
+  roofline     the dominant kernel = the pass itself (ONE launch: k_material<loop>): achieved = 80 B x shaded pixels /
                kernel_ms, kernel_ms = HIP events on the launch stream around the K timed steps / K (the same launches
                ms_per_step is the wall clock of).  Which roof binds is DERIVED, not assumed: valu_issue_frac = the kernel's
                vector-issue cycles / (1024 SIMDs x 2.4 GHz x kernel_ms), priced per instruction class (the light loop's v_pk_*
@@ -494,7 +494,7 @@ def main():
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                 "traffic_source": f"static: {pmc_src}, round {pmc.get('round')} (rocprofv3 --pmc, separate passes; not measured in this run)" if pmc else None,
-                "kernel": f"{'k_material_many_lights' if n_lights > 12 else 'k_material_few_lights'} (the whole pass in one launch: material fetch, shadow test, "
+                "kernel": f"k_material<{2 if n_lights > 12 else 1}> (the whole pass in one launch: material fetch, shadow test, "
                           f"{'packed' if n_lights > 12 else 'scalar'} light loop, tonemap, store; {'two tiles' if sc.width * sc.height >= 3000000 else 'one tile'} per wave, "
                           f"strips handed out in the order the G-buffer pass left: lit ones dealt evenly, the end of the list shadowed ones only)",
                 "settle_ms_before_measuring": SETTLE_MS,

@@ -75,12 +75,10 @@ def test_shading_kernels_keep_their_register_budgets(shade_isa):
     compiler's counts move with unrelated edits: the default kernels are pinned here (round 3 shipped 72 VGPRs + 16 bytes of scratch;
     a day of round 4 saw 82 ... 102 SGPRs)."""
     res = _kernel_resources(shade_isa)
-    many = res["_ZN6arctic12_GLOBAL__N_122k_material_many_lightsENS_11ShadeParamsE"]     # the packed light loop: 7 waves per SIMD
-    assert many["vgprs"] <= 72 and many["sgprs"] <= 96 and many["scratch"] == 0, many
-    few = res["_ZN6arctic12_GLOBAL__N_121k_material_few_lightsENS_11ShadeParamsE"]        # the scalar loop: 8 waves per SIMD
-    assert few["vgprs"] <= 64 and few["sgprs"] <= 80 and few["scratch"] == 0, few
-    for k in (many, few):
-        assert k["lds"] <= 20 * 1024, k       # 8 workgroups per CU must fit the 160 KiB
-    for name in ("_ZN6arctic12_GLOBAL__N_126k_material_vis_many_lightsENS_11ShadeParamsE", "_ZN6arctic12_GLOBAL__N_125k_material_vis_few_lightsENS_11ShadeParamsE"):
-        k = res[name]                                                                       # whole frames from the visibility plane: 7 waves
-        assert k["vgprs"] <= 72 and k["sgprs"] <= 96 and k["scratch"] == 0, (name, k)
+    for loop in (1, 2):
+        k = res[f"_ZN6arctic12_GLOBAL__N_110k_materialILi{loop}ELb0ELb0EEEvNS_11ShadeParamsE"]       # the pass over a G-buffer: 7 waves per SIMD
+        assert k["vgprs"] <= 72 and k["sgprs"] <= 96 and k["scratch"] == 0, (loop, k)
+        assert k["lds"] <= 20 * 1024, (loop, k)       # 8 workgroups per CU must fit the 160 KiB
+    for loop in (1, 2):
+        k = res[f"_ZN6arctic12_GLOBAL__N_114k_material_visILi{loop}ELb0ELb0EEEvNS_11ShadeParamsE"]   # whole frames: 6 waves (7 measured slower, DESIGN 4.2c)
+        assert k["vgprs"] <= 80 and k["scratch"] == 0, (loop, k)

@@ -33,7 +33,7 @@ dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
 json.dump(res, open(os.path.join(dst, f"{tag}_pmc_counters.json"), "w"), indent=1)
 latest = {"round": tag,
           "command": "tools/profile_round.sh: rocprofv3 --pmc <set> --kernel-trace -- python3 tools/prof_shade.py full (one set per run)",
-          "config": "config 3: 3840x2160, 64 point lights, shadow 4000^2, ACES; one shading pass = one launch of k_material_many_lights",
+          "config": "config 3: 3840x2160, 64 point lights, shadow 4000^2, ACES; one shading pass = one launch of k_material<2>",
           "algorithmic_bytes_per_launch": 3840 * 2160 * 80}
 if "FETCH_SIZE" in out and "WRITE_SIZE" in out:
     latest.update({"FETCH_SIZE_KB": out["FETCH_SIZE"], "WRITE_SIZE_KB": out["WRITE_SIZE"],
