@@ -36,9 +36,6 @@
 #ifndef ARCTIC_WG_WAVES
 #define ARCTIC_WG_WAVES 4       // waves per workgroup of the shading kernels: 4 (a strip of 4 tiles per workgroup) or 1 (a tile per workgroup; A/B)
 #endif
-#ifndef ARCTIC_WINDOW_IN_LDS
-#define ARCTIC_WINDOW_IN_LDS 0  // A/B builds only: the fast tile's 25-tap path with the lane's 4x4 window in LDS (shadow_window_lds); measured slower
-#endif
 #ifndef ARCTIC_EDGE_IN_FAST
 #define ARCTIC_EDGE_IN_FAST 1   // A/B switch (build_tmp variants only): 0 = a tile on a shadow edge goes to the general tile, as in round 3
 #endif
@@ -358,60 +355,8 @@ __device__ __forceinline__ float shadow_window(const float *__restrict__ map, ui
     return shadow / 25.0f;
 }
 
-// The same 25 taps with the lane's 4x4 window in LDS instead of registers (round 4; the fast tile's shadow-edge path).  Registers cannot be
-// indexed per lane, so shadow_window picks every texel with v_cndmask chains (~185 of them, and a dozen lane masks in scalar registers);
-// LDS can: texel k = 4 row + column of lane l lives at word 64 k + l of the wave's region (bank = l: no conflicts whatever k each lane
-// asks for), and a tap reads its four texels at ONE computed address (two ds_read2st64_b32).  The taps no longer share their horizontal
-// lerps (that would take a second LDS region -- 5 KiB per wave would cost the scalar-loop kernel its eighth wave per SIMD -- or the
-// selects again): every tap is lerp(lerp(t00, t10, fx), lerp(t01, t11, fx), fy) on its own, the oracle's expression, so the same bits.
-// Per window ~290 vector instructions + 58 LDS operations instead of ~425 + 0, no selects, no masks.  `win`: 16 x 64 floats of this wave.
-// MEASURED SLOWER and off by default (ARCTIC_WINDOW_IN_LDS, A/B builds only; profiles/r4_d_ab_window_in_lds.txt, config 3 at 4K, one box:
-// 64 / 16 / 0 point lights 0.1918 / 0.1280 / 0.0964 ms with the register window, 0.1945 / 0.1318 / 0.0950 with this one): a tap is two
-// dependent LDS round trips in front of its three lerps, 25 times in a row, where the select chains are plain issue slots.
-constexpr int WINDOW_LDS_FLOATS = 16 * 64;
-__device__ __forceinline__ float shadow_window_lds(const float *__restrict__ map, uint32_t S, float px, float py, float pz, float *win, uint32_t lane) {
-#pragma clang fp contract(off)
-    const float Sf = (float)S;
-    const float u0 = px + -0.0002f, u4 = px + 0.0002f, v0 = py + -0.0002f, v4 = py + 0.0002f;
-    const float xa = floorf(u0 * Sf - 0.5f), xb = floorf(u4 * Sf - 0.5f), ya = floorf(v0 * Sf - 0.5f), yb = floorf(v4 * Sf - 0.5f);
-    const bool ok = u0 >= 0.0f && u4 < 1.0f && v0 >= 0.0f && v4 < 1.0f && xa >= 0.0f && ya >= 0.0f && xb - xa <= 2.0f && yb - ya <= 2.0f &&
-                    xa + 3.0f < Sf && ya + 3.0f < Sf;
-    if (!ok) return shadow_generic(map, S, px, py, pz);
-    const uint32_t o0 = ((uint32_t)(int)ya * S + (uint32_t)(int)xa) * 4u;   // byte offset: maps are at most 16384^2 floats
-    const float4u w0 = gload_f4u(map, o0), w1 = gload_f4u(map, o0 + S * 4u), w2 = gload_f4u(map, o0 + S * 8u), w3 = gload_f4u(map, o0 + S * 12u);
-    const float lo = fminf(fminf(fminf(fminf(w0.x, w0.y), fminf(w0.z, w0.w)), fminf(fminf(w1.x, w1.y), fminf(w1.z, w1.w))),
-                           fminf(fminf(fminf(w2.x, w2.y), fminf(w2.z, w2.w)), fminf(fminf(w3.x, w3.y), fminf(w3.z, w3.w))));
-    const float hi = fmaxf(fmaxf(fmaxf(fmaxf(w0.x, w0.y), fmaxf(w0.z, w0.w)), fmaxf(fmaxf(w1.x, w1.y), fmaxf(w1.z, w1.w))),
-                           fmaxf(fmaxf(fmaxf(w2.x, w2.y), fmaxf(w2.z, w2.w)), fmaxf(fmaxf(w3.x, w3.y), fmaxf(w3.z, w3.w))));
-    if (pz > hi) return 1.0f;
-    if (!(pz > lo)) return 0.0f;
-    float *col = win + lane;            // texel k of this lane: col[64 k]
-    col[0 * 64] = w0.x; col[1 * 64] = w0.y; col[2 * 64] = w0.z; col[3 * 64] = w0.w;
-    col[4 * 64] = w1.x; col[5 * 64] = w1.y; col[6 * 64] = w1.z; col[7 * 64] = w1.w;
-    col[8 * 64] = w2.x; col[9 * 64] = w2.y; col[10 * 64] = w2.z; col[11 * 64] = w2.w;
-    col[12 * 64] = w3.x; col[13 * 64] = w3.y; col[14 * 64] = w3.z; col[15 * 64] = w3.w;
-    float fy[5];
-    int ry[5];                          // row of tap j relative to the window, as a word offset: 0 / 256 / 512
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        const float y = (py + (float)(j - 2) * 0.0001f) * Sf - 0.5f, yf = floorf(y);
-        fy[j] = y - yf;
-        ry[j] = (int)(yf - ya) * 256;
-    }
-    float shadow = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const float x = (px + (float)(i - 2) * 0.0001f) * Sf - 0.5f, xf = floorf(x), fx = x - xf;
-        const float *c = col + (int)(xf - xa) * 64;
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const float *t = c + ry[j];
-            const float top = lerp_exact(t[0], t[64], fx), bot = lerp_exact(t[256], t[320], fx);
-            shadow += pz > lerp_exact(top, bot, fy[j]) ? 1.0f : 0.0f;
-        }
-    }
-    return shadow / 25.0f;
-}
+// (Round 4 also tried the lane's 4x4 window in LDS -- texel k of lane l at word 64 k + l, a tap = two ds_read2st64_b32 at a computed address, ~290 vector
+// instructions + 58 LDS operations instead of ~425 + 0 -- and measured it slower: profiles/r4_d_ab_window_in_lds.txt; code in commit ec02d97.)
 
 // ---- the LDS variant of the 25-tap path (north_star: "stages ... shadow-map tiles in LDS"; ARCTIC_OPT_DEBUG bit 4 selects the
 // kernels instantiated with it) ----------------------------------------------------------------------------------------------
@@ -955,7 +900,7 @@ __device__ __forceinline__ f3 lit_radiance(SP sp, uint32_t lane, float nr, float
 // `second(pc, pd, pe, gc, gd, ge)` delivers the lit pixels' remaining attributes (world position + tangent frame, packed like the
 // G-buffer planes c, d, e): loaded from the G-buffer, or interpolated on the spot by the visibility-buffer kernel.
 template <int LOOP, bool STATS, class Second>
-__device__ __forceinline__ bool shade_tile_fast(SP sp, KernArgs args, const ArgsA &A, const float *lut, float *win, uint32_t ty, uint32_t tx, uint32_t lane, const TileHead &cur, Second second) {
+__device__ __forceinline__ bool shade_tile_fast(SP sp, KernArgs args, const ArgsA &A, const float *lut, uint32_t ty, uint32_t tx, uint32_t lane, const TileHead &cur, Second second) {
     ArgsB B = args_b(args);   // (the head of the tile is in flight)
     const int32_t row0 = (int32_t)(ty * 8) - (int32_t)B.row0_in_tile;   // the tile's first pixel row in the target (wave-uniform)
     if ((A.debug & (1 | 2 | 4 | 256)) != 0 || tx * 8 + 8 > B.width || row0 < 0 || row0 + 8 > (int32_t)B.rows) return false;
@@ -991,11 +936,7 @@ __device__ __forceinline__ bool shade_tile_fast(SP sp, KernArgs args, const Args
         // "writes" every component) and asked for again behind it -- cache hits, and such tiles are few
         asm("" : "=v"(pt.r0.x), "=v"(pt.r0.y), "=v"(pt.r0.z), "=v"(pt.r0.w), "=v"(pt.r1.x), "=v"(pt.r1.y), "=v"(pt.r1.z), "=v"(pt.r1.w));
         asm("" : "=v"(pt.w00), "=v"(pt.w10), "=v"(pt.w01), "=v"(pt.w11));
-#if ARCTIC_WINDOW_IN_LDS
-        if (!decided) lit = 1.0f - shadow_window_lds(B.sh.map, B.sh.S, spos.px, spos.py, spos.pz, win, wave_lane());
-#else
         if (!decided) lit = 1.0f - shadow_window(B.sh.map, B.sh.S, spos.px, spos.py, spos.pz);
-#endif
         // ... and so are the argument batches and the descriptor (the 25 taps hold a dozen lane masks in scalar registers: with the
         // batches alive across them the kernel would pass 96 SGPRs, i.e. lose a wave per SIMD): loaded again, two scalar round trips
         asm volatile("" : "+s"(args));
@@ -1230,7 +1171,6 @@ __device__ __forceinline__ bool next_tile(const ArgsA &A, const OrderArgs &O, co
 template <int LOOP, bool STATS, bool LDS_SHADOW>
 __global__ __launch_bounds__(64 * ARCTIC_WG_WAVES) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_material(const ShadeParams sp_by_value) {
     __shared__ float lut[256];
-    __shared__ float window[ARCTIC_WINDOW_IN_LDS ? ARCTIC_WG_WAVES : 1][ARCTIC_WINDOW_IN_LDS ? WINDOW_LDS_FLOATS : 1];   // one per wave: shadow_window_lds
     __shared__ float shadow_tiles[LDS_SHADOW ? ARCTIC_WG_WAVES : 1][LDS_SHADOW ? SHADOW_TILE * SHADOW_TILE : 1];   // one per wave (the LDS variant of the PCF slow path)
     KernArgs args = kernel_args();
     unsigned long long t_entry = trace_entry();
@@ -1260,7 +1200,7 @@ __global__ __launch_bounds__(64 * ARCTIC_WG_WAVES) __attribute__((amdgpu_waves_p
         const auto second = [&](const float4 *pc, const float4 *pd, const float4 *pe, float4 &gc, float4 &gd, float4 &ge) {
             gc = gload_f4(pc + tile * 64, lane * 16u); gd = gload_f4(pd + tile * 64, lane * 16u); ge = gload_f4(pe + tile * 64, lane * 16u);
         };
-        const bool fast = shade_tile_fast<LOOP, STATS>(sp, args, A, lut, window[ARCTIC_WINDOW_IN_LDS ? wave : 0], ty, tx, lane, cur, second);
+        const bool fast = shade_tile_fast<LOOP, STATS>(sp, args, A, lut, ty, tx, lane, cur, second);
         if (!fast) shade_tile<LOOP, STATS, LDS_SHADOW>(sp, lut, shadow_tiles[LDS_SHADOW ? wave : 0], ty, tx, lane, cur, second);
         trace_end(sp, A, tile, fast);
         if (++k >= A.T) break;
@@ -1281,7 +1221,6 @@ __global__ __launch_bounds__(64 * ARCTIC_WG_WAVES) __attribute__((amdgpu_waves_p
 template <int LOOP, bool STATS, bool LDS_SHADOW>
 __global__ __launch_bounds__(64 * ARCTIC_WG_WAVES) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_material_vis(const ShadeParams sp_by_value) {
     __shared__ float lut[256];
-    __shared__ float window[ARCTIC_WINDOW_IN_LDS ? ARCTIC_WG_WAVES : 1][ARCTIC_WINDOW_IN_LDS ? WINDOW_LDS_FLOATS : 1];   // one per wave: shadow_window_lds
     __shared__ float shadow_tiles[LDS_SHADOW ? ARCTIC_WG_WAVES : 1][LDS_SHADOW ? SHADOW_TILE * SHADOW_TILE : 1];   // one per wave (the LDS variant of the PCF slow path)
     KernArgs args = kernel_args();
     unsigned long long t_entry = trace_entry();
@@ -1389,7 +1328,7 @@ __global__ __launch_bounds__(64 * ARCTIC_WG_WAVES) __attribute__((amdgpu_waves_p
             ge = make_float4(interpolate_attr(B, A0, A1, A2, 7), interpolate_attr(B, A0, A1, A2, 8), interpolate_attr(B, A0, A1, A2, 9), interpolate_attr(B, A0, A1, A2, 10));
         }
     };
-    const bool fast = shade_tile_fast<LOOP, STATS>(sp, args, A, lut, window[ARCTIC_WINDOW_IN_LDS ? wave : 0], ty, tx, lane, cur, second);
+    const bool fast = shade_tile_fast<LOOP, STATS>(sp, args, A, lut, ty, tx, lane, cur, second);
     if (!fast) shade_tile<LOOP, STATS, LDS_SHADOW>(sp, lut, shadow_tiles[LDS_SHADOW ? wave : 0], ty, tx, lane, cur, second);
     trace_end(sp, A, (size_t)ty * A.tiles_x + tx, fast);
     if (++k >= A.T) break;
