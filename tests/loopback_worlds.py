@@ -6,7 +6,10 @@ ranks do: arctic_comm_init (its layout all-gather), frames rendered into two alt
 each (the grouped send / recv into the root + the placement kernel, overlapping the next frame), the sharded shadow map's in-place
 all-gather when the sun moves.  Checked: the root's assembled frames == the single-device frame, byte for byte.
 
-usage: python tests/loopback_worlds.py <world> <bands|rows> [shadow]     prints LOOPBACK_OK on success"""
+With `streams` every rank's handle runs on a caller's stream (arctic_set_stream before arctic_comm_init, as bench.py's ranks do): the handle's
+own stream is then the exchange stream only, and frames stay three in flight on the caller's stream + the remaining prepass stream.
+
+usage: python tests/loopback_worlds.py <world> <bands|rows> [shadow] [streams]     prints LOOPBACK_OK on success"""
 import os
 import sys
 import threading
@@ -21,7 +24,8 @@ import __graft_entry__ as entry  # noqa: E402
 
 def main():
     world, layout = int(sys.argv[1]), sys.argv[2]
-    sharded_shadow = len(sys.argv) > 3 and sys.argv[3] == "shadow"
+    sharded_shadow = "shadow" in sys.argv[3:]
+    callers_streams = "streams" in sys.argv[3:]
     assert os.environ.get("ARCTIC_RCCL_LIB"), "the loopback communicator is selected with ARCTIC_RCCL_LIB"
     import torch
     pkg = entry.load_package()
@@ -50,12 +54,17 @@ def main():
                 r = sc.upload(hip.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights, band_rows=band, shard=(rank, world)))
             else:
                 r = sc.upload(hip.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights, row_begin=cuts[rank], row_end=cuts[rank + 1]))
+            stream = None
+            if callers_streams:
+                stream = torch.cuda.Stream()
+                r.set_stream(stream.cuda_stream)
             start.wait()
             r.comm_init(uid, rank, world)
             if sharded_shadow:
                 r.set_option("shadow_sharded", 1)
                 r.set_option("shadow_cache", 0)        # the map is redrawn -- in row slices, all-gathered -- every frame
             outs = [torch.zeros((max(r.rows, 1), sc.width, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
+            torch.cuda.synchronize()                   # (the fills run on torch's stream, the frames on the handle's)
             for k in range(4):                         # alternating shard buffers: gather k overlaps frame k + 1
                 b = k % 2
                 r.render_frame_device(sc.desc, sc.settings, outs[b].data_ptr())
@@ -93,7 +102,7 @@ def main():
         single.close()
         for rank in range(world):
             np.testing.assert_array_equal(results[("map", rank)].view(np.uint32), ref_map.view(np.uint32))
-    print(f"LOOPBACK_OK world {world} {layout}{' sharded-shadow' if sharded_shadow else ''}", flush=True)
+    print(f"LOOPBACK_OK world {world} {layout}{' sharded-shadow' if sharded_shadow else ''}{' callers-streams' if callers_streams else ''}", flush=True)
 
 
 if __name__ == "__main__":
