@@ -438,6 +438,8 @@ __global__ __launch_bounds__(SETUP_THREADS) void k_setup(const ObjectRec *__rest
     bool has = inside && setup_triangle(a, b, c, gp, t);
     EmitPlan e;
     plan_triangle(has, t, gp, e);
+    // an uncut source triangle: its vertices carry unit barycentrics (load_triangle), setup_triangle may have exchanged the last two
+    if (has) e.q.flags |= RASTER_UNIT_BARY | (t.bary[1][2] == 1.0f ? RASTER_SWAPPED : 0u);
     const unsigned long long m = __ballot(has);
     const uint32_t iincl = wave_inclusive_sum(e.nb, lane);
     if (lane == 63) { s_count[wave][0] = (uint32_t)__popcll(m); s_count[wave][1] = iincl; }

@@ -1267,8 +1267,7 @@ __global__ __launch_bounds__(64 * ARCTIC_WG_WAVES) __attribute__((amdgpu_waves_p
             const double A0 = ld1(so), C0 = ld1(so + 48u), A2 = ld1(so + 16u), B0 = ld1(so + 24u), B2 = ld1(so + 40u), C2 = ld1(so + 64u);
             (void)ld2;
             const float4u s2 = gload_f4u(sp.recs, so + 32u);             // z[2], iw[0..2]
-            const float4u b0 = gload_f4u(sp.recs, so + 48u), b1 = gload_f4u(sp.recs, so + 64u);   // bary[0][0..2], bary[1][0] | bary[1][1..2], bary[2][0..1]
-            const float b22 = __uint_as_float(gload_u32(sp.recs, so + 80u));
+            const uint32_t fl = __float_as_uint(qf.w);
             {   // source_barycentrics (edges.h), on the fields just loaded: the same operations in the same order
 #pragma clang fp contract(off)
                 const double x = (double)px, y = (double)py;
@@ -1278,9 +1277,18 @@ __global__ __launch_bounds__(64 * ARCTIC_WG_WAVES) __attribute__((amdgpu_waves_p
                 const float pw0 = l0 * s2.y, pw1 = l1 * s2.z, pw2 = l2 * s2.w;
                 const float rr = 1.0f / ((pw0 + pw1) + pw2);
                 const float c0 = pw0 * rr, c1 = pw1 * rr, c2 = pw2 * rr;
-                B[0] = (c0 * b0.x + c1 * b0.w) + c2 * b1.z;
-                B[1] = (c0 * b0.y + c1 * b1.x) + c2 * b1.w;
-                B[2] = (c0 * b0.z + c1 * b1.y) + c2 * b22;
+                if (__ballot((fl & RASTER_UNIT_BARY) == 0u) == 0ull) {
+                    // every record under the tile is an uncut source triangle (nearly every tile): the rows of its barycentric matrix are
+                    // unit vectors and the products below return c0, c1, c2 themselves -- in source order when set-up exchanged two vertices
+                    const bool swapped = (fl & RASTER_SWAPPED) != 0u;
+                    B[0] = c0; B[1] = swapped ? c2 : c1; B[2] = swapped ? c1 : c2;
+                } else {
+                    const float4u b0 = gload_f4u(sp.recs, so + 48u), b1 = gload_f4u(sp.recs, so + 64u);   // bary[0][0..2], bary[1][0] | bary[1][1..2], bary[2][0..1]
+                    const float b22 = __uint_as_float(gload_u32(sp.recs, so + 80u));
+                    B[0] = (c0 * b0.x + c1 * b0.w) + c2 * b1.z;
+                    B[1] = (c0 * b0.y + c1 * b1.x) + c2 * b1.w;
+                    B[2] = (c0 * b0.z + c1 * b1.y) + c2 * b22;
+                }
             }
         } else source_barycentrics(sp.recs[ri], sp.rrecs[ri], px, py, B);   // rare: coordinates of 2^24 and more
         cur.b2 = __uint_as_float(src.w);
