@@ -285,7 +285,7 @@ struct ShadeLaunch {
     uint32_t stats;      // 1: the counting variant (ShadeParams::stats)
     uint32_t tiles_per_wave;   // 0: DEFAULT_TILES_PER_WAVE (ARCTIC_OPT_TILES_PER_WAVE)
 };
-constexpr uint32_t N_SHADE_STATS = 5;
+constexpr uint32_t N_SHADE_STATS = 9;   // [0..4] light statistics, [5..8] shadow-edge statistics of the fast tile (shade.hip)
 constexpr uint32_t DEFAULT_TILES_PER_WAVE = 2;
 constexpr uint32_t SMALL_FRAME_TILES = 48000;   // fewer 8x8 tiles than this (~3 Mpx): one tile per wave (launch_shade)
 // the shadow-bounds table: one entry per 4x4 texel block; only for maps whose 25 PCF taps (4e-4 S apart end to end, in fp32)

@@ -54,6 +54,15 @@ __device__ __forceinline__ void source_barycentrics(const SetupRec &t, const Ras
     const float pw0 = l0 * t.iw[0], pw1 = l1 * t.iw[1], pw2 = l2 * t.iw[2];
     const float rr = 1.0f / ((pw0 + pw1) + pw2);
     const float b0 = pw0 * rr, b1 = pw1 * rr, b2 = pw2 * rr;
+    if (q.flags & RASTER_UNIT_BARY) {
+        // an uncut source triangle: the rows of t.bary are unit vectors, the product below is (b0, b1, b2) itself -- in source order when set-up
+        // exchanged two vertices.  Taken HERE, for every consumer (k_resolve, k_material_vis, the integer-path records), so that the G-buffer
+        // path and the visibility-plane path agree bit for bit also where the product would not return its operand: b * 1 + b' * 0 + b'' * 0
+        // is NaN once a b is infinite or NaN (a degenerate 1/w sum), and -0 for a negative zero.
+        const bool swapped = (q.flags & RASTER_SWAPPED) != 0u;
+        B[0] = b0; B[1] = swapped ? b2 : b1; B[2] = swapped ? b1 : b2;
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < 3; ++k) B[k] = (b0 * t.bary[0][k] + b1 * t.bary[1][k]) + b2 * t.bary[2][k];
 }

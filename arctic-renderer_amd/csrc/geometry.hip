@@ -958,7 +958,9 @@ __global__ __launch_bounds__(256) void k_resolve(const unsigned long long *__res
 }
 
 // ---------------------------------------------------------------------------------------------
-// the shading pass's dispatch order from the tiles' cost classes (ONE workgroup; 32 k strips at 4K)
+// the shading pass's dispatch order from the tiles' cost classes (ONE workgroup; 32 k strips at 4K: 112 us measured, profiles/r4_g_kernel_stats_bench_command.csv --
+// each thread walks 32 strips twice with byte loads and 64-bit divisions; at 16384^2 it would be ~1 k strips per thread.  ARCTIC_OPT_TILE_ORDER is OFF by default
+// since round 5: an opt-in measuring aid, not part of the default G-buffer pass)
 // ---------------------------------------------------------------------------------------------
 // A job of the shading pass = a STRIP of 4 horizontally adjacent tiles (one workgroup, a wave per tile), coded ty << 16 | strip
 // column.  A strip is costly when one of its tiles is.  The order deals the costly strips evenly over the first (1 - tail) of the
@@ -986,7 +988,7 @@ __global__ __launch_bounds__(1024) void k_tile_order(const uint8_t *__restrict__
     for (uint32_t s = s0; s < s1; ++s) mine += costly(s);
     part[threadIdx.x] = mine;
     __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {   // inclusive scan, Hillis-Steele (ten steps; the kernel is a few microseconds)
+    for (uint32_t d = 1; d < 1024; d <<= 1) {   // inclusive scan, Hillis-Steele (ten steps)
         const uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
         __syncthreads();
         part[threadIdx.x] += v;

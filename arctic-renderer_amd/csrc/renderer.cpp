@@ -210,6 +210,7 @@ struct ArcticRenderer {
     bool recs_worst_case = false;   // record table at 7 per source triangle (after an overflow of the 2-per-triangle table)
     uint32_t item_cap_floor = 1u << 22;   // its smallest size (ARCTIC_OPT_ITEM_TABLE_FLOOR; tests shrink it to reach the overflow path)
     uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t edge_stats[4] = {0, 0, 0, 0};   // stats[12..15]: fast tiles the shadow table left undecided, their undecided pixels, tiles / pixels that ran the 25 compares
     uint64_t light_stats[2] = {0, 0};   // stats[8], [9]: (tile, light) pairs with n.wi <= 0 in every lit lane; tiles with a lit pixel
     int keep_float = 0, count_evals = 0, culling = 1, debug = 0, hdr16 = 0, tile_trace = 0;
     uint32_t tiles_per_wave = 0;     // ARCTIC_OPT_TILES_PER_WAVE (0 = the library's default)
@@ -218,7 +219,9 @@ struct ArcticRenderer {
     // a stale or missing order changes the pass's time, never its image.
     DevBuf d_tile_class, d_order_lists, d_tile_order;
     bool have_order = false;         // d_tile_order belongs to the G-buffer in place
-    int tile_order = 1;              // ARCTIC_OPT_TILE_ORDER: 0 = the geometric order of round 3
+    int tile_order = 0;              // ARCTIC_OPT_TILE_ORDER: 0 (default since round 5) = the geometric, XCD-aware order of round 3; 1 = the cost-class order of round 4.
+                                     // Measured (profiles/r5_a_*): the order gains <= 2 us of the pass, its one-workgroup kernel costs the G-buffer pass 112 us, and handing strips
+                                     // out by cost instead of by XCD row costs the pass 83 MB of fabric reads per launch (L2 hits 2.33 M -> 1.73 M: neighbouring strips no longer meet in one L2)
     uint32_t order_tail = 60;        // ARCTIC_OPT_ORDER_TAIL: the last part of the order (per mille) that holds cheap strips only
     DevBuf d_tile_trace;             // ARCTIC_OPT_TILE_TRACE: 4 x u64 per tile of the latest shading pass
     int raster_owner = -1;           // ARCTIC_OPT_RASTER_OWNER: bit 0 forward pass, bit 1 shadow pass: the blocks of the target are written once by owner waves
@@ -675,6 +678,7 @@ int pass_shade(ArcticRenderer *r, const ArcticScene *sc, const ArcticSettings *s
         HIPCHECK(r, hipStreamSynchronize(r->stream));
         r->stats[5] = n[0]; r->stats[6] = n[1]; r->stats[7] = n[2];
         r->light_stats[0] = n[3]; r->light_stats[1] = n[4];
+        for (int i = 0; i < 4; ++i) r->edge_stats[i] = n[5 + i];
     }
     r->have_output = (d_out == nullptr);
     return ARCTIC_OK;
@@ -862,9 +866,15 @@ int arctic_use_own_stream(ArcticRenderer *r) {
     if (rc) return rc;
     HIPCHECK(r, hipStreamSynchronize(r->stream));
     if (r->own_stream_is_prepass()) HIPCHECK(r, hipStreamSynchronize(r->own_stream));
-    if (r->comm_stream_borrowed) {   // one role per stream: the exchange moves to a stream of its own (what own_stream still holds of it stays ordered in front of the passes to come)
-        HIPCHECK(r, hipStreamCreateWithFlags(&r->comm_stream, hipStreamNonBlocking));
-        r->comm_stream_borrowed = false;
+    if (r->comm_stream_borrowed) {
+        // One role per stream.  The exchange KEEPS the stream it has been running on -- it may hold gathers the other ranks have not matched yet, and
+        // passes queued behind those would stall until they do -- and becomes its owner; the passes get a fresh stream (ordered against earlier
+        // gathers the way they always are: by the events of the shard buffers they write, pass_shade).  The new stream goes into a local first: a
+        // failed creation leaves the handle exactly as it was.
+        hipStream_t fresh = nullptr;
+        HIPCHECK(r, hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking));
+        r->comm_stream_borrowed = false;   // comm_stream == the old own_stream: owned by the exchange from here on (destroyed with the communicator)
+        r->own_stream = fresh;
     }
     r->stream = r->own_stream;
     return ARCTIC_OK;
@@ -1228,7 +1238,7 @@ int arctic_stats(ArcticRenderer *r, uint64_t *out, uint32_t n) {
     if (!r || !out) return ARCTIC_E_INVALID;
     if (select_device(r) == ARCTIC_OK) (void)hipStreamSynchronize(r->stream);
     if (r->h_counts) for (int i = 0; i < 4; ++i) r->stats[i] = r->h_counts[i];
-    for (uint32_t i = 0; i < n && i < 12; ++i) out[i] = i < 8 ? r->stats[i] : i < 10 ? r->light_stats[i - 8] : (r->h_counts ? r->h_counts[6 + (i - 10)] : 0);
+    for (uint32_t i = 0; i < n && i < 16; ++i) out[i] = i < 8 ? r->stats[i] : i < 10 ? r->light_stats[i - 8] : i < 12 ? (r->h_counts ? r->h_counts[6 + (i - 10)] : 0) : r->edge_stats[i - 12];
     return ARCTIC_OK;
 }
 

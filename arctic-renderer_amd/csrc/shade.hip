@@ -36,6 +36,9 @@
 #ifndef ARCTIC_WG_WAVES
 #define ARCTIC_WG_WAVES 4       // waves per workgroup of the shading kernels: 4 (a strip of 4 tiles per workgroup) or 1 (a tile per workgroup; A/B)
 #endif
+#ifndef ARCTIC_LUT_SHARED
+#define ARCTIC_LUT_SHARED 0     // A/B switch: 1 = each wave of a workgroup loads a quarter of the sRGB table (256 B instead of 1 KiB per wave) and a barrier stands behind the stores
+#endif
 #ifndef ARCTIC_EDGE_IN_FAST
 #define ARCTIC_EDGE_IN_FAST 1   // A/B switch (build_tmp variants only): 0 = a tile on a shadow edge goes to the general tile, as in round 3
 #endif
@@ -310,7 +313,7 @@ __device__ __noinline__ float shadow_generic(const float *__restrict__ map, uint
 //                  shared between taps, which does not change any tap's value).
 // Lanes near the map border (WRAP would engage) or with a wider footprint use shadow_generic.
 
-__device__ __forceinline__ float shadow_window(const float *__restrict__ map, uint32_t S, float px, float py, float pz) {
+__device__ __forceinline__ float shadow_window(const float *__restrict__ map, uint32_t S, float px, float py, float pz, bool *tapped = nullptr /* statistics: this lane ran the 25 compares */) {
 #pragma clang fp contract(off)
     const float Sf = (float)S;
     // inside [0,1): u - floor(u) == u, so the coordinates below are wrap_axis without the wrap
@@ -327,6 +330,7 @@ __device__ __forceinline__ float shadow_window(const float *__restrict__ map, ui
                            fmaxf(fmaxf(fmaxf(w2.x, w2.y), fmaxf(w2.z, w2.w)), fmaxf(fmaxf(w3.x, w3.y), fmaxf(w3.z, w3.w))));
     if (pz > hi) return 1.0f;
     if (!(pz > lo)) return 0.0f;
+    if (tapped) *tapped = true;
     // the 25 compares, one tap column at a time (few live registers: this path sets the kernel's register count): the
     // four horizontal lerps of column i, h[r] = lerp(w[r][c_i], w[r][c_i + 1], fx_i), are shared by its five taps
     float fy[5];
@@ -863,6 +867,10 @@ __device__ __forceinline__ f3 lit_radiance(SP sp, uint32_t lane, float nr, float
                 finish(dx, dy, dz, B1, C1, p);
                 if (++p == n_pairs) break;
             }
+            // No load is in flight here (the last trip issues none), but only the trip counts say so: a path-insensitive reader of the ISA --
+            // tools/isa_lint.py follows every asm scalar load along every branch to its wait -- sees the loop's exits behind a load of the
+            // other set.  One scalar instruction per lit tile makes "nothing of a light pair is pending behind the loop" a fact of the code.
+            asm volatile("s_waitcnt lgkmcnt(0)");
         }
         float A[3], Bs[3], Cs[3];
         {   // the sun joins the sums
@@ -936,7 +944,15 @@ __device__ __forceinline__ bool shade_tile_fast(SP sp, KernArgs args, const Args
         // "writes" every component) and asked for again behind it -- cache hits, and such tiles are few
         asm("" : "=v"(pt.r0.x), "=v"(pt.r0.y), "=v"(pt.r0.z), "=v"(pt.r0.w), "=v"(pt.r1.x), "=v"(pt.r1.y), "=v"(pt.r1.z), "=v"(pt.r1.w));
         asm("" : "=v"(pt.w00), "=v"(pt.w10), "=v"(pt.w01), "=v"(pt.w11));
-        if (!decided) lit = 1.0f - shadow_window(B.sh.map, B.sh.S, spos.px, spos.py, spos.pz);
+        bool tapped = false;
+        if (!decided) lit = 1.0f - shadow_window(B.sh.map, B.sh.S, spos.px, spos.py, spos.pz, STATS ? &tapped : nullptr);
+        if (STATS) {   // [5] tiles with a pixel the table left undecided, [6] such pixels, [7] tiles that ran the 25 compares, [8] pixels that did
+            const unsigned long long und = __ballot(!decided), tap = __ballot(tapped);
+            if (wave_lane() == 0) {
+                atomicAdd(sp.stats + 5, 1ull); atomicAdd(sp.stats + 6, (unsigned long long)__popcll(und));
+                if (tap) { atomicAdd(sp.stats + 7, 1ull); atomicAdd(sp.stats + 8, (unsigned long long)__popcll(tap)); }
+            }
+        }
         // ... and so are the argument batches and the descriptor (the 25 taps hold a dozen lane masks in scalar registers: with the
         // batches alive across them the kernel would pass 96 SGPRs, i.e. lose a wave per SIMD): loaded again, two scalar round trips
         asm volatile("" : "+s"(args));
@@ -1181,14 +1197,26 @@ __global__ __launch_bounds__(64 * ARCTIC_WG_WAVES) __attribute__((amdgpu_waves_p
     OrderArgs O;
     ArgsA A = args_a_first(args, srgb_lut, vis_unused, O);
     uint32_t tx, ty, k = 0;
-    if (!next_tile(A, O, blk, k, tx, ty)) return;
     TileHead cur;
+#if ARCTIC_LUT_SHARED && ARCTIC_WG_WAVES == 4
+    {   // a quarter of the table per wave (waves without a tile load theirs too), the barrier behind the head loads' issue
+        const bool has_tile = next_tile(A, O, blk, k, tx, ty);
+        const uint32_t lane = wave_lane();
+        const float q = __uint_as_float(gload_u32(srgb_lut, (blk.wave * 64u + lane) * 4u));
+        if (has_tile) cur = load_head(A.ga, A.gb, (size_t)ty * A.tiles_x + tx, lane);
+        lut[blk.wave * 64u + lane] = q;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (!has_tile) return;
+    }
+#else
+    if (!next_tile(A, O, blk, k, tx, ty)) return;
     {
         const uint32_t lane = wave_lane();
         const LutRegs lr = lut_load(srgb_lut, lane);                                       // an L2 hit: back first ...
         cur = load_head(A.ga, A.gb, (size_t)ty * A.tiles_x + tx, lane);                   // ... while the tile's first bytes travel
         lut_store(lut, lane, lr);
     }
+#endif
 #pragma nounroll
     for (;;) {
         asm volatile("" : "+s"(args));   // see SP
@@ -1231,14 +1259,26 @@ __global__ __launch_bounds__(64 * ARCTIC_WG_WAVES) __attribute__((amdgpu_waves_p
     OrderArgs O;
     ArgsA A = args_a_first(args, srgb_lut, vis_plane, O);
     uint32_t tx, ty, k = 0;
+    unsigned long long key = ~0ull;
+#if ARCTIC_LUT_SHARED && ARCTIC_WG_WAVES == 4
+    {
+        const bool has_tile = next_tile(A, O, blk, k, tx, ty);
+        const uint32_t lane = wave_lane();
+        const float q = __uint_as_float(gload_u32(srgb_lut, (blk.wave * 64u + lane) * 4u));
+        if (has_tile) key = vis_plane[((size_t)ty * A.tiles_x + tx) * 64 + lane];
+        lut[blk.wave * 64u + lane] = q;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (!has_tile) return;
+    }
+#else
     if (!next_tile(A, O, blk, k, tx, ty)) return;
-    unsigned long long key;
     {
         const uint32_t lane = wave_lane();
         const LutRegs lr = lut_load(srgb_lut, lane);
         key = vis_plane[((size_t)ty * A.tiles_x + tx) * 64 + lane];
         lut_store(lut, lane, lr);
     }
+#endif
 #pragma nounroll
     for (;;) {
     asm volatile("" : "+s"(args));   // see SP
@@ -1282,12 +1322,12 @@ __global__ __launch_bounds__(64 * ARCTIC_WG_WAVES) __attribute__((amdgpu_waves_p
                     // unit vectors and the products below return c0, c1, c2 themselves -- in source order when set-up exchanged two vertices
                     const bool swapped = (fl & RASTER_SWAPPED) != 0u;
                     B[0] = c0; B[1] = swapped ? c2 : c1; B[2] = swapped ? c1 : c2;
-                } else {
+                } else {   // a tile with a cut triangle under it: the product per lane, and the lanes of uncut triangles as above (source_barycentrics' rule: edges.h)
                     const float4u b0 = gload_f4u(sp.recs, so + 48u), b1 = gload_f4u(sp.recs, so + 64u);   // bary[0][0..2], bary[1][0] | bary[1][1..2], bary[2][0..1]
                     const float b22 = __uint_as_float(gload_u32(sp.recs, so + 80u));
-                    B[0] = (c0 * b0.x + c1 * b0.w) + c2 * b1.z;
-                    B[1] = (c0 * b0.y + c1 * b1.x) + c2 * b1.w;
-                    B[2] = (c0 * b0.z + c1 * b1.y) + c2 * b22;
+                    const bool unit = (fl & RASTER_UNIT_BARY) != 0u, swapped = (fl & RASTER_SWAPPED) != 0u;
+                    const float p0 = (c0 * b0.x + c1 * b0.w) + c2 * b1.z, p1 = (c0 * b0.y + c1 * b1.x) + c2 * b1.w, p2 = (c0 * b0.z + c1 * b1.y) + c2 * b22;
+                    B[0] = unit ? c0 : p0; B[1] = unit ? (swapped ? c2 : c1) : p1; B[2] = unit ? (swapped ? c1 : c2) : p2;
                 }
             }
         } else source_barycentrics(sp.recs[ri], sp.rrecs[ri], px, py, B);   // rare: coordinates of 2^24 and more

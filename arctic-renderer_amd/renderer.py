@@ -229,8 +229,8 @@ class Renderer:
         return ldr, hdr, rgba
 
     def stats(self):
-        s = np.zeros(12, np.uint64)
-        self._check(self.L.arctic_stats(self.h, _ptr(s), 12))
+        s = np.zeros(16, np.uint64)
+        self._check(self.L.arctic_stats(self.h, _ptr(s), 16))
         return s
 
     def tile_trace(self):

@@ -79,26 +79,38 @@ def log(*a):
 
 
 def count_gpus_without_hip():
-    """GPUs this process may use, WITHOUT a HIP call (the launcher must not initialise the GPU): the *_VISIBLE_DEVICES lists when set,
-    else the KFD topology's nodes that have SIMDs (CPU nodes have none; no KFD at all: 0).  None when the topology cannot be read:
-    the ranks then fail by themselves, loudly, if a device is missing."""
-    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+    """GPUs this process may use, WITHOUT a HIP call (the launcher must not initialise the GPU): the KFD topology's nodes that have SIMDs
+    and whose render node this process may open (a lease that restricts devices by cgroup / device-node permissions rather than by
+    environment still lists every GPU in the topology), cut down by the *_VISIBLE_DEVICES lists that are set -- they compose (HIP indexes
+    into what ROCr shows), so the smallest count holds.  0 without an amdgpu compute driver; None when the topology cannot be read: the
+    ranks then fail by themselves, loudly, if a device is missing."""
+    listed = []
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         v = os.environ.get(var)
         if v is not None:
-            return len([x for x in v.split(",") if x.strip() != ""])
+            listed.append(len([x for x in v.split(",") if x.strip() != ""]))
     base = "/sys/class/kfd/kfd/topology/nodes"
+    n = None
     if not os.path.isdir("/sys/class/kfd"):
-        return 0        # no amdgpu compute driver on this machine at all
-    try:
-        n = 0
-        for node in os.listdir(base):
-            with open(os.path.join(base, node, "properties")) as f:
-                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
-            if int(props.get("simd_count", "0")) > 0:
+        n = 0        # no amdgpu compute driver on this machine at all
+    else:
+        try:
+            n = 0
+            for node in os.listdir(base):
+                with open(os.path.join(base, node, "properties")) as f:
+                    props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+                if int(props.get("simd_count", "0")) <= 0:
+                    continue
+                minor = int(props.get("drm_render_minor", "-1"))
+                dev = f"/dev/dri/renderD{minor}"
+                if minor >= 0 and os.path.exists("/dev/dri") and not (os.path.exists(dev) and os.access(dev, os.R_OK | os.W_OK)):
+                    continue     # in the topology, but not this process's to open
                 n += 1
-        return n
-    except OSError:
-        return None
+        except (OSError, ValueError):
+            n = None
+    if listed:
+        return min(listed) if n is None else min([n] + listed)
+    return n
 
 
 def launch_ranks(n, argv):
@@ -112,7 +124,7 @@ def launch_ranks(n, argv):
     import subprocess
     import threading
     share = os.environ.get("ARCTIC_BENCH_SHARE_GPU") == "1"
-    if any("rocprof" in os.environ.get(v, "") for v in ("LD_PRELOAD", "HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES")) or any(k.startswith("ROCPROF") for k in os.environ):
+    if any("rocprof" in os.environ.get(v, "") for v in ("LD_PRELOAD", "HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES")) or os.environ.get("ROCPROFILER_REGISTER_FORCE_LOAD"):
         # under rocprofv3 the profiler's preloaded library has initialised the GPU before this program started: starting the ranks
         # from here would be a fork + exec from a GPU-initialised process (refused on this pool)
         raise SystemExit("bench.py --gpus N under a profiler: profile ONE rank directly (RANK / WORLD_SIZE / MASTER_* set by hand), not the launcher")
@@ -211,6 +223,8 @@ def main():
     # the library launches on torch's stream (torch events see its kernels) -- set before the communicator is made: the exchange then
     # runs on the handle's own stream, idle from here on, instead of a stream more (hardware queues are few: DESIGN.md 4.3)
     r.set_stream(torch.cuda.current_stream().cuda_stream)
+    tile_order = 1 if os.environ.get("ARCTIC_BENCH_TILE_ORDER") == "1" else 0   # ARCTIC_OPT_TILE_ORDER: off like the library's default (A/B: =1)
+    r.set_option("tile_order", tile_order)
     cabi = False
     if world > 1 and backend == "nccl" and os.environ.get("ARCTIC_BENCH_EXCHANGE", "cabi") == "cabi":
         # The exchange below Python: an RCCL communicator owned by the handle; the 128-byte id travels over torch.distributed.
@@ -255,6 +269,7 @@ def main():
         for _ in range(2):
             h = sc.upload(pkg.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights, device=local))
             h.set_stream(torch.cuda.current_stream().cuda_stream)
+            h.set_option("tile_order", tile_order)
             h.pass_shadow_map(sc.desc)
             h.pass_gbuffer(sc.desc)
             h.flush()
@@ -491,12 +506,21 @@ def main():
             except Exception:
                 pmc = None
         traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
+        build_now, build_pmc = entry.source_id(), (pmc or {}).get("build") or {}
+        if pmc and build_pmc.get("csrc_sha16") != build_now["csrc_sha16"]:
+            log(f"[bench] warning: profiles/pmc_latest.json was measured on other kernel sources (csrc {build_pmc.get('csrc_sha16')}, commit {build_pmc.get('commit')}) "
+                f"than this run's (csrc {build_now['csrc_sha16']}): roofline.traffic / valu_issue_frac are STATIC figures of that build")
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                 "traffic_source": f"static: {pmc_src}, round {pmc.get('round')} (rocprofv3 --pmc, separate passes; not measured in this run)" if pmc else None,
+                "traffic_commit": build_pmc.get("commit") if pmc else None,
+                "traffic_sources_match": (build_pmc.get("csrc_sha16") == build_now["csrc_sha16"]) if pmc else None,
+                "build": build_now,
+                "tile_order": tile_order,
                 "kernel": f"k_material<{2 if n_lights > 12 else 1}> (the whole pass in one launch: material fetch, shadow test, "
                           f"{'packed' if n_lights > 12 else 'scalar'} light loop, tonemap, store; {'two tiles' if sc.width * sc.height >= 3000000 else 'one tile'} per wave, "
-                          f"strips handed out in the order the G-buffer pass left: lit ones dealt evenly, the end of the list shadowed ones only)",
+                          + ("strips handed out in the order the G-buffer pass left (ARCTIC_OPT_TILE_ORDER=1: its one-workgroup order kernel costs the UNTIMED G-buffer pass ~112 us at 4K))"
+                             if tile_order else "tile rows dealt to the XCDs by row, ARCTIC_OPT_TILE_ORDER=0: the library's default)"),
                 "settle_ms_before_measuring": SETTLE_MS,
                 "warmup_effective": warmup_effective,
                 "timed_launches": [first_timed, first_timed + args.steps],

@@ -253,7 +253,10 @@ int arctic_frame_constants(const ArcticScene *scene, float *proj_view, float *li
  * with a lit pixel; [10], [11] work items of the forward / shadow pass that
  * went through the atomicMin rasteriser (all of them with
  * ARCTIC_OPT_RASTER_OWNER = 0; with block ownership those that found their
- * block's bin full or whose record takes the integer path).  n <= 12. */
+ * block's bin full or whose record takes the integer path); with
+ * ARCTIC_OPT_COUNT_LIGHT_EVALS also [12] tiles of the fast path with a pixel
+ * the shadow map's min/max table left undecided, [13] such pixels, [14] tiles
+ * that ran the 25 PCF compares, [15] pixels that did.  n <= 16. */
 int arctic_stats(ArcticRenderer *r, uint64_t *out, uint32_t n);
 
 /* tuning / debug switches. */
@@ -301,11 +304,14 @@ int arctic_stats(ArcticRenderer *r, uint64_t *out, uint32_t n);
                                          for the exact binary64 planes, go through the merging atomicMin rasteriser afterwards.  Bit clear = atomicMin rasteriser
                                          only (round 2; the shadow pass is instruction bound, not atomic bound: measured slower with owners).  Same visibility /
                                          shadow map, bit for bit (D3D12's fixed-function raster of forward_pass.cpp:137-151,212-224 / shadow_map_pass.cpp:96-97,157-167) */
-#define ARCTIC_OPT_TILE_ORDER        19 /* 1 (default) = arctic_pass_gbuffer leaves, next to the G-buffer, a cost class per 8x8 tile (can a pixel of it be lit at all,
+#define ARCTIC_OPT_TILE_ORDER        19 /* 1 = arctic_pass_gbuffer leaves, next to the G-buffer, a cost class per 8x8 tile (can a pixel of it be lit at all,
                                           by the shadow map's min/max table -- the shading kernel's own first test) and from the classes the ORDER in which
                                           arctic_pass_shade hands out its work: lit tiles dealt evenly over the dispatch, shadowed ones in between, the end of
-                                          the list shadowed ones only.  A hint: images never depend on it.  0 = the geometric order (takes effect at the next
-                                          G-buffer pass; a G-buffer written by arctic_write_gbuffer has no order) */
+                                          the list shadowed ones only.  A hint: images never depend on it.  0 (default since round 5) = the geometric, XCD-aware
+                                          order (takes effect at the next G-buffer pass; a G-buffer written by arctic_write_gbuffer has no order).  Off by default
+                                          because it is a net loss as built: the order kernel is ONE workgroup (112 us per G-buffer pass at 4K) for <= 2 us of
+                                          the shading pass, and strips dealt by cost no longer share an XCD's L2 with their neighbours (+83 MB of fabric reads
+                                          per 4K pass: profiles/r5_a_traffic_tile_order.json) */
 #define ARCTIC_OPT_ORDER_TAIL        20 /* per mille of the dispatch order, at its end, that holds cheap tiles only (default 60) */
 #define ARCTIC_OPT_MARKERS          13 /* 1 = roctx ranges around each pass, named like the reference's Tracy zones (process-wide; libroctx64 is loaded on demand) */
 int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value);

@@ -9,7 +9,10 @@ all-gather when the sun moves.  Checked: the root's assembled frames == the sing
 With `streams` every rank's handle runs on a caller's stream (arctic_set_stream before arctic_comm_init, as bench.py's ranks do): the handle's
 own stream is then the exchange stream only, and frames stay three in flight on the caller's stream + the remaining prepass stream.
 
-usage: python tests/loopback_worlds.py <world> <bands|rows> [shadow] [streams]     prints LOOPBACK_OK on success"""
+With `ownback` (implies streams) every rank returns to the handle's own stream (arctic_use_own_stream) between frames 1 and 2, with gather 1 in flight
+on the stream the exchange had borrowed: the exchange keeps that stream, the passes move to a fresh one.
+
+usage: python tests/loopback_worlds.py <world> <bands|rows> [shadow] [streams] [ownback]     prints LOOPBACK_OK on success"""
 import os
 import sys
 import threading
@@ -25,7 +28,8 @@ import __graft_entry__ as entry  # noqa: E402
 def main():
     world, layout = int(sys.argv[1]), sys.argv[2]
     sharded_shadow = "shadow" in sys.argv[3:]
-    callers_streams = "streams" in sys.argv[3:]
+    own_back = "ownback" in sys.argv[3:]
+    callers_streams = "streams" in sys.argv[3:] or own_back
     assert os.environ.get("ARCTIC_RCCL_LIB"), "the loopback communicator is selected with ARCTIC_RCCL_LIB"
     import torch
     pkg = entry.load_package()
@@ -67,6 +71,8 @@ def main():
             torch.cuda.synchronize()                   # (the fills run on torch's stream, the frames on the handle's)
             for k in range(4):                         # alternating shard buffers: gather k overlaps frame k + 1
                 b = k % 2
+                if own_back and k == 2:
+                    r.set_stream(None)                 # arctic_use_own_stream, gather 1 possibly unmatched on the borrowed stream
                 r.render_frame_device(sc.desc, sc.settings, outs[b].data_ptr())
                 r.gather_frame(outs[b].data_ptr(), frames[b].data_ptr() if rank == 0 else None, 0)
             r.flush()
@@ -102,7 +108,7 @@ def main():
         single.close()
         for rank in range(world):
             np.testing.assert_array_equal(results[("map", rank)].view(np.uint32), ref_map.view(np.uint32))
-    print(f"LOOPBACK_OK world {world} {layout}{' sharded-shadow' if sharded_shadow else ''}{' callers-streams' if callers_streams else ''}", flush=True)
+    print(f"LOOPBACK_OK world {world} {layout}{' sharded-shadow' if sharded_shadow else ''}{' callers-streams' if callers_streams else ''}{' own-stream-again' if own_back else ''}", flush=True)
 
 
 if __name__ == "__main__":

@@ -47,6 +47,24 @@ def test_launcher_refuses_more_ranks_than_devices(visible):
     assert out.returncode != 0 and "one GPU per rank" in out.stderr and out.stdout.strip() == ""
 
 
+def test_visible_device_lists_compose(monkeypatch):
+    """ROCR_VISIBLE_DEVICES and HIP_VISIBLE_DEVICES compose (HIP indexes into what ROCr shows): the smallest count holds, and never more than
+    the topology's GPUs this process may open"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(k, raising=False)
+    topo = bench.count_gpus_without_hip()
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "0,1,2")
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0")
+    got = bench.count_gpus_without_hip()
+    assert got is not None and got <= 1 and (topo is None or got <= topo)
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert bench.count_gpus_without_hip() == 0
+
+
 def test_launcher_refuses_to_start_ranks_under_a_profiler():
     """under rocprofv3 the preloaded tool library has initialised the GPU before bench.py starts: no fork + exec from there"""
     env = dict(os.environ, ROCPROFILER_REGISTER_FORCE_LOAD="1")

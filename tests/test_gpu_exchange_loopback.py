@@ -35,12 +35,14 @@ def test_loopback_communicator_builds_and_exports_what_the_library_resolves():
 @pytest.mark.parametrize("world,layout,shadow,streams", [(2, "bands", False, False), (3, "bands", True, False), (8, "bands", False, False), (2, "rows", True, False),
                                                          (3, "rows", False, False), (8, "rows", True, False),
                                                          # every rank on a caller's stream, as bench.py's ranks are: own stream = exchange stream only
-                                                         (3, "bands", False, True), (4, "rows", True, True)],
+                                                         (3, "bands", False, True), (4, "rows", True, True),
+                                                         # ... and back to the handle's own stream between frames, a gather in flight on the stream the exchange borrowed
+                                                         (3, "bands", False, "ownback"), (2, "rows", True, "ownback")],
                          ids=lambda v: str(v))
 def test_exchange_with_more_than_one_rank(hip, world, layout, shadow, streams):
     build()
     env = dict(os.environ, ARCTIC_RCCL_LIB=LIB)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "loopback_worlds.py"), str(world), layout] + (["shadow"] if shadow else []) + (["streams"] if streams else []),
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "loopback_worlds.py"), str(world), layout] + (["shadow"] if shadow else []) + (["ownback"] if streams == "ownback" else ["streams"] if streams else []),
                          capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0 and "LOOPBACK_OK" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
 

@@ -39,6 +39,7 @@ def test_dispatch_order_is_placement_only(pkg, hip, cfg, scale):
 def test_order_is_a_permutation_that_spreads_the_costly_strips(pkg, hip, tail):
     sc = pkg.scenes.config3(scale=0.13)
     r = sc.upload(hip.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights))
+    r.set_option("tile_order", 1)   # (opt-in since round 5)
     r.set_option("order_tail", tail)
     r.pass_shadow_map(sc.desc); r.pass_gbuffer(sc.desc)
     order, classes = r.tile_order()
@@ -69,6 +70,7 @@ def test_cost_classes_cover_every_pixel_that_can_be_lit(pkg, hip, oracle):
     and the hint is not vacuous: tiles in full shadow exist and are cheap"""
     sc = pkg.scenes.config3(scale=0.1)
     r = sc.upload(hip.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights))
+    r.set_option("tile_order", 1)
     r.pass_shadow_map(sc.desc); r.pass_gbuffer(sc.desc)
     _, classes = r.tile_order()
     attrs, mat, _, _ = r.read_gbuffer()
@@ -102,6 +104,7 @@ def test_order_of_an_interleaved_shard(pkg, hip):
     world, band = 3, 16
     for rank in range(world):
         r = sc.upload(hip.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights, band_rows=band, shard=(rank, world)))
+        r.set_option("tile_order", 1)
         r.pass_shadow_map(sc.desc); r.pass_gbuffer(sc.desc); r.pass_shade(sc.desc, sc.settings)
         order, classes = r.tile_order()
         assert order.size == ((classes.shape[1] + 3) // 4) * classes.shape[0]

@@ -31,7 +31,9 @@ for path in glob.glob(os.path.join(root, "**", "*kernel_stats.csv"), recursive=T
 res = {"round": tag, "counters": out, "instances_per_dispatch": inst, "kernel_stats": stats}
 dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
 json.dump(res, open(os.path.join(dst, f"{tag}_pmc_counters.json"), "w"), indent=1)
-latest = {"round": tag,
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import __graft_entry__ as entry   # (no GPU call: only the source hash / commit of the build that was profiled)
+latest = {"round": tag, "build": entry.source_id(),
           "command": "tools/profile_round.sh: rocprofv3 --pmc <set> --kernel-trace -- python3 tools/prof_shade.py full (one set per run)",
           "config": "config 3: 3840x2160, 64 point lights, shadow 4000^2, ACES; one shading pass = one launch of k_material<2>",
           "algorithmic_bytes_per_launch": 3840 * 2160 * 80}

@@ -3,10 +3,13 @@ import sys, numpy as np
 import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import __graft_entry__ as e
 pkg=e.load_package()
-mode=sys.argv[1] if len(sys.argv)>1 else "full"
-cfg=int(sys.argv[2]) if len(sys.argv)>2 else 3      # BASELINE config number (default 3: the metric's)
+opts=[a for a in sys.argv[1:] if "=" in a]                 # name=value: arctic_set_option before anything is rendered
+args=[a for a in sys.argv[1:] if "=" not in a]
+mode=args[0] if len(args)>0 else "full"
+cfg=int(args[1]) if len(args)>1 else 3      # BASELINE config number (default 3: the metric's)
 sc=pkg.scenes.CONFIGS[cfg](scale=1.0)
 r=sc.upload(pkg.Renderer(sc.width,sc.height,sc.shadow_size,sc.max_lights))
+for o in opts: r.set_option(o.split('=')[0], int(o.split('=')[1]))
 r.pass_shadow_map(sc.desc); r.pass_gbuffer(sc.desc); r.flush()
 if mode=="nolights": r.update_lights(sc.lights[:0])
 if mode=="nocull": r.set_option("culling",0)
