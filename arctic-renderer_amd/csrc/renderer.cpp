@@ -219,6 +219,7 @@ struct ArcticRenderer {
     // a stale or missing order changes the pass's time, never its image.
     DevBuf d_tile_class, d_order_lists, d_tile_order;
     bool have_order = false;         // d_tile_order belongs to the G-buffer in place
+    int sampler = 0;                 // ARCTIC_OPT_SAMPLER: bit 0 material footprints, bit 2 PCF taps with coordinates snapped to 1/256 texel (D3D-style 8-bit filter weights)
     int tile_order = 0;              // ARCTIC_OPT_TILE_ORDER: 0 (default since round 5) = the geometric, XCD-aware order of round 3; 1 = the cost-class order of round 4.
                                      // Measured (profiles/r5_a_*): the order gains <= 2 us of the pass, its one-workgroup kernel costs the G-buffer pass 112 us, and handing strips
                                      // out by cost instead of by XCD row costs the pass 83 MB of fabric reads per launch (L2 hits 2.33 M -> 1.73 M: neighbouring strips no longer meet in one L2)
@@ -631,7 +632,7 @@ int fill_shade_params(ArcticRenderer *r, const ArcticScene *sc, const ArcticSett
     }
     if (!from_vis && r->have_order && r->tile_order) sp.tile_order = r->d_tile_order.as<uint32_t>();   // (n_jobs: launch_shade)
     sp.culling = r->culling;
-    sp.debug = r->debug | (sp.trace ? (1 << 30) : 0);   // bit 30: the kernels learn of the trace from the first block of their arguments
+    sp.debug = r->debug | (sp.trace ? (1 << 30) : 0) | ((r->sampler & 5) << 20);   // bit 30: the kernels learn of the trace from the first block of their arguments; bits 20..22: ARCTIC_OPT_SAMPLER (shade.hip SAMPLER_SHIFT)
     sp.hdr16 = r->hdr16;
     sp.env = r->env_w ? r->d_env.as<float4>() : nullptr; sp.env_w = r->env_w; sp.env_h = r->env_h;
     camera_sky_basis(sc->camera.rotation, sc->camera.aspect, sc->camera.fov_y, sp.sky_fwd, sp.sky_right, sp.sky_up);
@@ -1356,6 +1357,10 @@ int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value) {
         r->tiles_per_wave = (uint32_t)value;
         break;
     case ARCTIC_OPT_TILE_TRACE: r->tile_trace = value != 0; break;
+    case ARCTIC_OPT_SAMPLER:
+        if (value < 0 || (value & ~5ll)) return r->fail(ARCTIC_E_INVALID, "set_option: sampler is a mask of bit 0 (material footprints) and bit 2 (PCF taps); bit 1 (sRGB decode after filtering) exists in the oracle only");
+        r->sampler = (int)value;
+        break;
     case ARCTIC_OPT_TILE_ORDER: r->tile_order = value != 0; if (!r->tile_order) r->have_order = false; break;
     case ARCTIC_OPT_ORDER_TAIL:
         if (value < 0 || value > 1000) return r->fail(ARCTIC_E_INVALID, "set_option: order tail is per mille, 0..1000");

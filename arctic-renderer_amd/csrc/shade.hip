@@ -39,6 +39,14 @@
 #ifndef ARCTIC_LUT_SHARED
 #define ARCTIC_LUT_SHARED 0     // A/B switch: 1 = each wave of a workgroup loads a quarter of the sRGB table (256 B instead of 1 KiB per wave) and a barrier stands behind the stores
 #endif
+#ifndef ARCTIC_PCF_CANDIDATES
+#define ARCTIC_PCF_CANDIDATES 0   // A/B switch: 1 = the 25 vertical lerps of k_material's PCF taps evaluate three candidate cells and select the RESULT instead of selecting
+                                  // the operands of every lerp (same bits; measured -0.4 % at 0 / 16 lights, nothing at 64: profiles/r5_b_ab_inplace_sums_and_pcf_candidates.txt --
+                                  // and 74 VGPRs once the kernel also carries the D3D-style sampler's taps, a wave per SIMD: off)
+#endif
+#ifndef ARCTIC_PCF_ROW_CANDIDATES
+#define ARCTIC_PCF_ROW_CANDIDATES 0   // A/B switch: 1 = the horizontal lerps of the 25 PCF taps as candidates too (register pressure: see shadow_window)
+#endif
 #ifndef ARCTIC_EDGE_IN_FAST
 #define ARCTIC_EDGE_IN_FAST 1   // A/B switch (build_tmp variants only): 0 = a tile on a shadow edge goes to the general tile, as in round 3
 #endif
@@ -84,6 +92,14 @@ __device__ __forceinline__ OrderArgs order_args(KernArgs a) {
     return O;
 }
 constexpr int32_t DEBUG_TRACE = 1 << 30;   // ShadeParams::debug: the host asked for a tile trace (ShadeParams::trace is set)
+// ShadeParams::debug bits 20..22 = ARCTIC_OPT_SAMPLER: the D3D-style sampler variants the oracle has had since round 4 (oracle/arctic_oracle.cpp SAMPLER_*),
+// now selectable on the HIP side.  The reference's filter arithmetic is its D3D12 sampler's (forward_pass.cpp:38-51, MIN_MAG_MIP_LINEAR + WRAP); D3D lets the
+// hardware keep texel coordinates in fixed point with 8 fractional bits (D3D11.3 functional specification 3.2.4.1 / 7.18.8):
+//   bit 0  material textures: the scaled coordinate u W - 0.5 snapped to 1/256 texel (round to nearest) before the index / weight split
+//   bit 2  the same for the 25 PCF taps of the shadow map (forward.hlsl:84-92 goes through the same sampler)
+// (bit 1, sRGB decoded after filtering, stays an oracle-only bound: a conformant D3D10+ sampler decodes first.)  Wave-uniform branches: the default costs nothing.
+constexpr int SAMPLER_SHIFT = 20;
+constexpr int32_t SAMPLER_Q8_MATERIAL = 1 << SAMPLER_SHIFT, SAMPLER_Q8_SHADOW = 4 << SAMPLER_SHIFT;
 struct ShadowArgs { const float *map; const float2 *bounds; uint32_t S, pitch; };   // calculate_shadow's inputs
 struct ArgsB { const TexDesc *tex; ShadowArgs sh; uint8_t *out; uint32_t width, rows, row0_in_tile; int32_t culling, hdr16, tm; };
 __device__ __forceinline__ ArgsB args_b(KernArgs a) {   // while the head of the tile is in flight
@@ -154,10 +170,16 @@ constexpr float INV_PI = 1.0f / 3.14159265f;
 
 // ---- sampler: MIN_MAG_MIP_LINEAR + WRAP (forward_pass.cpp:38-51), texel centres at +0.5 ----------
 // exact arithmetic: these coordinates select texels and weights
-__device__ __forceinline__ void wrap_axis(float u, uint32_t n, int &i0, int &i1, float &f) {
+// 24.8 fixed point, round to nearest: the oracle's floor(x * 256 + 0.5) / 256 (x * 256 and / 256 are exact)
+__device__ __forceinline__ float snap256(float x) {
+#pragma clang fp contract(off)
+    return floorf(x * 256.0f + 0.5f) * 0.00390625f;
+}
+__device__ __forceinline__ void wrap_axis(float u, uint32_t n, int &i0, int &i1, float &f, bool q8 = false /* wave-uniform */) {
 #pragma clang fp contract(off)
     float uw = u - floorf(u);
     float x = uw * (float)n - 0.5f;
+    if (q8) x = snap256(x);
     float xf = floorf(x);
     f = x - xf;
     i0 = (int)xf;                       // in [-1, n - 1]
@@ -217,6 +239,17 @@ __device__ __forceinline__ float4u gload_f4u(const void *base, uint32_t o) { ret
 
 // texel coordinate along one axis WITHOUT the wrap (the bordered packed images never need it): the oracle's operations in the
 // oracle's order, i0 = first texel of the footprint in [-1, n - 1], f = weight of the second
+__device__ __forceinline__ float axis_scaled(float u, float nf) {
+#pragma clang fp contract(off)
+    const float uw = u - floorf(u);
+    return uw * nf - 0.5f;
+}
+__device__ __forceinline__ void axis_split(float x, int &i0, float &f) {
+#pragma clang fp contract(off)
+    const float xf = floorf(x);
+    f = x - xf;
+    i0 = (int)xf;
+}
 __device__ __forceinline__ void axis_nowrap(float u, float nf, int &i0, float &f) {
 #pragma clang fp contract(off)
     const float uw = u - floorf(u);
@@ -235,22 +268,24 @@ __device__ __forceinline__ void tap_weights(float fx, float fy, Taps &t) {
     t.w00 = gx * gy; t.w10 = fx * gy; t.w01 = gx * fy; t.w11 = fx * fy;
 }
 // packed + bordered image: the footprint is two 16-byte loads, their address one multiply-add and one shifted add
-__device__ __forceinline__ void fetch_taps_packed(const TexS &d, float u, float v, Taps &t) {
+__device__ __forceinline__ void fetch_taps_packed(const TexS &d, float u, float v, Taps &t, bool q8 = false /* wave-uniform: ARCTIC_OPT_SAMPLER bit 0 */) {
     int x0, y0;
     float fx, fy;
-    axis_nowrap(u, d.wf, x0, fx);
-    axis_nowrap(v, d.hf, y0, fy);
+    float x = axis_scaled(u, d.wf), y = axis_scaled(v, d.hf);
+    if (q8) { asm volatile(""); x = snap256(x); y = snap256(y); }   // (a real branch: one for both axes, nothing for the default sampler)
+    axis_split(x, x0, fx);
+    axis_split(y, y0, fy);
     // padded texel (x0 + 1, y0 + 1): (y0 * pitch + x0) + (pitch + 1) >= 0
     const uint32_t o = ((uint32_t)(__mul24(y0, (int)d.pitch) + x0) + (d.pitch + 1u)) << 3;
     t.r0 = gload_u4u(d.texels, o);
     t.r1 = gload_u4u(d.texels + (size_t)d.pitch * 8u, o);
     tap_weights(fx, fy, t);
 }
-__device__ __forceinline__ void fetch_taps_plain(const TexS &d, float u, float v, Taps &t) {
+__device__ __forceinline__ void fetch_taps_plain(const TexS &d, float u, float v, Taps &t, bool q8 = false) {
     int x0, x1, y0, y1;
     float fx, fy;
-    wrap_axis(u, d.w, x0, x1, fx);
-    wrap_axis(v, d.h, y0, y1, fy);
+    wrap_axis(u, d.w, x0, x1, fx, q8);
+    wrap_axis(v, d.h, y0, y1, fy, q8);
     const uint32_t r0 = (uint32_t)y0 * d.w, r1 = (uint32_t)y1 * d.w;
     t.r0.x = gload_u32(d.texels, (r0 + (uint32_t)x0) * 4u); t.r0.z = gload_u32(d.texels, (r0 + (uint32_t)x1) * 4u);
     t.r1.x = gload_u32(d.texels, (r1 + (uint32_t)x0) * 4u); t.r1.z = gload_u32(d.texels, (r1 + (uint32_t)x1) * 4u);
@@ -282,15 +317,15 @@ template <int K> __device__ __forceinline__ float filt_srgb(const Taps &t, const
 // Bit-exact against the oracle: the result is k/25 and one flipped comparison is a visible error.
 __device__ __forceinline__ float lerp_exact(float a, float b, float t) { return __builtin_fmaf(t, b - a, a); }
 
-__device__ __noinline__ float shadow_generic(const float *__restrict__ map, uint32_t S, float px, float py, float pz) {
+__device__ __noinline__ float shadow_generic(const float *__restrict__ map, uint32_t S, float px, float py, float pz, bool q8 = false) {
 #pragma clang fp contract(off)
     float shadow = 0.0f;
     for (int i = -2; i <= 2; ++i) {
         int x0, x1; float fx;
-        wrap_axis(px + (float)i * 0.0001f, S, x0, x1, fx);
+        wrap_axis(px + (float)i * 0.0001f, S, x0, x1, fx, q8);
         for (int j = -2; j <= 2; ++j) {
             int y0, y1; float fy;
-            wrap_axis(py + (float)j * 0.0001f, S, y0, y1, fy);
+            wrap_axis(py + (float)j * 0.0001f, S, y0, y1, fy, q8);
             const float *r0 = map + (size_t)y0 * S, *r1 = map + (size_t)y1 * S;
             float top = lerp_exact(r0[x0], r0[x1], fx), bot = lerp_exact(r1[x0], r1[x1], fx);
             float closest = lerp_exact(top, bot, fy);
@@ -313,15 +348,20 @@ __device__ __noinline__ float shadow_generic(const float *__restrict__ map, uint
 //                  shared between taps, which does not change any tap's value).
 // Lanes near the map border (WRAP would engage) or with a wider footprint use shadow_generic.
 
+// Q8: the D3D-style sampler for the taps (ARCTIC_OPT_SAMPLER bit 2; the oracle's SAMPLER_Q8_SHADOW): every scaled tap coordinate snapped to 1/256
+// texel before it is split into texel and weight.  The window is then the one of the SNAPPED coordinates (a coordinate may snap across an
+// integer); its span is checked like the plain one's, and whatever does not fit takes shadow_generic with the same sampler.
+template <bool CANDIDATES = false, bool Q8 = false>
 __device__ __forceinline__ float shadow_window(const float *__restrict__ map, uint32_t S, float px, float py, float pz, bool *tapped = nullptr /* statistics: this lane ran the 25 compares */) {
 #pragma clang fp contract(off)
     const float Sf = (float)S;
+    const auto scaled = [&](float u) { const float x = u * Sf - 0.5f; return Q8 ? snap256(x) : x; };
     // inside [0,1): u - floor(u) == u, so the coordinates below are wrap_axis without the wrap
     const float u0 = px + -0.0002f, u4 = px + 0.0002f, v0 = py + -0.0002f, v4 = py + 0.0002f;
-    const float xa = floorf(u0 * Sf - 0.5f), xb = floorf(u4 * Sf - 0.5f), ya = floorf(v0 * Sf - 0.5f), yb = floorf(v4 * Sf - 0.5f);
+    const float xa = floorf(scaled(u0)), xb = floorf(scaled(u4)), ya = floorf(scaled(v0)), yb = floorf(scaled(v4));
     const bool ok = u0 >= 0.0f && u4 < 1.0f && v0 >= 0.0f && v4 < 1.0f && xa >= 0.0f && ya >= 0.0f && xb - xa <= 2.0f && yb - ya <= 2.0f &&
                     xa + 3.0f < Sf && ya + 3.0f < Sf;
-    if (!ok) return shadow_generic(map, S, px, py, pz);
+    if (!ok) return shadow_generic(map, S, px, py, pz, Q8);
     const uint32_t o0 = ((uint32_t)(int)ya * S + (uint32_t)(int)xa) * 4u;   // byte offset: maps are at most 16384^2 floats
     const float4u w0 = gload_f4u(map, o0), w1 = gload_f4u(map, o0 + S * 4u), w2 = gload_f4u(map, o0 + S * 8u), w3 = gload_f4u(map, o0 + S * 12u);
     const float lo = fminf(fminf(fminf(fminf(w0.x, w0.y), fminf(w0.z, w0.w)), fminf(fminf(w1.x, w1.y), fminf(w1.z, w1.w))),
@@ -331,29 +371,51 @@ __device__ __forceinline__ float shadow_window(const float *__restrict__ map, ui
     if (pz > hi) return 1.0f;
     if (!(pz > lo)) return 0.0f;
     if (tapped) *tapped = true;
-    // the 25 compares, one tap column at a time (few live registers: this path sets the kernel's register count): the
-    // four horizontal lerps of column i, h[r] = lerp(w[r][c_i], w[r][c_i + 1], fx_i), are shared by its five taps
+    // The 25 compares, one tap column at a time.  A tap's texels are whichever CELL of the window it falls into, per lane -- selecting the two
+    // operands of every lerp costs four v_cndmask (4.3 issue cycles each) per lerp.  Round 5: each lerp is evaluated in all three candidate
+    // cells instead -- fmaf(t, b - a, a) with the differences b - a formed once per row (the oracle's own subtraction), three fused
+    // multiply-adds at 2.9 cycles -- and the RESULT of the lane's cell is selected (two v_cndmask): the same operations on the same operands
+    // for the cell that counts, so the same bits; 17 issue cycles per lerp instead of 23.
     float fy[5];
     bool r0[5], r1[5];   // row of tap j relative to the window: 0 / 1 / 2
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
-        const float y = (py + (float)(j - 2) * 0.0001f) * Sf - 0.5f, yf = floorf(y);
+        const float y = scaled(py + (float)(j - 2) * 0.0001f), yf = floorf(y);
         fy[j] = y - yf;
         r0[j] = yf == ya; r1[j] = yf == ya + 1.0f;
     }
     float shadow = 0.0f;
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-        const float x = (px + (float)(i - 2) * 0.0001f) * Sf - 0.5f, xf = floorf(x), fx = x - xf;
+        const float x = scaled(px + (float)(i - 2) * 0.0001f), xf = floorf(x), fx = x - xf;
         const bool c0 = xf == xa, c1 = xf == xa + 1.0f;
-        const float h0 = lerp_exact(c0 ? w0.x : (c1 ? w0.y : w0.z), c0 ? w0.y : (c1 ? w0.z : w0.w), fx);
-        const float h1 = lerp_exact(c0 ? w1.x : (c1 ? w1.y : w1.z), c0 ? w1.y : (c1 ? w1.z : w1.w), fx);
-        const float h2 = lerp_exact(c0 ? w2.x : (c1 ? w2.y : w2.z), c0 ? w2.y : (c1 ? w2.z : w2.w), fx);
-        const float h3 = lerp_exact(c0 ? w3.x : (c1 ? w3.y : w3.z), c0 ? w3.y : (c1 ? w3.z : w3.w), fx);
+        const auto pick = [](bool p0, bool p1, float v0, float v1, float v2) { return p0 ? v0 : (p1 ? v1 : v2); };
+        float h0, h1, h2, h3;
+        if (CANDIDATES && ARCTIC_PCF_ROW_CANDIDATES) {
+            // (the horizontal lerps the same way keep the window's twelve differences alive through all five columns: 76 VGPRs, a wave per SIMD lost)
+            h0 = pick(c0, c1, __builtin_fmaf(fx, w0.y - w0.x, w0.x), __builtin_fmaf(fx, w0.z - w0.y, w0.y), __builtin_fmaf(fx, w0.w - w0.z, w0.z));
+            h1 = pick(c0, c1, __builtin_fmaf(fx, w1.y - w1.x, w1.x), __builtin_fmaf(fx, w1.z - w1.y, w1.y), __builtin_fmaf(fx, w1.w - w1.z, w1.z));
+            h2 = pick(c0, c1, __builtin_fmaf(fx, w2.y - w2.x, w2.x), __builtin_fmaf(fx, w2.z - w2.y, w2.y), __builtin_fmaf(fx, w2.w - w2.z, w2.z));
+            h3 = pick(c0, c1, __builtin_fmaf(fx, w3.y - w3.x, w3.x), __builtin_fmaf(fx, w3.z - w3.y, w3.y), __builtin_fmaf(fx, w3.w - w3.z, w3.z));
+        } else {
+            h0 = lerp_exact(pick(c0, c1, w0.x, w0.y, w0.z), pick(c0, c1, w0.y, w0.z, w0.w), fx);
+            h1 = lerp_exact(pick(c0, c1, w1.x, w1.y, w1.z), pick(c0, c1, w1.y, w1.z, w1.w), fx);
+            h2 = lerp_exact(pick(c0, c1, w2.x, w2.y, w2.z), pick(c0, c1, w2.y, w2.z, w2.w), fx);
+            h3 = lerp_exact(pick(c0, c1, w3.x, w3.y, w3.z), pick(c0, c1, w3.y, w3.z, w3.w), fx);
+        }
+        if (CANDIDATES) {
+            const float e0 = h1 - h0, e1 = h2 - h1, e2 = h3 - h2;   // b - a down the column, for the three cells
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const float closest = lerp_exact(r0[j] ? h0 : (r1[j] ? h1 : h2), r0[j] ? h1 : (r1[j] ? h2 : h3), fy[j]);
-            shadow += pz > closest ? 1.0f : 0.0f;
+            for (int j = 0; j < 5; ++j) {
+                const float closest = pick(r0[j], r1[j], __builtin_fmaf(fy[j], e0, h0), __builtin_fmaf(fy[j], e1, h1), __builtin_fmaf(fy[j], e2, h2));
+                shadow += pz > closest ? 1.0f : 0.0f;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const float closest = lerp_exact(pick(r0[j], r1[j], h0, h1, h2), pick(r0[j], r1[j], h1, h2, h3), fy[j]);
+                shadow += pz > closest ? 1.0f : 0.0f;
+            }
         }
     }
     return shadow / 25.0f;
@@ -417,16 +479,16 @@ __device__ __forceinline__ bool shadow_lds_tile(const ShadowArgs &sa, float *til
 // 1 - shadow in two steps.  shadow_quick decides from the bounds table where it can (and for every pixel outside the map);
 // returns false for the lanes that need shadow_slow: tiles on a shadow edge, the map's border, maps above 5000^2.
 // (ShadowPos, shadow_coords, shadow_table_offset: shadow_coords.h, shared with the prepass's cost hint)
-__device__ __forceinline__ bool shadow_table_entry(const ShadowArgs &sa, const ShadowPos &p, uint32_t &offset) { return shadow_table_offset(sa.S, sa.pitch, p, offset); }
+__device__ __forceinline__ bool shadow_table_entry(const ShadowArgs &sa, const ShadowPos &p, uint32_t &offset, bool q8) { return shadow_table_offset(sa.S, sa.pitch, p, offset, q8 ? 4u : 3u); }
 // in two steps, so that a caller can put other work (a batch of scalar loads) between the table load and its use:
 //   shadow_quick_issue   coordinates + the load of the table entry; returns whether the pixel is within the table's reach
 //   shadow_quick_decide  lit = 0 / 1 where the entry (or the map's border rule) decides; false: the pixel needs shadow_slow
-__device__ __forceinline__ bool shadow_quick_issue(const ShadowArgs &sa, float lsx, float lsy, float lsz, float lsw, ShadowPos &p, float2 &mm, uint32_t *offset_out = nullptr) {
+__device__ __forceinline__ bool shadow_quick_issue(const ShadowArgs &sa, float lsx, float lsy, float lsz, float lsw, ShadowPos &p, float2 &mm, uint32_t *offset_out = nullptr, bool q8 = false /* wave-uniform */) {
     mm = make_float2(0.0f, 0.0f);
     if (sa.map == nullptr) return false;
     shadow_coords(lsx, lsy, lsz, lsw, p);
     uint32_t offset = 0;
-    const bool in_table = sa.bounds != nullptr && shadow_table_entry(sa, p, offset);   // (a table only for S <= 4900: shadow_bounds_pitch)
+    const bool in_table = sa.bounds != nullptr && shadow_table_entry(sa, p, offset, q8);   // (a table only for S <= 4900: shadow_bounds_pitch)
     if (in_table) mm = gload_f2(sa.bounds, offset);
     if (offset_out) *offset_out = offset;
     return in_table;
@@ -441,13 +503,14 @@ __device__ __forceinline__ bool shadow_quick_decide(const ShadowArgs &sa, bool i
     // outside the map: no shadow (forward.hlsl:75-77); everything else takes the slow path
     return p.pz > 1.0f || p.px < 0.0f || p.py < 0.0f || p.px > 1.0f || p.py > 1.0f;
 }
-__device__ __forceinline__ bool shadow_quick(const ShadowArgs &sa, float lsx, float lsy, float lsz, float lsw, ShadowPos &p, float &lit) {
+__device__ __forceinline__ bool shadow_quick(const ShadowArgs &sa, float lsx, float lsy, float lsz, float lsw, ShadowPos &p, float &lit, bool q8 = false) {
     float2 mm;
-    const bool in_table = shadow_quick_issue(sa, lsx, lsy, lsz, lsw, p, mm);
+    const bool in_table = shadow_quick_issue(sa, lsx, lsy, lsz, lsw, p, mm, nullptr, q8);
     return shadow_quick_decide(sa, in_table, p, mm, lit);
 }
-__device__ __forceinline__ float shadow_slow(const ShadowArgs &sa, const ShadowPos &p) {
+__device__ __forceinline__ float shadow_slow(const ShadowArgs &sa, const ShadowPos &p, bool q8 = false /* wave-uniform */) {
     const uint32_t S = sa.S;
+    if (q8) { asm volatile(""); return 1.0f - (S <= 5000u ? shadow_window<false, true>(sa.map, S, p.px, p.py, p.pz) : shadow_generic(sa.map, S, p.px, p.py, p.pz, true)); }
     return 1.0f - (S <= 5000u ? shadow_window(sa.map, S, p.px, p.py, p.pz) : shadow_generic(sa.map, S, p.px, p.py, p.pz));
 }
 
@@ -556,8 +619,9 @@ PK_DEFS2(0, 1)
 PK_DEFS2(1, 0)
 PK_DEFS2(1, 1)
 __device__ __forceinline__ v2 pk_fma(v2 a, v2 b, v2 c) { return __builtin_elementwise_fma(a, b, c); }
-// colour (SGPR pair) * s + acc
-__device__ __forceinline__ v2 pk_fma_s(v2 c, v2 s, v2 acc) { v2 r; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "s"(c), "v"(s), "v"(acc)); return r; }
+// acc += colour (SGPR pair) * s, IN PLACE: with a separate result register the compiler renames the 18 sums between the two halves of the
+// unrolled loop -- 18 copies at one of its exits and a second set of 18 zeroes in front of it (round 5: read off the ISA)
+__device__ __forceinline__ void pk_fma_s(v2 c, v2 s, v2 &acc) { asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "s"(c), "v"(s)); }
 // v_pk_mul_f32 with the clamp bit: sat(a * b) for both halves in one instruction (no packed max/min exists for fp32)
 __device__ __forceinline__ v2 pk_mul_sat(v2 a, v2 b) { v2 r; asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b)); return r; }
 // Transcendentals.  gfx950 needs one wait state between a transcendental and a VALU instruction that reads its result; the
@@ -640,9 +704,9 @@ __device__ __forceinline__ v2 accumulate_pair(const PackedPix &k, v2 dx, v2 dy, 
     const v2 p5 = m2 * m2 * m;
     const v2 s2 = (sc * ndwi) * rden;
     const v2 s1 = pk_fma(-sc, p5, sc), s3 = s2 * p5;
-    S.a[0] = pk_fma_s(cr, s1, S.a[0]); S.a[1] = pk_fma_s(cg, s1, S.a[1]); S.a[2] = pk_fma_s(cb, s1, S.a[2]);
-    S.b[0] = pk_fma_s(cr, s2, S.b[0]); S.b[1] = pk_fma_s(cg, s2, S.b[1]); S.b[2] = pk_fma_s(cb, s2, S.b[2]);
-    S.c[0] = pk_fma_s(cr, s3, S.c[0]); S.c[1] = pk_fma_s(cg, s3, S.c[1]); S.c[2] = pk_fma_s(cb, s3, S.c[2]);
+    pk_fma_s(cr, s1, S.a[0]); pk_fma_s(cg, s1, S.a[1]); pk_fma_s(cb, s1, S.a[2]);
+    pk_fma_s(cr, s2, S.b[0]); pk_fma_s(cg, s2, S.b[1]); pk_fma_s(cb, s2, S.b[2]);
+    pk_fma_s(cr, s3, S.c[0]); pk_fma_s(cg, s3, S.c[1]); pk_fma_s(cb, s3, S.c[2]);
     return nd;
 }
 
@@ -907,7 +971,7 @@ __device__ __forceinline__ f3 lit_radiance(SP sp, uint32_t lane, float nr, float
 // that kind (decided wave-wide; the texel loads already issued are then dropped): the caller shades it with shade_tile.
 // `second(pc, pd, pe, gc, gd, ge)` delivers the lit pixels' remaining attributes (world position + tangent frame, packed like the
 // G-buffer planes c, d, e): loaded from the G-buffer, or interpolated on the spot by the visibility-buffer kernel.
-template <int LOOP, bool STATS, class Second>
+template <int LOOP, bool STATS, bool PCF_CAND, class Second>
 __device__ __forceinline__ bool shade_tile_fast(SP sp, KernArgs args, const ArgsA &A, const float *lut, uint32_t ty, uint32_t tx, uint32_t lane, const TileHead &cur, Second second) {
     ArgsB B = args_b(args);   // (the head of the tile is in flight)
     const int32_t row0 = (int32_t)(ty * 8) - (int32_t)B.row0_in_tile;   // the tile's first pixel row in the target (wave-uniform)
@@ -924,12 +988,13 @@ __device__ __forceinline__ bool shade_tile_fast(SP sp, KernArgs args, const Args
     ShadowPos spos;
     float2 mm;
     uint32_t toff = 0;
-    const bool in_table = shadow_quick_issue(B.sh, lsx, cur.a.w, cur.b0, cur.b1, spos, mm, &toff);
+    const bool q8s = (A.debug & SAMPLER_Q8_SHADOW) != 0;   // (wave-uniform: ARCTIC_OPT_SAMPLER)
+    const bool in_table = shadow_quick_issue(B.sh, lsx, cur.a.w, cur.b0, cur.b1, spos, mm, &toff, q8s);
     // ---- A: material fetch, forward.hlsl:98-124: two 16-byte texel loads
     TexS d0 = tex_desc_wait(dv, toff);
     if (!d0.packed) return false;
     Taps pt;
-    fetch_taps_packed(d0, cur.a.x, cur.a.y, pt);
+    fetch_taps_packed(d0, cur.a.x, cur.a.y, pt, (A.debug & SAMPLER_Q8_MATERIAL) != 0);
     ArgsC C = args_c(args, A, B);   // the next batch of arguments arrives in the shadow of those loads
     float lit;
     const bool decided = shadow_quick_decide(B.sh, in_table, spos, mm, lit);
@@ -945,7 +1010,8 @@ __device__ __forceinline__ bool shade_tile_fast(SP sp, KernArgs args, const Args
         asm("" : "=v"(pt.r0.x), "=v"(pt.r0.y), "=v"(pt.r0.z), "=v"(pt.r0.w), "=v"(pt.r1.x), "=v"(pt.r1.y), "=v"(pt.r1.z), "=v"(pt.r1.w));
         asm("" : "=v"(pt.w00), "=v"(pt.w10), "=v"(pt.w01), "=v"(pt.w11));
         bool tapped = false;
-        if (!decided) lit = 1.0f - shadow_window(B.sh.map, B.sh.S, spos.px, spos.py, spos.pz, STATS ? &tapped : nullptr);
+        if (q8s) { asm volatile(""); if (!decided) lit = 1.0f - shadow_window<false, true>(B.sh.map, B.sh.S, spos.px, spos.py, spos.pz); }   // (no statistics of this one)
+        else if (!decided) lit = 1.0f - shadow_window<PCF_CAND>(B.sh.map, B.sh.S, spos.px, spos.py, spos.pz, STATS ? &tapped : nullptr);
         if (STATS) {   // [5] tiles with a pixel the table left undecided, [6] such pixels, [7] tiles that ran the 25 compares, [8] pixels that did
             const unsigned long long und = __ballot(!decided), tap = __ballot(tapped);
             if (wave_lane() == 0) {
@@ -959,7 +1025,7 @@ __device__ __forceinline__ bool shade_tile_fast(SP sp, KernArgs args, const Args
         B = args_b(args);
         C = args_c(args, A, B);
         d0 = tex_desc(B.tex, m0 * 3);
-        fetch_taps_packed(d0, cur.a.x, cur.a.y, pt);
+        fetch_taps_packed(d0, cur.a.x, cur.a.y, pt, (A.debug & SAMPLER_Q8_MATERIAL) != 0);
     }
     // exact culling: Lo of ps_main is a sum of terms each multiplied by (1 - shadow) (point lights too: forward.hlsl:222,
     // 230), so a fully shadowed pixel is ambient * base and needs neither the sun, nor any point light, nor its normal,
@@ -1006,6 +1072,7 @@ __device__ __forceinline__ void shade_tile(SP sp, const float *lut, float *shado
     const bool covered = in_frame && mat < sp.n_materials;
     const uint32_t o = (uint32_t)y * sp.width + x;   // targets are at most 16384^2 pixels
     const float u = cur.a.x, v = cur.a.y;
+    const bool q8m = (sp.debug & SAMPLER_Q8_MATERIAL) != 0, q8s = (sp.debug & SAMPLER_Q8_SHADOW) != 0;   // ARCTIC_OPT_SAMPLER (wave-uniform)
 
     // ---- A: material fetch, forward.hlsl:98-124.  Texel loads of packed materials stay in flight over the shadow test.
     Taps pt;
@@ -1022,10 +1089,10 @@ __device__ __forceinline__ void shade_tile(SP sp, const float *lut, float *shado
         auto fetch = [&](uint32_t m, bool mine) {   // m wave-uniform: the descriptor comes through the scalar unit
             const TexS d0 = tex_desc(sp.tex, m * 3);
             if (mine) {
-                if (d0.packed) fetch_taps_packed(d0, u, v, pt);
+                if (d0.packed) fetch_taps_packed(d0, u, v, pt, q8m);
                 else {
                     Taps t0;
-                    fetch_taps_plain(d0, u, v, t0);
+                    fetch_taps_plain(d0, u, v, t0, q8m);
                     base = mk(filt_srgb<0>(t0, lut), filt_srgb<1>(t0, lut), filt_srgb<2>(t0, lut));
                     plain = true;
                 }
@@ -1052,10 +1119,10 @@ __device__ __forceinline__ void shade_tile(SP sp, const float *lut, float *shado
     if (!(sp.debug & 2)) {
         ShadowPos spos;
         const ShadowArgs sh = shadow_args(sp);
-        const bool decided = !covered || shadow_quick(sh, cur.a.z, cur.a.w, cur.b0, cur.b1, spos, lit);
+        const bool decided = !covered || shadow_quick(sh, cur.a.z, cur.a.w, cur.b0, cur.b1, spos, lit, q8s);
         if (__ballot(!decided) != 0ull) {   // a tile on a shadow edge (or at the map's border)
-            const bool staged = LDS_SHADOW && sh.S <= 5000u && shadow_lds_tile(sh, shadow_tile, lane, !decided, spos.px, spos.py, spos.pz, lit);
-            if (!staged && !decided) lit = shadow_slow(sh, spos);
+            const bool staged = LDS_SHADOW && !q8s && sh.S <= 5000u && shadow_lds_tile(sh, shadow_tile, lane, !decided, spos.px, spos.py, spos.pz, lit);
+            if (!staged && !decided) lit = shadow_slow(sh, spos, q8s);
             // the 25-tap path is what sets the kernel's register count: the texels fetched above are dropped across it and
             // fetched again (cache hits; such tiles are few) instead of being kept alive through it
             fetch_material();
@@ -1093,8 +1160,8 @@ __device__ __forceinline__ void shade_tile(SP sp, const float *lut, float *shado
                 const TexS d1 = tex_desc(sp.tex, m * 3 + 1), d2 = tex_desc(sp.tex, m * 3 + 2);
                 if (mine) {
                     Taps t1, t2;
-                    fetch_taps_plain(d1, u, v, t1);
-                    fetch_taps_plain(d2, u, v, t2);
+                    fetch_taps_plain(d1, u, v, t1, q8m);
+                    fetch_taps_plain(d2, u, v, t2, q8m);
                     nr = filt_bytes<0, 0>(t1); ng = filt_bytes<0, 1>(t1); nb = filt_bytes<0, 2>(t1);
                     rough = filt_unorm<0, 1>(t2); metal = filt_unorm<0, 2>(t2);
                 }
@@ -1228,7 +1295,7 @@ __global__ __launch_bounds__(64 * ARCTIC_WG_WAVES) __attribute__((amdgpu_waves_p
         const auto second = [&](const float4 *pc, const float4 *pd, const float4 *pe, float4 &gc, float4 &gd, float4 &ge) {
             gc = gload_f4(pc + tile * 64, lane * 16u); gd = gload_f4(pd + tile * 64, lane * 16u); ge = gload_f4(pe + tile * 64, lane * 16u);
         };
-        const bool fast = shade_tile_fast<LOOP, STATS>(sp, args, A, lut, ty, tx, lane, cur, second);
+        const bool fast = shade_tile_fast<LOOP, STATS, ARCTIC_PCF_CANDIDATES != 0>(sp, args, A, lut, ty, tx, lane, cur, second);
         if (!fast) shade_tile<LOOP, STATS, LDS_SHADOW>(sp, lut, shadow_tiles[LDS_SHADOW ? wave : 0], ty, tx, lane, cur, second);
         trace_end(sp, A, tile, fast);
         if (++k >= A.T) break;
@@ -1376,7 +1443,7 @@ __global__ __launch_bounds__(64 * ARCTIC_WG_WAVES) __attribute__((amdgpu_waves_p
             ge = make_float4(interpolate_attr(B, A0, A1, A2, 7), interpolate_attr(B, A0, A1, A2, 8), interpolate_attr(B, A0, A1, A2, 9), interpolate_attr(B, A0, A1, A2, 10));
         }
     };
-    const bool fast = shade_tile_fast<LOOP, STATS>(sp, args, A, lut, ty, tx, lane, cur, second);
+    const bool fast = shade_tile_fast<LOOP, STATS, false>(sp, args, A, lut, ty, tx, lane, cur, second);
     if (!fast) shade_tile<LOOP, STATS, LDS_SHADOW>(sp, lut, shadow_tiles[LDS_SHADOW ? wave : 0], ty, tx, lane, cur, second);
     trace_end(sp, A, (size_t)ty * A.tiles_x + tx, fast);
     if (++k >= A.T) break;

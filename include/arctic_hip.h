@@ -313,6 +313,13 @@ int arctic_stats(ArcticRenderer *r, uint64_t *out, uint32_t n);
                                           the shading pass, and strips dealt by cost no longer share an XCD's L2 with their neighbours (+83 MB of fabric reads
                                           per 4K pass: profiles/r5_a_traffic_tile_order.json) */
 #define ARCTIC_OPT_ORDER_TAIL        20 /* per mille of the dispatch order, at its end, that holds cheap tiles only (default 60) */
+#define ARCTIC_OPT_SAMPLER           21 /* which arithmetic stands in for the reference's D3D12 sampler (MIN_MAG_MIP_LINEAR + WRAP, forward_pass.cpp:38-51; the
+                                          shadow map goes through the same sampler, forward.hlsl:84-92).  0 (default) = texel coordinates and bilinear weights in
+                                          full fp32.  Bit 0: material textures with the scaled coordinate u W - 0.5 snapped to 1/256 texel (round to nearest)
+                                          before it is split into texel index and weight -- 8-bit filter weights, what the D3D11.3 functional specification
+                                          (3.2.4.1, 7.18.8) lets a sampler do and hardware does.  Bit 2: the same for the 25 PCF taps.  Same bits as the oracle's
+                                          oracle_set_sampler_mode (its bit 1, sRGB decode after filtering, is an oracle-only bound: D3D10+ decodes first).
+                                          A DX12 host comparing against captures of the real reference should pick 5; INTEGRATION.md section 7 */
 #define ARCTIC_OPT_MARKERS          13 /* 1 = roctx ranges around each pass, named like the reference's Tracy zones (process-wide; libroctx64 is loaded on demand) */
 int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value);
 
