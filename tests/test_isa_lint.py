@@ -111,3 +111,17 @@ def test_shading_kernels_keep_their_register_budgets(shade_isa):
     for loop in (1, 2):
         k = res[f"_ZN6arctic12_GLOBAL__N_114k_material_visILi{loop}ELb0ELb0EEEvNS_11ShadeParamsE"]   # whole frames: 6 waves (7 measured slower)
         assert k["vgprs"] <= 80 and k["scratch"] == 0, (loop, k)
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")
+@pytest.mark.parametrize("defines", [("-DARCTIC_WG_WAVES=1", "-DARCTIC_EDGE_IN_FAST=0"),
+                                     ("-DARCTIC_LUT_SHARED=1", "-DARCTIC_PCF_CANDIDATES=1", "-DARCTIC_PCF_ROW_CANDIDATES=1")],
+                         ids=["one-wave-workgroups+edge-tiles-to-general-tile", "shared-lut+pcf-candidates"])
+def test_ab_switches_still_compile(tmp_path, defines):
+    """the A/B compile switches of shade.hip (measured variants kept behind a default: DESIGN 4.2c, profiles/r4_c_*, r5_a_*, r5_b_*) build for gfx950 with
+    their non-default values -- device code through the backend (register allocation included), nothing is run"""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = os.path.join(ROOT, "arctic-renderer_amd", "csrc", "shade.hip")
+    out = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "--offload-device-only", "-ffp-contract=off", "-mllvm", "-disable-machine-licm",
+                          *defines, "-c", src, "-o", str(tmp_path / "shade_variant.o")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
