@@ -207,7 +207,11 @@ struct TexDesc {
     uint32_t w, h;           // image size (without the border); w bit 31: packed
     float wf, hf;            // (float)w, (float)h: exact (sides are below 65536)
     uint32_t pitch;          // packed: texels per row of the bordered image = w + 2
-    uint32_t pad;
+    uint32_t tile_row_bytes; // packed only.  0: the bordered image is row-major.  Otherwise it is stored in TILES of 4 x 4 texels (128 bytes = one cache line, row-major
+                             // inside the tile), tile_row_bytes = 128 * tiles per row of tiles: padded texel (X, Y) at (Y >> 2) * tile_row_bytes + (X >> 2) * 128 +
+                             // ((Y & 3) * 4 + (X & 3)) * 8.  The reference creates ONE mip level (rhi.cpp:550), so a large texture on a small object is minified at
+                             // mip 0: every pixel's 2 x 2 footprint is then its own cache lines -- two of them in a row-major image (the footprint's two rows),
+                             // (1 + 1/4)^2 = 1.56 on average in 4 x 4 tiles (round 5; the choice is made per material at creation: ARCTIC_OPT_TEXTURE_TILING)
 };
 static_assert(sizeof(TexDesc) == 32, "TexDesc layout (tex_desc loads it with one s_load_dwordx8)");
 constexpr uint32_t TEX_INTERLEAVED = 0x80000000u;

@@ -219,6 +219,7 @@ struct ArcticRenderer {
     // a stale or missing order changes the pass's time, never its image.
     DevBuf d_tile_class, d_order_lists, d_tile_order;
     bool have_order = false;         // d_tile_order belongs to the G-buffer in place
+    int texture_tiling = -1;         // ARCTIC_OPT_TEXTURE_TILING: materials created from now on: -1 = 4 x 4-texel tiles for images of 2048 texels a side and more, 0 = never, 1 = always
     int sampler = 0;                 // ARCTIC_OPT_SAMPLER: bit 0 material footprints, bit 2 PCF taps with coordinates snapped to 1/256 texel (D3D-style 8-bit filter weights)
     int tile_order = 0;              // ARCTIC_OPT_TILE_ORDER: 0 (default since round 5) = the geometric, XCD-aware order of round 3; 1 = the cost-class order of round 4.
                                      // Measured (profiles/r5_a_*): the order gains <= 2 us of the pass, its one-workgroup kernel costs the G-buffer pass 112 us, and handing strips
@@ -898,13 +899,20 @@ int arctic_create_material(ArcticRenderer *r, const void *diffuse, uint32_t dw, 
         // equal sizes (the usual glTF case): pack the eight channels ps_main reads into 8-byte texels, with a one-texel WRAP
         // border around the image (layout: common.h TexDesc, shade.hip)
         const uint32_t pw = dw + 2, ph = dh + 2;
-        size_t n = (size_t)pw * ph;
+        // 4 x 4-texel tiles for textures that will be minified at their only mip level (common.h TexDesc::tile_row_bytes): the library's choice is by
+        // size -- a 2048^2 image on a model that covers a part of a 1080p or 4K frame is sampled several texels apart, a 1024^2 wall texture about 1:1,
+        // where the row-major strips of neighbouring pixels share their lines and the tiled address (15 instructions against 3) would only cost
+        const bool tiled = r->texture_tiling < 0 ? std::min(dw, dh) >= 2048u : r->texture_tiling != 0;
+        const uint32_t tpr = (pw + 3) / 4, trows = (ph + 3) / 4;
+        size_t n = tiled ? (size_t)tpr * trows * 16 : (size_t)pw * ph;
+        if (n > (1ull << 29)) return r->fail(ARCTIC_E_CAPACITY, "create_material: image above 2^29 texels");
         std::vector<uint32_t> packed(n * 2);
         const uint8_t *a = static_cast<const uint8_t *>(diffuse), *b = static_cast<const uint8_t *>(normal), *c = static_cast<const uint8_t *>(mr);
         for (uint32_t Y = 0; Y < ph; ++Y) {
             const size_t sy = (size_t)((Y + dh - 1) % dh) * dw;
             for (uint32_t X = 0; X < pw; ++X) {
-                const size_t i = sy + (X + dw - 1) % dw, o = (size_t)Y * pw + X;
+                const size_t i = sy + (X + dw - 1) % dw;
+                const size_t o = tiled ? ((size_t)(Y >> 2) * tpr + (X >> 2)) * 16 + (Y & 3) * 4 + (X & 3) : (size_t)Y * pw + X;
                 packed[2 * o] = (uint32_t)a[4 * i] | ((uint32_t)a[4 * i + 1] << 8) | ((uint32_t)a[4 * i + 2] << 16) | ((uint32_t)b[4 * i] << 24);
                 packed[2 * o + 1] = (uint32_t)b[4 * i + 1] | ((uint32_t)b[4 * i + 2] << 8) | ((uint32_t)c[4 * i + 1] << 16) | ((uint32_t)c[4 * i + 2] << 24);
             }
@@ -913,7 +921,7 @@ int arctic_create_material(ArcticRenderer *r, const void *diffuse, uint32_t dw, 
         HIPCHECK(r, hipMalloc(&p, n * 8));
         r->tex_allocs.push_back(p);
         HIPCHECK(r, hipMemcpy(p, packed.data(), n * 8, hipMemcpyHostToDevice));   // synchronous like rhi.cpp:480-519
-        for (int i = 0; i < 3; ++i) { td[i] = TexDesc{static_cast<const uint32_t *>(p), dw | TEX_INTERLEAVED, dh, (float)dw, (float)dh, pw, 0u}; }
+        for (int i = 0; i < 3; ++i) { td[i] = TexDesc{static_cast<const uint32_t *>(p), dw | TEX_INTERLEAVED, dh, (float)dw, (float)dh, pw, tiled ? tpr * 128u : 0u}; }
     } else {
         for (int i = 0; i < 3; ++i) {
             void *p = nullptr;
@@ -1357,6 +1365,7 @@ int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value) {
         r->tiles_per_wave = (uint32_t)value;
         break;
     case ARCTIC_OPT_TILE_TRACE: r->tile_trace = value != 0; break;
+    case ARCTIC_OPT_TEXTURE_TILING: r->texture_tiling = value < 0 ? -1 : (value != 0); break;
     case ARCTIC_OPT_SAMPLER:
         if (value < 0 || (value & ~5ll)) return r->fail(ARCTIC_E_INVALID, "set_option: sampler is a mask of bit 0 (material footprints) and bit 2 (PCF taps); bit 1 (sRGB decode after filtering) exists in the oracle only");
         r->sampler = (int)value;

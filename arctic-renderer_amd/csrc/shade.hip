@@ -193,7 +193,7 @@ __device__ __forceinline__ void wrap_axis(float u, uint32_t n, int &i0, int &i1,
 // reads (forward.hlsl:98-124), with a one-texel WRAP border around it (common.h TexDesc):
 //   word 0 = diffuse.r | diffuse.g << 8 | diffuse.b << 16 | normal.r << 24
 //   word 1 = normal.g | normal.b << 8 | metal_rough.g << 16 | metal_rough.b << 24
-struct TexS { const uint8_t *texels; uint32_t w, h, packed; float wf, hf; uint32_t pitch; };
+struct TexS { const uint8_t *texels; uint32_t w, h, packed; float wf, hf; uint32_t pitch, tile_row_bytes; };
 // The descriptor is fetched with an explicit s_load: written as a plain load the compiler sinks it into the `mat == m` branch
 // of the waterfall loop, replaces the uniform m by the per-lane mat it equals there, and issues a vector load per lane.
 typedef uint32_t u4v __attribute__((ext_vector_type(4)));
@@ -203,7 +203,7 @@ __device__ __forceinline__ TexS tex_decode(const u8v &v) {
     t.texels = reinterpret_cast<const uint8_t *>(((unsigned long long)v[1] << 32) | v[0]);
     t.w = v[2] & 0x7FFFFFFFu; t.h = v[3];
     t.packed = v[2] >> 31;   // TexDesc::w bit 31
-    t.wf = __uint_as_float(v[4]); t.hf = __uint_as_float(v[5]); t.pitch = v[6];
+    t.wf = __uint_as_float(v[4]); t.hf = __uint_as_float(v[5]); t.pitch = v[6]; t.tile_row_bytes = v[7];
     return t;
 }
 __device__ __forceinline__ TexS tex_desc(const TexDesc *tex, uint32_t i /* wave-uniform */) {
@@ -275,10 +275,20 @@ __device__ __forceinline__ void fetch_taps_packed(const TexS &d, float u, float 
     if (q8) { asm volatile(""); x = snap256(x); y = snap256(y); }   // (a real branch: one for both axes, nothing for the default sampler)
     axis_split(x, x0, fx);
     axis_split(y, y0, fy);
-    // padded texel (x0 + 1, y0 + 1): (y0 * pitch + x0) + (pitch + 1) >= 0
-    const uint32_t o = ((uint32_t)(__mul24(y0, (int)d.pitch) + x0) + (d.pitch + 1u)) << 3;
-    t.r0 = gload_u4u(d.texels, o);
-    t.r1 = gload_u4u(d.texels + (size_t)d.pitch * 8u, o);
+    if (d.tile_row_bytes) {   // (wave-uniform) 4 x 4-texel tiles, common.h TexDesc::tile_row_bytes: four 8-byte loads, a texel of the footprint may sit in the next tile
+        asm volatile("");
+        const uint32_t X = (uint32_t)(x0 + 1), Y = (uint32_t)(y0 + 1), rx = X & 3u, ry = Y & 3u;
+        const uint32_t o00 = ((__umul24(Y >> 2, d.tile_row_bytes >> 7) + (X >> 2)) << 7) + ((ry * 4u + rx) << 3);
+        const uint32_t dx = rx == 3u ? 128u - 24u : 8u, dy = ry == 3u ? d.tile_row_bytes - 96u : 32u;
+        const uint2 a = gload_u2(d.texels, o00), b = gload_u2(d.texels, o00 + dx), c = gload_u2(d.texels, o00 + dy), e = gload_u2(d.texels, o00 + dy + dx);
+        t.r0 = (u4v){a.x, a.y, b.x, b.y};
+        t.r1 = (u4v){c.x, c.y, e.x, e.y};
+    } else {
+        // padded texel (x0 + 1, y0 + 1): (y0 * pitch + x0) + (pitch + 1) >= 0
+        const uint32_t o = ((uint32_t)(__mul24(y0, (int)d.pitch) + x0) + (d.pitch + 1u)) << 3;
+        t.r0 = gload_u4u(d.texels, o);
+        t.r1 = gload_u4u(d.texels + (size_t)d.pitch * 8u, o);
+    }
     tap_weights(fx, fy, t);
 }
 __device__ __forceinline__ void fetch_taps_plain(const TexS &d, float u, float v, Taps &t, bool q8 = false) {

@@ -216,10 +216,14 @@ def main():
     t0 = time.time()
     sc = pkg.scenes.CONFIGS[args.config](scale=args.scale)
     BAND = 16   # N > 1: rows are dealt to the ranks in interleaved bands of 16 (lit regions are clustered: load balance)
-    if world > 1:
-        r = sc.upload(pkg.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights, device=local, band_rows=BAND, shard=(rank, world)))
-    else:
-        r = sc.upload(pkg.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights, device=local))
+    tiling = os.environ.get("ARCTIC_BENCH_TEXTURE_TILING")   # A/B only: ARCTIC_OPT_TEXTURE_TILING for the materials (default: the library's choice by image size)
+
+    def new_handle(**kw):
+        h = pkg.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights, device=local, **kw)
+        if tiling is not None:
+            h.set_option("texture_tiling", int(tiling))
+        return sc.upload(h)
+    r = new_handle(band_rows=BAND, shard=(rank, world)) if world > 1 else new_handle()
     # the library launches on torch's stream (torch events see its kernels) -- set before the communicator is made: the exchange then
     # runs on the handle's own stream, idle from here on, instead of a stream more (hardware queues are few: DESIGN.md 4.3)
     r.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -267,7 +271,7 @@ def main():
     rotation = [r]
     if world == 1 and working_set < (512 << 20) and os.environ.get("ARCTIC_BENCH_ROTATE", "1") != "0":
         for _ in range(2):
-            h = sc.upload(pkg.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights, device=local))
+            h = new_handle()
             h.set_stream(torch.cuda.current_stream().cuda_stream)
             h.set_option("tile_order", tile_order)
             h.pass_shadow_map(sc.desc)

@@ -320,6 +320,10 @@ int arctic_stats(ArcticRenderer *r, uint64_t *out, uint32_t n);
                                           (3.2.4.1, 7.18.8) lets a sampler do and hardware does.  Bit 2: the same for the 25 PCF taps.  Same bits as the oracle's
                                           oracle_set_sampler_mode (its bit 1, sRGB decode after filtering, is an oracle-only bound: D3D10+ decodes first).
                                           A DX12 host comparing against captures of the real reference should pick 5; INTEGRATION.md section 7 */
+#define ARCTIC_OPT_TEXTURE_TILING    22 /* how arctic_create_material stores the packed image of a material from now on: -1 (default) = the library's choice, tiles of
+                                          4 x 4 texels (one 128-byte line each) for images of 2048 texels a side and more, row-major below; 0 = row-major; 1 = tiles.
+                                          The reference creates one mip level (rhi.cpp:550), so large textures are minified at mip 0 and every pixel's footprint is its
+                                          own cache lines: 2 in a row-major image, 1.56 on average in tiles.  A layout only: same texels, same image */
 #define ARCTIC_OPT_MARKERS          13 /* 1 = roctx ranges around each pass, named like the reference's Tracy zones (process-wide; libroctx64 is loaded on demand) */
 int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value);
 

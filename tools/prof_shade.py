@@ -8,8 +8,9 @@ args=[a for a in sys.argv[1:] if "=" not in a]
 mode=args[0] if len(args)>0 else "full"
 cfg=int(args[1]) if len(args)>1 else 3      # BASELINE config number (default 3: the metric's)
 sc=pkg.scenes.CONFIGS[cfg](scale=1.0)
-r=sc.upload(pkg.Renderer(sc.width,sc.height,sc.shadow_size,sc.max_lights))
-for o in opts: r.set_option(o.split('=')[0], int(o.split('=')[1]))
+r=pkg.Renderer(sc.width,sc.height,sc.shadow_size,sc.max_lights)
+for o in opts: r.set_option(o.split('=')[0], int(o.split('=')[1]))   # (before the upload: texture_tiling applies to materials created afterwards)
+sc.upload(r)
 r.pass_shadow_map(sc.desc); r.pass_gbuffer(sc.desc); r.flush()
 if mode=="nolights": r.update_lights(sc.lights[:0])
 if mode=="nocull": r.set_option("culling",0)

@@ -6,7 +6,8 @@
 # from FETCH_SIZE's point of view: it counts requests leaving L2).
 set -e -o pipefail
 CFG=${1:?usage: profile_config.sh <config> <tag>}
-TAG=${2:?usage: profile_config.sh <config> <tag>}
+TAG=${2:?usage: profile_config.sh <config> <tag> [option=value ...]}
+shift 2   # what is left: arctic_set_option pairs for tools/prof_shade.py
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
@@ -14,7 +15,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES"; do
     i=$((i + 1))
-    rocprofv3 --pmc $set --kernel-trace --stats --output-format csv -d "$OUT/pmc$i" -- python3 "$ROOT/tools/prof_shade.py" full "$CFG" > "$OUT/pmc$i.log" 2>&1
+    rocprofv3 --pmc $set --kernel-trace --stats --output-format csv -d "$OUT/pmc$i" -- python3 "$ROOT/tools/prof_shade.py" full "$CFG" "$@" > "$OUT/pmc$i.log" 2>&1
     echo "[profile] config $CFG counters pass $i done: $set"
 done
 cd "$ROOT"
