@@ -9,12 +9,35 @@ namespace arctic {
 // floor and convert in one instruction (exact for |x| < 2^31)
 __device__ __forceinline__ int floor_to_int(float x) { int i; asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(i) : "v"(x)); return i; }
 
+#ifndef ARCTIC_NEAR_ONE_DIVISION
+#define ARCTIC_NEAR_ONE_DIVISION 1   // A/B switch: 0 = three full IEEE divisions whenever a lane's w is not exactly 1 (rounds 1-4)
+#endif
 struct ShadowPos { float px, py, pz; };
+// THE IEEE QUOTIENT x / w FOR A DIVISOR WITHIN SIX ULP-STEPS OF 1.0, in three instructions behind one v_rcp_f32 shared by the three numerators
+// (round 5).  The reference's sun is orthographic (scene.cpp:61-70): w is 1 at every vertex and (b0 + b1) + b2 -- one, two, three ulps off 1 --
+// after interpolation; in the benchmark frame 30 % of the pixels carry such a w and NOT ONE 8x8 tile is free of them, so every tile paid three
+// full IEEE divisions (v_div_scale x 2, v_rcp, 7 x fma, v_div_fmas, v_div_fixup each: 33 VALU + 3 transcendentals, a quarter of a shadowed tile).
+// The quotient feeds floor() and the 25 PCF compares: it has to be the IEEE one, bit for bit.  q0 = x y, q = fma(fma(-w, q0, x), y, q0) with
+// y = v_rcp_f32(w) IS that for every w = 1.0 -+ 0..6 ulp-steps and EVERY x with 2^-100 < |x| < 2^100 -- all 13 x 2^32 cases compared with the
+// compiler's division on the device (tools/experiments/div_near_one.hip, 1 s; tests/test_gpu_division.py runs it) -- and near_one_divisible is that
+// domain.  (Markstein's correction step; its textbook exception, a divisor whose mantissa is all ones, is w = 1 - 2^-24 itself: hence enumeration.)
+__device__ __forceinline__ float quotient_near_one(float x, float w, float y /* v_rcp_f32(w) */) {
+#pragma clang fp contract(off)
+    const float q0 = x * y;
+    return __builtin_fmaf(__builtin_fmaf(-w, q0, x), y, q0);
+}
+__device__ __forceinline__ bool near_one_divisible(float x, float y, float z, float w) {
+    const float hi = fmaxf(fmaxf(fabsf(x), fabsf(y)), fabsf(z)), lo = fminf(fminf(fabsf(x), fabsf(y)), fabsf(z));
+    return __float_as_uint(w) - 0x3F7FFFFAu <= 12u && lo > 0x1p-100f && hi < 0x1p100f;
+}
 // light-space position -> shadow-map coordinates, forward.hlsl:69-74
 __device__ __forceinline__ void shadow_coords(float lsx, float lsy, float lsz, float lsw, ShadowPos &p) {
 #pragma clang fp contract(off)
-    if (__ballot(lsw != 1.0f) == 0ull) { p.px = lsx; p.py = lsy; p.pz = lsz; }   // orthographic sun: w == 1, x / 1 == x
-    else { p.px = lsx / lsw; p.py = lsy / lsw; p.pz = lsz / lsw; }
+    if (__ballot(lsw != 1.0f) == 0ull) { p.px = lsx; p.py = lsy; p.pz = lsz; }   // w == 1 in every lane, x / 1 == x
+    else if (ARCTIC_NEAR_ONE_DIVISION && __ballot(!near_one_divisible(lsx, lsy, lsz, lsw)) == 0ull) {          // orthographic sun: w == 1 -+ a few ulps (nearly every tile)
+        const float y = __builtin_amdgcn_rcpf(lsw);
+        p.px = quotient_near_one(lsx, lsw, y); p.py = quotient_near_one(lsy, lsw, y); p.pz = quotient_near_one(lsz, lsw, y);
+    } else { p.px = lsx / lsw; p.py = lsy / lsw; p.pz = lsz / lsw; }
     p.px = p.px * 0.5f + 0.5f;
     p.py = p.py * 0.5f + 0.5f;
     p.py = 1.0f - p.py;
