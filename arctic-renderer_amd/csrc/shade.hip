@@ -47,6 +47,9 @@
 #ifndef ARCTIC_PCF_ROW_CANDIDATES
 #define ARCTIC_PCF_ROW_CANDIDATES 0   // A/B switch: 1 = the horizontal lerps of the 25 PCF taps as candidates too (register pressure: see shadow_window)
 #endif
+#ifndef ARCTIC_PIN_SECOND_WAVE
+#define ARCTIC_PIN_SECOND_WAVE 1   // A/B switch: see shade_tile_fast
+#endif
 #ifndef ARCTIC_EDGE_IN_FAST
 #define ARCTIC_EDGE_IN_FAST 1   // A/B switch (build_tmp variants only): 0 = a tile on a shadow edge goes to the general tile, as in round 3
 #endif
@@ -1044,7 +1047,14 @@ __device__ __forceinline__ bool shade_tile_fast(SP sp, KernArgs args, const Args
     float4 gc, gd, ge;
     if (live) second(C.gc, C.gd, C.ge, gc, gd, ge);   // second wave of loads: lit pixels only (48 B / pixel, whole 128-byte tile rows)
     // ---- C: base colour
-    const f3 base = mk(filt_srgb<0>(pt, lut), filt_srgb<1>(pt, lut), filt_srgb<2>(pt, lut));
+    f3 base = mk(filt_srgb<0>(pt, lut), filt_srgb<1>(pt, lut), filt_srgb<2>(pt, lut));
+#if ARCTIC_PIN_SECOND_WAVE
+    // Round 5, read off the ISA: the compiler copied components of gc / gd / ge into the register pairs its packed multiplies want RIGHT BEHIND the
+    // three loads (s_waitcnt vmcnt(2), (1), (0) + v_mov inside the `live` branch): the wave sat out the whole memory latency there, in front of the
+    // twelve table look-ups of the base colour.  The twelve values and a component of the base colour pass through one empty asm statement: whatever
+    // the compiler does with the loaded registers, it does behind the base colour.
+    asm volatile("" : "+v"(gc.x), "+v"(gc.y), "+v"(gc.z), "+v"(gc.w), "+v"(gd.x), "+v"(gd.y), "+v"(gd.z), "+v"(gd.w), "+v"(ge.x), "+v"(ge.y), "+v"(ge.z), "+v"(ge.w), "+v"(base.x));
+#endif
     // ---- D: the lights.  (The ambient term is formed behind the light loop on either side of the branch: formed in front of it, it
     // would occupy three registers through the loop.)
     EpiArgs E = {C.st, B.out, B.width, B.row0_in_tile, C.ambient};
