@@ -291,6 +291,15 @@ struct ShadeLaunch {
 };
 constexpr uint32_t N_SHADE_STATS = 9;   // [0..4] light statistics, [5..8] shadow-edge statistics of the fast tile (shade.hip)
 constexpr uint32_t DEFAULT_TILES_PER_WAVE = 2;
+// The dispatch order's slots (geometry.hip k_tile_order, shade.hip next_tile): eight lists -- list x = the strips of tile rows ty = x (mod 8) -- of L slots
+// each (the longest list in whole groups), interleaved in groups of `group` slots: slot (q * 8 + x) * group + k = entry q * group + k of list x.  Block b of
+// the pass takes slots b * group ..., i.e. ONE list: b % 8 = x, the XCD the hardware deals block b to.  ORDER_NONE: no strip in this slot.
+constexpr uint32_t ORDER_NONE = 0xFFFFFFFFu;
+__host__ __device__ inline uint32_t order_slot(uint32_t list, uint32_t i, uint32_t group) { return ((i / group) * 8u + list) * group + i % group; }
+__host__ __device__ inline uint32_t order_slots(uint32_t tiles_x, uint32_t tiles_y, uint32_t group) {
+    const uint32_t longest = ((tiles_x + 3) / 4) * ((tiles_y + 7) / 8);
+    return 8u * ((longest + group - 1) / group * group);
+}
 constexpr uint32_t SMALL_FRAME_TILES = 48000;   // fewer 8x8 tiles than this (~3 Mpx): one tile per wave (launch_shade)
 // the shadow-bounds table: one entry per 4x4 texel block; only for maps whose 25 PCF taps (4e-4 S apart end to end, in fp32)
 // span less than 2 texels, so that a footprint never leaves the 4x4 window behind its first texel
@@ -318,9 +327,9 @@ hipError_t launch_raster_owned(bool depth_only, const RasterRec *rrecs, const ui
                                const GeomParams &gp, unsigned long long *vis, uint32_t *depth_bits, hipStream_t s);
 hipError_t launch_resolve(const unsigned long long *vis, const SetupRec *recs, const RasterRec *rrecs, const uint32_t *rec_of, const ObjectRec *objs, const XVert *xv,
                           const GeomParams &gp, uint32_t n_tiles, GBuffer g, const TileHint &hint, hipStream_t s);
-// the shading pass's dispatch order (ShadeParams::tile_order) from the cost classes k_resolve left: lists = scratch of 2 N words, order = N words,
-// N = ceil(tiles_x / 4) * tiles_y strips; tail_permille: the last part of the order that holds cheap strips only
-hipError_t launch_tile_order(const uint8_t *tile_class, uint32_t tiles_x, uint32_t tiles_y, uint32_t tail_permille, uint32_t *lists, uint32_t *order, hipStream_t s);
+// the shading pass's dispatch order (ShadeParams::tile_order) from the cost classes k_resolve left: lists = scratch of 2 N words, N = ceil(tiles_x / 4) *
+// tiles_y strips; order = order_slots() words; tail_permille: the last part of each list that holds cheap strips only; group = tiles per wave of the pass
+hipError_t launch_tile_order(const uint8_t *tile_class, uint32_t tiles_x, uint32_t tiles_y, uint32_t tail_permille, uint32_t group, uint32_t *lists, uint32_t *order, hipStream_t s);
 hipError_t launch_fill_u64(unsigned long long *p, unsigned long long v, size_t n, hipStream_t s);
 hipError_t launch_fill_u32(uint32_t *p, uint32_t v, size_t n, hipStream_t s);
 hipError_t launch_shade(const ShadeParams &sp, const ShadeLaunch &L);

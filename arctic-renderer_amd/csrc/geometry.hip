@@ -958,57 +958,72 @@ __global__ __launch_bounds__(256) void k_resolve(const unsigned long long *__res
 }
 
 // ---------------------------------------------------------------------------------------------
-// the shading pass's dispatch order from the tiles' cost classes (ONE workgroup; 32 k strips at 4K: 112 us measured, profiles/r4_g_kernel_stats_bench_command.csv --
-// each thread walks 32 strips twice with byte loads and 64-bit divisions; at 16384^2 it would be ~1 k strips per thread.  ARCTIC_OPT_TILE_ORDER is OFF by default
-// since round 5: an opt-in measuring aid, not part of the default G-buffer pass)
+// the shading pass's dispatch order from the tiles' cost classes: EIGHT workgroups, one per XCD's share of the tile rows
 // ---------------------------------------------------------------------------------------------
 // A job of the shading pass = a STRIP of 4 horizontally adjacent tiles (one workgroup, a wave per tile), coded ty << 16 | strip
-// column.  A strip is costly when one of its tiles is.  The order deals the costly strips evenly over the first (1 - tail) of the
-// list, in raster order, and fills everything else with the cheap ones, in raster order: whatever part of the frame the light
-// falls on, every stretch of the dispatch carries the frame's own mix of ALU-bound and latency-bound work (so the two hide behind
-// each other on every SIMD from the first wave on), and the last workgroups dispatched are all short (no tail of lit tiles on a
-// draining chip).  Position p holds a costly strip iff cnt(p + 1) > cnt(p), cnt(p) = ceil(p nL / span) = costly strips in front of p.
+// column.  A strip is costly when one of its tiles is.  Round 4 built ONE list over the whole frame in one workgroup (112 us at 4K, and handing
+// strips out by cost alone sent neighbouring strips to different XCDs: +83 MB of fabric reads per pass, profiles/r5_a_traffic_tile_order.json).
+// Round 5: the strips of tile rows ty = x (mod 8) form list x -- the rows the geometric order gives to "XCD x" -- and each list is ordered
+// by its own workgroup, independently (no scan across workgroups): costly strips dealt evenly over the first (1 - tail) of the list, in raster
+// order, everything else filled with the cheap ones in raster order; position p of a list holds a costly strip iff cnt(p + 1) > cnt(p),
+// cnt(p) = ceil(p nL / span) = costly strips in front of p.  The lists are interleaved in groups of G = tiles per wave (common.h order_slot):
+// block b of the pass takes the slots b G ... b G + G - 1, all of list b % 8 -- blocks are dealt round-robin over the XCDs, so a list stays
+// on one XCD and horizontally adjacent strips still meet in one L2.  Lists shorter than the longest end in ORDER_NONE slots (skipped by the pass).
 __device__ __forceinline__ uint32_t costly_before(uint32_t p, uint32_t nL, uint32_t span) {
     const unsigned long long c = ((unsigned long long)p * nL + span - 1) / span;
     return c < nL ? (uint32_t)c : nL;
 }
-__global__ __launch_bounds__(1024) void k_tile_order(const uint8_t *__restrict__ tile_class, uint32_t tiles_x, uint32_t tiles_y, uint32_t tail_permille,
-                                                     uint32_t *__restrict__ lists /* 2 N: costly strips, then cheap strips */, uint32_t *__restrict__ order /* N */) {
-    __shared__ uint32_t part[1024];
-    __shared__ uint32_t total;
-    const uint32_t bpr = (tiles_x + 3) / 4, N = bpr * tiles_y;
-    const uint32_t per = (N + 1023) / 1024, s0 = min(N, threadIdx.x * per), s1 = min(N, s0 + per);
+__global__ __launch_bounds__(1024) void k_tile_order(const uint8_t *__restrict__ tile_class, uint32_t tiles_x, uint32_t tiles_y, uint32_t tail_permille, uint32_t group,
+                                                     uint32_t *__restrict__ lists /* 2 N: per list its costly strips, then its cheap strips */, uint32_t *__restrict__ order /* order_slots() */) {
+    __shared__ uint32_t wave_count[16];
+    __shared__ uint32_t base_costly;
+    const uint32_t x = blockIdx.x, t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint32_t bpr = (tiles_x + 3) / 4;
+    const uint32_t rows = tiles_y > x ? (tiles_y - x + 7) / 8 : 0u, N = bpr * rows;        // this list: tile rows x, x + 8, ...
+    const uint32_t rows_max = (tiles_y + 7) / 8, L = (bpr * rows_max + group - 1) / group * group;   // slots per list (the longest list, whole groups)
+    // where this list's scratch starts: lists 0 .. x - 1 hold bpr * their rows entries each, twice (costly | cheap)
+    uint32_t before = 0;
+    for (uint32_t y = 0; y < x; ++y) before += tiles_y > y ? (tiles_y - y + 7) / 8 : 0u;
+    uint32_t *costly_list = lists + 2u * bpr * before, *cheap_list = costly_list + N;
+    const auto code_of = [&](uint32_t s) { return ((8u * (s / bpr) + x) << 16) | (s % bpr); };
     const auto costly = [&](uint32_t s) {
-        const uint32_t ty = s / bpr, x0 = (s % bpr) * 4, x1 = min(tiles_x, x0 + 4);
+        const uint32_t ty = 8u * (s / bpr) + x, x0 = (s % bpr) * 4, x1 = min(tiles_x, x0 + 4);
         uint32_t c = 0;
-        for (uint32_t x = x0; x < x1; ++x) c |= tile_class[(size_t)ty * tiles_x + x];
-        return c != 0 ? 1u : 0u;
+        for (uint32_t xx = x0; xx < x1; ++xx) c |= tile_class[(size_t)ty * tiles_x + xx];
+        return c != 0;
     };
-    uint32_t mine = 0;
-    for (uint32_t s = s0; s < s1; ++s) mine += costly(s);
-    part[threadIdx.x] = mine;
+    if (t == 0) base_costly = 0;
     __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {   // inclusive scan, Hillis-Steele (ten steps)
-        const uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+    // compaction in raster order, 1024 strips at a time: rank in the wave by ballot, the waves' counts through LDS
+    for (uint32_t cb = 0; cb < N; cb += 1024) {
+        const uint32_t s = cb + t;
+        const bool in = s < N, c = in && costly(s);
+        const unsigned long long m = __ballot(c);
+        if (lane == 0) wave_count[wave] = (uint32_t)__popcll(m);
         __syncthreads();
-        part[threadIdx.x] += v;
+        uint32_t pre = 0, tot = 0;
+        for (uint32_t w = 0; w < 16; ++w) { const uint32_t n = wave_count[w]; pre += w < wave ? n : 0u; tot += n; }
+        const uint32_t rank_c = base_costly + pre + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (in) {
+            if (c) costly_list[rank_c] = code_of(s);
+            else cheap_list[s - rank_c] = code_of(s);     // cheap strips in front of s = s - costly strips in front of s
+        }
         __syncthreads();
-    }
-    if (threadIdx.x == 1023) total = part[1023];
-    uint32_t l = part[threadIdx.x] - mine;   // costly strips in front of s0
-    for (uint32_t s = s0; s < s1; ++s) {
-        const uint32_t code = ((s / bpr) << 16) | (s % bpr);
-        if (costly(s)) lists[l++] = code;
-        else lists[N + (s - l)] = code;
+        if (t == 0) base_costly += tot;
+        __syncthreads();
     }
     __threadfence_block();
     __syncthreads();
-    const uint32_t nL = total;
+    const uint32_t nL = base_costly;
     const uint32_t tail = (uint32_t)((unsigned long long)N * tail_permille / 1000);
     const uint32_t span = max(max(nL, N - min(N, tail)), 1u);
-    for (uint32_t p = s0; p < s1; ++p) {
-        const uint32_t c = costly_before(p, nL, span);
-        order[p] = costly_before(p + 1, nL, span) > c ? lists[c] : lists[N + (p - c)];
+    for (uint32_t p = t; p < L; p += 1024) {
+        uint32_t e = ORDER_NONE;
+        if (p < N) {
+            const uint32_t c = costly_before(p, nL, span);
+            e = costly_before(p + 1, nL, span) > c ? costly_list[c] : cheap_list[p - c];
+        }
+        order[order_slot(x, p, group)] = e;
     }
 }
 
@@ -1123,9 +1138,9 @@ hipError_t launch_resolve(const unsigned long long *vis, const SetupRec *recs, c
     k_resolve<<<div_up(n_tiles, 4), 256, 0, s>>>(vis, recs, rrecs, rec_of, objs, xv, gp, n_tiles, g, hint);
     return hipGetLastError();
 }
-hipError_t launch_tile_order(const uint8_t *tile_class, uint32_t tiles_x, uint32_t tiles_y, uint32_t tail_permille, uint32_t *lists, uint32_t *order, hipStream_t s) {
-    if (tiles_x == 0 || tiles_y == 0) return hipSuccess;
-    k_tile_order<<<1, 1024, 0, s>>>(tile_class, tiles_x, tiles_y, tail_permille, lists, order);
+hipError_t launch_tile_order(const uint8_t *tile_class, uint32_t tiles_x, uint32_t tiles_y, uint32_t tail_permille, uint32_t group, uint32_t *lists, uint32_t *order, hipStream_t s) {
+    if (tiles_x == 0 || tiles_y == 0 || group == 0) return hipSuccess;
+    k_tile_order<<<8, 1024, 0, s>>>(tile_class, tiles_x, tiles_y, tail_permille, group, lists, order);
     return hipGetLastError();
 }
 

@@ -219,6 +219,7 @@ struct ArcticRenderer {
     // a stale or missing order changes the pass's time, never its image.
     DevBuf d_tile_class, d_order_lists, d_tile_order;
     bool have_order = false;         // d_tile_order belongs to the G-buffer in place
+    uint32_t order_group = 0, order_slots = 0;   // ... built for this many tiles per wave, this many slots (common.h order_slot)
     int texture_tiling = -1;         // ARCTIC_OPT_TEXTURE_TILING: materials created from now on: -1 = 4 x 4-texel tiles for images of 2048 texels a side and more, 0 = never, 1 = always
     int sampler = 0;                 // ARCTIC_OPT_SAMPLER: bit 0 material footprints, bit 2 PCF taps with coordinates snapped to 1/256 texel (D3D-style 8-bit filter weights)
     int tile_order = 0;              // ARCTIC_OPT_TILE_ORDER: 0 (default since round 5) = the geometric, XCD-aware order of round 3; 1 = the cost-class order of round 4.
@@ -559,10 +560,13 @@ int resolve_gbuffer(ArcticRenderer *r) {
     TileHint hint = {nullptr, nullptr, 0, 0, 0};
     const uint32_t bpr = (r->tiles_x + 3) / 4, n_jobs = bpr * r->tiles_y;
     r->have_order = false;
+    // (the order's slots come in groups of the tiles a wave of the pass will shade: launch_shade's rule)
+    r->order_group = r->tiles_per_wave ? r->tiles_per_wave : ((uint32_t)r->n_tiles() < SMALL_FRAME_TILES ? 1u : DEFAULT_TILES_PER_WAVE);
+    r->order_slots = order_slots(r->tiles_x, r->tiles_y, r->order_group);
     if (r->tile_order && n_jobs) {
         HIPCHECK(r, r->d_tile_class.ensure(r->n_tiles()));
         HIPCHECK(r, r->d_order_lists.ensure((size_t)n_jobs * 8));
-        HIPCHECK(r, r->d_tile_order.ensure((size_t)n_jobs * 4));
+        HIPCHECK(r, r->d_tile_order.ensure((size_t)r->order_slots * 4));
         hint.tile_class = r->d_tile_class.as<uint8_t>();
         hint.sky = r->env_w ? 1u : 0u;
         const uint32_t nb = shadow_bounds_pitch(r->shadow_size);
@@ -576,7 +580,7 @@ int resolve_gbuffer(ArcticRenderer *r) {
                                r->geo[r->fwd()].d_xverts.as<XVert>(), r->tables[r->fwd()].gp, (uint32_t)r->n_tiles(), r->gbuffer(), hint,
                                r->stream));
     if (hint.tile_class) {
-        HIPCHECK(r, launch_tile_order(hint.tile_class, r->tiles_x, r->tiles_y, r->order_tail, r->d_order_lists.as<uint32_t>(), r->d_tile_order.as<uint32_t>(), r->stream));
+        HIPCHECK(r, launch_tile_order(hint.tile_class, r->tiles_x, r->tiles_y, r->order_tail, r->order_group, r->d_order_lists.as<uint32_t>(), r->d_tile_order.as<uint32_t>(), r->stream));
         r->have_order = true;
     }
     r->have_gbuffer = true;
@@ -631,7 +635,10 @@ int fill_shade_params(ArcticRenderer *r, const ArcticScene *sc, const ArcticSett
         HIPCHECK(r, hipMemsetAsync(r->d_tile_trace.p, 0, bytes, r->stream));
         sp.trace = r->d_tile_trace.as<unsigned long long>();
     }
-    if (!from_vis && r->have_order && r->tile_order) sp.tile_order = r->d_tile_order.as<uint32_t>();   // (n_jobs: launch_shade)
+    // (the order was built for groups of order_group tiles per wave: a pass that shades another number per wave takes the geometric order)
+    if (!from_vis && r->have_order && r->tile_order && (r->tiles_per_wave == 0 || r->tiles_per_wave == r->order_group)) {
+        sp.tile_order = r->d_tile_order.as<uint32_t>(); sp.n_jobs = r->order_slots; sp.tiles_per_wave = r->order_group;
+    }
     sp.culling = r->culling;
     sp.debug = r->debug | (sp.trace ? (1 << 30) : 0) | ((r->sampler & 5) << 20);   // bit 30: the kernels learn of the trace from the first block of their arguments; bits 20..22: ARCTIC_OPT_SAMPLER (shade.hip SAMPLER_SHIFT)
     sp.hdr16 = r->hdr16;
@@ -1321,7 +1328,13 @@ int arctic_read_tile_order(ArcticRenderer *r, uint32_t *order, uint8_t *tile_cla
     int rc = select_device(r);
     if (rc) return rc;
     HIPCHECK(r, hipStreamSynchronize(r->stream));
-    if (order) HIPCHECK(r, hipMemcpy(order, r->d_tile_order.p, n_jobs * 4, hipMemcpyDeviceToHost));
+    if (order) {   // the slots in dispatch order, the empty ones left out: n_jobs entries
+        std::vector<uint32_t> slots(r->order_slots);
+        HIPCHECK(r, hipMemcpy(slots.data(), r->d_tile_order.p, (size_t)r->order_slots * 4, hipMemcpyDeviceToHost));
+        uint64_t k = 0;
+        for (uint32_t e : slots) if (e != ORDER_NONE && k < n_jobs) order[k++] = e;
+        if (k != n_jobs) return r->fail(ARCTIC_E_STATE, "read_tile_order: %llu strips in the order, %llu in the frame", (unsigned long long)k, (unsigned long long)n_jobs);
+    }
     if (tile_class) HIPCHECK(r, hipMemcpy(tile_class, r->d_tile_class.p, n, hipMemcpyDeviceToHost));
     return ARCTIC_OK;
 }

@@ -1537,10 +1537,8 @@ hipError_t launch_shade(const ShadeParams &sp_in, const ShadeLaunch &L) {
     const uint32_t bpr = (sp.tiles_x + 3) / 4, groups = (sp.tiles_y + 7) / 8;
     sp.group_stride = (groups + sp.tiles_per_wave - 1) / sp.tiles_per_wave;
     dim3 grid(8 * bpr, sp.group_stride);   // a block shades tiles_per_wave groups of 8 tile rows, group_stride groups apart
-    if (sp.tile_order) {                   // ... or tiles_per_wave consecutive jobs of the prepass's dispatch order
-        sp.n_jobs = bpr * sp.tiles_y;
+    if (sp.tile_order)                     // ... or tiles_per_wave consecutive slots of the prepass's dispatch order (n_jobs slots, common.h order_slot: a block = one XCD's list)
         grid = dim3((sp.n_jobs + sp.tiles_per_wave - 1) / sp.tiles_per_wave, 1);
-    }
     if (sp.debug & 16)   // A/B only: the 25-tap path staged through LDS (a separate instantiation: it costs the default kernels nothing)
         return L.loop == 2 ? launch_variant<2, false, true>(sp, L, grid) : launch_variant<1, false, true>(sp, L, grid);
     if (L.loop == 2) return L.stats ? launch_variant<2, true, false>(sp, L, grid) : launch_variant<2, false, false>(sp, L, grid);

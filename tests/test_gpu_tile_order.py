@@ -35,12 +35,15 @@ def test_dispatch_order_is_placement_only(pkg, hip, cfg, scale):
         np.testing.assert_array_equal(o, outs[0])
 
 
-@pytest.mark.parametrize("tail", [0, 60, 400])
-def test_order_is_a_permutation_that_spreads_the_costly_strips(pkg, hip, tail):
+@pytest.mark.parametrize("tail,group", [(0, 0), (60, 0), (400, 0), (60, 2), (250, 3)])
+def test_order_is_a_permutation_that_spreads_the_costly_strips_of_every_xcd_list(pkg, hip, tail, group):
+    """round 5: eight lists -- list x = the strips of tile rows ty = x (mod 8), the rows the geometric order gives to one XCD -- each ordered on its
+    own (costly strips dealt evenly over what the tail leaves, raster order inside both kinds), interleaved in groups of the tiles a wave shades"""
     sc = pkg.scenes.config3(scale=0.13)
     r = sc.upload(hip.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights))
     r.set_option("tile_order", 1)   # (opt-in since round 5)
     r.set_option("order_tail", tail)
+    r.set_option("tiles_per_wave", group)
     r.pass_shadow_map(sc.desc); r.pass_gbuffer(sc.desc)
     order, classes = r.tile_order()
     r.close()
@@ -51,18 +54,29 @@ def test_order_is_a_permutation_that_spreads_the_costly_strips(pkg, hip, tail):
     codes = (np.arange(ty, dtype=np.uint32)[:, None] << 16 | np.arange(bpr, dtype=np.uint32)[None, :])
     assert order.shape == (n,)
     np.testing.assert_array_equal(np.sort(order), np.sort(codes.ravel()))          # every strip exactly once
-    is_costly = costly[order >> 16, order & 0xFFFF]
-    nl = int(costly.sum())
-    assert 0 < nl < n                                                              # the scene has both kinds
-    # the i-th costly strip (raster order) sits at floor(i span / nL), span = what the tail leaves; the cheap ones fill the rest in raster order
-    span = max(nl, n - n * tail // 1000, 1)
-    expect = np.zeros(n, bool)
-    expect[(np.arange(nl, dtype=np.uint64) * span // nl).astype(np.int64)] = True
-    np.testing.assert_array_equal(is_costly, expect)
-    np.testing.assert_array_equal(order[is_costly], codes[costly])
-    np.testing.assert_array_equal(order[~is_costly], codes[~costly])
-    if tail and n - span > 0:
-        assert not is_costly[span:].any()
+    assert 0 < int(costly.sum()) < n                                               # the scene has both kinds
+    G = group or 1                                                                 # (a frame this small: one tile per wave by default)
+    lists = (order >> 16) % 8
+    shortest = min(int((lists == x).sum()) for x in range(8))
+    whole = 8 * G * (shortest // G)                                                # up to here no list has run out: the slots are all taken
+    np.testing.assert_array_equal(lists[:whole], (np.arange(whole) // G) % 8)      # block b = slots b G ..., all of list b % 8
+    for x in range(8):
+        lst = order[lists == x]                                                    # list x in the order it is dispatched
+        n_x = lst.size
+        assert n_x == bpr * len(range(x, ty, 8))
+        is_costly = costly[lst >> 16, lst & 0xFFFF]
+        nl = int(is_costly.sum())
+        # the i-th costly strip of the list (raster order) sits at floor(i span / nL), span = what the tail leaves; the cheap ones fill the rest in raster order
+        span = max(nl, n_x - n_x * tail // 1000, 1)
+        expect = np.zeros(n_x, bool)
+        if nl:
+            expect[(np.arange(nl, dtype=np.uint64) * span // nl).astype(np.int64)] = True
+        np.testing.assert_array_equal(is_costly, expect)
+        codes_x, costly_x = codes[x::8].ravel(), costly[x::8].ravel()
+        np.testing.assert_array_equal(lst[is_costly], codes_x[costly_x])
+        np.testing.assert_array_equal(lst[~is_costly], codes_x[~costly_x])
+        if tail and n_x - span > 0:
+            assert not is_costly[span:].any()
 
 
 def test_cost_classes_cover_every_pixel_that_can_be_lit(pkg, hip, oracle):
