@@ -50,6 +50,9 @@
 #ifndef ARCTIC_PIN_SECOND_WAVE
 #define ARCTIC_PIN_SECOND_WAVE 1   // A/B switch: see shade_tile_fast
 #endif
+#ifndef ARCTIC_TILED_FETCH
+#define ARCTIC_TILED_FETCH 1   // A/B switch (instruction census only): 0 = no code for tiled material images (such materials then render wrongly)
+#endif
 #ifndef ARCTIC_EDGE_IN_FAST
 #define ARCTIC_EDGE_IN_FAST 1   // A/B switch (build_tmp variants only): 0 = a tile on a shadow edge goes to the general tile, as in round 3
 #endif
@@ -206,7 +209,11 @@ __device__ __forceinline__ TexS tex_decode(const u8v &v) {
     t.texels = reinterpret_cast<const uint8_t *>(((unsigned long long)v[1] << 32) | v[0]);
     t.w = v[2] & 0x7FFFFFFFu; t.h = v[3];
     t.packed = v[2] >> 31;   // TexDesc::w bit 31
-    t.wf = __uint_as_float(v[4]); t.hf = __uint_as_float(v[5]); t.pitch = v[6]; t.tile_row_bytes = v[7];
+    t.wf = __uint_as_float(v[4]); t.hf = __uint_as_float(v[5]); t.pitch = v[6];
+    // (readfirstlane of a value that sits in an SGPR is a scalar move -- and tells the compiler's uniformity analysis so: the asm statements the descriptor
+    // comes through also carry a vector operand, which makes all their results "divergent" on paper; a branch on such a value turned the epilogue's scalar
+    // address arithmetic into vector instructions, 13 per tile -- round 5, found with SQ_INSTS_VALU)
+    t.tile_row_bytes = __builtin_amdgcn_readfirstlane(v[7]);
     return t;
 }
 __device__ __forceinline__ TexS tex_desc(const TexDesc *tex, uint32_t i /* wave-uniform */) {
@@ -278,7 +285,7 @@ __device__ __forceinline__ void fetch_taps_packed(const TexS &d, float u, float 
     if (q8) { asm volatile(""); x = snap256(x); y = snap256(y); }   // (a real branch: one for both axes, nothing for the default sampler)
     axis_split(x, x0, fx);
     axis_split(y, y0, fy);
-    if (d.tile_row_bytes) {   // (wave-uniform) 4 x 4-texel tiles, common.h TexDesc::tile_row_bytes: four 8-byte loads, a texel of the footprint may sit in the next tile
+    if (ARCTIC_TILED_FETCH && d.tile_row_bytes) {   // (wave-uniform) 4 x 4-texel tiles, common.h TexDesc::tile_row_bytes: four 8-byte loads, a texel of the footprint may sit in the next tile
         asm volatile("");
         const uint32_t X = (uint32_t)(x0 + 1), Y = (uint32_t)(y0 + 1), rx = X & 3u, ry = Y & 3u;
         const uint32_t o00 = ((__umul24(Y >> 2, d.tile_row_bytes >> 7) + (X >> 2)) << 7) + ((ry * 4u + rx) << 3);
@@ -1073,9 +1080,12 @@ __device__ __forceinline__ bool shade_tile_fast(SP sp, KernArgs args, const Args
         else color = amb;
     } else color = base * E.ambient;
     // ---- E: post_process + store: the tile's first pixel is a scalar address, the lane adds (lane >> 3) rows + (lane & 7)
-    const uint32_t tile_px = (ty * 8 - E.row0_in_tile) * E.width + tx * 8;   // (the tile is wholly inside the target: ty * 8 >= row0_in_tile)
+    // (readfirstlane: on a value in an SGPR a scalar move.  With the tiled-texture branch in fetch_taps_packed the compiler carried these two through the
+    //  tile in VECTOR registers -- and did the tile's address arithmetic below with vector instructions, 13 per tile: round 5, found with SQ_INSTS_VALU)
+    const uint32_t e_width = __builtin_amdgcn_readfirstlane(E.width), e_row0 = __builtin_amdgcn_readfirstlane(E.row0_in_tile);
+    const uint32_t tile_px = (ty * 8 - e_row0) * e_width + tx * 8;   // (the tile is wholly inside the target: ty * 8 >= row0_in_tile)
     const uint32_t l2 = wave_lane();
-    const uint32_t o = __umul24(l2 >> 3, E.width) + (l2 & 7u);   // (width <= 16384)
+    const uint32_t o = __umul24(l2 >> 3, e_width) + (l2 & 7u);   // (width <= 16384)
     store_pixel(E.st, E.out + (size_t)tile_px * 4u, o, tile_px + o, color);
     return true;
 }
