@@ -34,8 +34,12 @@
 #include "shadow_coords.h"
 
 #ifndef ARCTIC_WG_WAVES
-#define ARCTIC_WG_WAVES 4       // waves per workgroup of the shading kernels: 4 (a strip of 4 tiles per workgroup) or 1 (a tile per workgroup; A/B)
-#endif
+#define ARCTIC_WG_WAVES 1       // waves per workgroup of k_material, the pass over a G-buffer: 1 (a tile per workgroup; round 5) or 4 (a strip of 4 tiles per workgroup: rounds 1-4).
+#endif                          // A workgroup's slot is held until its LAST wave ends; with tiles of unequal length (shadowed 3 us, lit 13) one-wave workgroups keep
+                                // 5.1 instead of 4.5 waves resident per SIMD.  Round 4 measured them faster with few lights and 1.8 % slower at 64 (with its dispatch order on);
+                                // on round 5's build, order off: 64 / 16 / 0 lights 0.1874 / 0.1273 / 0.0951 -> 0.1857 / 0.1224 / 0.0936 ms (profiles/r5_l_ab_one_wave_workgroups.txt).
+                                // k_material_vis keeps 4 (VIS_WG_WAVES): whole frames are 9 % slower with one.
+constexpr int VIS_WG_WAVES = 4;
 #ifndef ARCTIC_LUT_SHARED
 #define ARCTIC_LUT_SHARED 0     // A/B switch: 1 = each wave of a workgroup loads a quarter of the sRGB table (256 B instead of 1 KiB per wave) and a barrier stands behind the stores
 #endif
@@ -1257,9 +1261,10 @@ __device__ __forceinline__ void lut_store(float *lut, uint32_t lane, const LutRe
 // same XCD (blocks are dealt round-robin over the 8 XCDs), so what the strip's tiles share still meets in one L2 -- and the strip is
 // block (b >> 5) * 8 + (b & 7) of the 4-wave numbering below.
 struct BlockId { uint32_t x, y, wave; };
+template <int WGW>
 __device__ __forceinline__ BlockId block_id() {
     BlockId b;
-    if (ARCTIC_WG_WAVES == 1) { b.x = (blockIdx.x >> 5) * 8 + (blockIdx.x & 7u); b.wave = (blockIdx.x >> 3) & 3u; }
+    if (WGW == 1) { b.x = (blockIdx.x >> 5) * 8 + (blockIdx.x & 7u); b.wave = (blockIdx.x >> 3) & 3u; }
     else { b.x = blockIdx.x; b.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
     b.y = blockIdx.y;
     return b;
@@ -1287,7 +1292,7 @@ __global__ __launch_bounds__(64 * ARCTIC_WG_WAVES) __attribute__((amdgpu_waves_p
     __shared__ float shadow_tiles[LDS_SHADOW ? ARCTIC_WG_WAVES : 1][LDS_SHADOW ? SHADOW_TILE * SHADOW_TILE : 1];   // one per wave (the LDS variant of the PCF slow path)
     KernArgs args = kernel_args();
     unsigned long long t_entry = trace_entry();
-    const BlockId blk = block_id();
+    const BlockId blk = block_id<ARCTIC_WG_WAVES>();
     const uint32_t wave = ARCTIC_WG_WAVES == 1 ? 0u : blk.wave;   // (of the workgroup: which LDS shadow tile is this wave's)
     const float *srgb_lut;
     const unsigned long long *vis_unused;
@@ -1344,20 +1349,20 @@ __global__ __launch_bounds__(64 * ARCTIC_WG_WAVES) __attribute__((amdgpu_waves_p
 // for the lit ones -- with the very operations of k_resolve (edges.h, fp contraction off), so the pixels are bit-identical
 // to the G-buffer path.  Everything after the attributes is shade_tile, shared.
 template <int LOOP, bool STATS, bool LDS_SHADOW>
-__global__ __launch_bounds__(64 * ARCTIC_WG_WAVES) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_material_vis(const ShadeParams sp_by_value) {
+__global__ __launch_bounds__(64 * VIS_WG_WAVES) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_material_vis(const ShadeParams sp_by_value) {
     __shared__ float lut[256];
-    __shared__ float shadow_tiles[LDS_SHADOW ? ARCTIC_WG_WAVES : 1][LDS_SHADOW ? SHADOW_TILE * SHADOW_TILE : 1];   // one per wave (the LDS variant of the PCF slow path)
+    __shared__ float shadow_tiles[LDS_SHADOW ? VIS_WG_WAVES : 1][LDS_SHADOW ? SHADOW_TILE * SHADOW_TILE : 1];   // one per wave (the LDS variant of the PCF slow path)
     KernArgs args = kernel_args();
     unsigned long long t_entry = trace_entry();
-    const BlockId blk = block_id();
-    const uint32_t wave = ARCTIC_WG_WAVES == 1 ? 0u : blk.wave;
+    const BlockId blk = block_id<VIS_WG_WAVES>();
+    const uint32_t wave = VIS_WG_WAVES == 1 ? 0u : blk.wave;
     const float *srgb_lut;     // XCD-aware order or the prepass's dispatch order, T tiles per wave, the LUT without a barrier: see k_material
     const unsigned long long *vis_plane;
     OrderArgs O;
     ArgsA A = args_a_first(args, srgb_lut, vis_plane, O);
     uint32_t tx, ty, k = 0;
     unsigned long long key = ~0ull;
-#if ARCTIC_LUT_SHARED && ARCTIC_WG_WAVES == 4
+#if ARCTIC_LUT_SHARED
     {
         const bool has_tile = next_tile(A, O, blk, k, tx, ty);
         const uint32_t lane = wave_lane();
@@ -1526,9 +1531,9 @@ __global__ __launch_bounds__(256) void k_post_process(const float4 *__restrict__
 
 template <int LOOP, bool STATS, bool LDS_SHADOW>
 hipError_t launch_variant(const ShadeParams &sp, const ShadeLaunch &L, dim3 grid) {
+    if (L.from_vis) { k_material_vis<LOOP, STATS, LDS_SHADOW><<<grid, 64 * VIS_WG_WAVES, 0, L.stream>>>(sp); return hipGetLastError(); }
     if (ARCTIC_WG_WAVES == 1) grid.x = (grid.x + 7) / 8 * 32;   // (block_id: four one-wave blocks per strip, a strip's blocks on one XCD)
-    if (L.from_vis) k_material_vis<LOOP, STATS, LDS_SHADOW><<<grid, 64 * ARCTIC_WG_WAVES, 0, L.stream>>>(sp);
-    else k_material<LOOP, STATS, LDS_SHADOW><<<grid, 64 * ARCTIC_WG_WAVES, 0, L.stream>>>(sp);
+    k_material<LOOP, STATS, LDS_SHADOW><<<grid, 64 * ARCTIC_WG_WAVES, 0, L.stream>>>(sp);
     return hipGetLastError();
 }
 

@@ -114,9 +114,9 @@ def test_shading_kernels_keep_their_register_budgets(shade_isa):
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")
-@pytest.mark.parametrize("defines", [("-DARCTIC_WG_WAVES=1", "-DARCTIC_EDGE_IN_FAST=0"),
+@pytest.mark.parametrize("defines", [("-DARCTIC_WG_WAVES=4", "-DARCTIC_EDGE_IN_FAST=0"),
                                      ("-DARCTIC_LUT_SHARED=1", "-DARCTIC_PCF_CANDIDATES=1", "-DARCTIC_PCF_ROW_CANDIDATES=1")],
-                         ids=["one-wave-workgroups+edge-tiles-to-general-tile", "shared-lut+pcf-candidates"])
+                         ids=["four-wave-workgroups+edge-tiles-to-general-tile", "shared-lut+pcf-candidates"])
 def test_ab_switches_still_compile(tmp_path, defines):
     """the A/B compile switches of shade.hip (measured variants kept behind a default: DESIGN 4.2c, profiles/r4_c_*, r5_a_*, r5_b_*) build for gfx950 with
     their non-default values -- device code through the backend (register allocation included), nothing is run"""
