@@ -39,7 +39,7 @@
                                 // 5.1 instead of 4.5 waves resident per SIMD.  Round 4 measured them faster with few lights and 1.8 % slower at 64 (with its dispatch order on);
                                 // on round 5's build, order off: 64 / 16 / 0 lights 0.1874 / 0.1273 / 0.0951 -> 0.1857 / 0.1224 / 0.0936 ms (profiles/r5_l_ab_one_wave_workgroups.txt).
                                 // k_material_vis keeps 4 (VIS_WG_WAVES): whole frames are 9 % slower with one.
-constexpr int VIS_WG_WAVES = 4;
+constexpr int VIS_WG_WAVES = 4;   // (2 and 1 measured: whole frames 0.2765 -> 0.2955 / 0.2964 ms, profiles/r5_l_ab_one_wave_workgroups.txt)
 #ifndef ARCTIC_LUT_SHARED
 #define ARCTIC_LUT_SHARED 0     // A/B switch: 1 = each wave of a workgroup loads a quarter of the sRGB table (256 B instead of 1 KiB per wave) and a barrier stands behind the stores
 #endif
@@ -1293,7 +1293,7 @@ __global__ __launch_bounds__(64 * ARCTIC_WG_WAVES) __attribute__((amdgpu_waves_p
     KernArgs args = kernel_args();
     unsigned long long t_entry = trace_entry();
     const BlockId blk = block_id<ARCTIC_WG_WAVES>();
-    const uint32_t wave = ARCTIC_WG_WAVES == 1 ? 0u : blk.wave;   // (of the workgroup: which LDS shadow tile is this wave's)
+    const uint32_t wave = ARCTIC_WG_WAVES == 1 ? 0u : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (of the workgroup: which LDS shadow tile is this wave's)
     const float *srgb_lut;
     const unsigned long long *vis_unused;
     OrderArgs O;
@@ -1355,7 +1355,7 @@ __global__ __launch_bounds__(64 * VIS_WG_WAVES) __attribute__((amdgpu_waves_per_
     KernArgs args = kernel_args();
     unsigned long long t_entry = trace_entry();
     const BlockId blk = block_id<VIS_WG_WAVES>();
-    const uint32_t wave = VIS_WG_WAVES == 1 ? 0u : blk.wave;
+    const uint32_t wave = VIS_WG_WAVES == 1 ? 0u : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (of the workgroup: which LDS shadow tile is this wave's)
     const float *srgb_lut;     // XCD-aware order or the prepass's dispatch order, T tiles per wave, the LUT without a barrier: see k_material
     const unsigned long long *vis_plane;
     OrderArgs O;
