@@ -115,7 +115,8 @@ constexpr uint32_t ITEM_SKIP = 0xFFFFFFFFu;
 // runs afterwards and spreads them over the whole chip.
 constexpr uint32_t BIN_SLOTS = 32;
 constexpr uint32_t N_GEO_COUNTERS = 8;   // device counters per table set: [0] records, [1] work items, [2] a table overflowed, [3] clip-list entries,
-                                         // [4] k_bin left items for the atomic rasteriser; zeroed by k_vertex
+                                         // [4] k_bin left items for the atomic rasteriser, [5] clusters k_setup skipped, [6] vertex blocks k_vertex skipped (both
+                                         // counted only under GeomParams::raster_flags bit 1); zeroed by k_vertex
 struct BinTables {
     uint32_t *count;      // items offered to each block's bin (may exceed BIN_SLOTS: the bin holds the first BIN_SLOTS)
     uint32_t *slots;      // BIN_SLOTS record indices per block
@@ -310,11 +311,13 @@ inline uint32_t shadow_bounds_pitch(uint32_t S) { return S >= 4 && S <= 4900 ? (
 hipError_t launch_vertex(const ObjectRec *objs, const uint32_t *block_obj, const uint32_t *block_first,
                          uint32_t n_blocks, const GeomParams &gp, XVert *xv, int clip_only, uint32_t *counters /*zeroed here for k_setup*/,
                          unsigned long long *clear, unsigned long long clear_value, size_t clear_count /*the pass's target, cleared in the same launch*/,
-                         uint32_t *zero, size_t zero_count /*the bin counters of an owned raster, zeroed in the same launch*/, hipStream_t s);
+                         uint32_t *zero, size_t zero_count /*the bin counters of an owned raster, zeroed in the same launch*/,
+                         const float *block_bounds /*6 floats per block: object-space box of every cluster that uses a vertex of the block, or null (no culling)*/, hipStream_t s);
 hipError_t launch_setup(const ObjectRec *objs, const uint32_t *block_obj, const uint32_t *block_first, uint32_t n_blocks,
                         const GeomParams &gp, const XVert *xv, SetupRec *recs, RasterRec *rrecs, uint32_t *rec_of /*8 per source triangle*/,
                         uint2 *items, uint32_t item_cap, uint32_t rec_cap, uint32_t *counters /*records, items, overflow, clip-list length: zeroed by launch_vertex*/,
-                        uint2 *clip_list /*one entry per source triangle*/, hipStream_t s);
+                        uint2 *clip_list /*one entry per source triangle*/,
+                        const float *block_bounds /*6 floats per block of SETUP_THREADS triangles: object-space box of their positions, or null*/, hipStream_t s);
 uint32_t raster_grid_blocks(bool depth_only, uint32_t cu_count);
 // after_owned: the blocks were written by k_raster_owned; only what k_bin left in the item table (counters[4] != 0) is drawn
 hipError_t launch_raster_vis(const SetupRec *recs, const RasterRec *rrecs, const uint2 *items, uint32_t item_cap, const uint32_t *counters, uint32_t grid_blocks,

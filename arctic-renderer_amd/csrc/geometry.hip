@@ -206,6 +206,39 @@ __device__ __forceinline__ void normalize3(const float *v, float *o) {
     o[0] = v[0] * inv; o[1] = v[1] * inv; o[2] = v[2] * inv;
 }
 
+// Cluster culling (round 5; no counterpart in the reference, which hands every triangle to the hardware's own clipper and culler,
+// forward_pass.cpp:212-224).  bb = {min xyz, max xyz} in object space of the positions a workgroup's triangles use (renderer.cpp:
+// cluster_bounds).  True only when NO triangle with its vertices in the box can touch a pixel this pass keeps: all eight corners, transformed
+// with the products k_vertex uses, lie beyond ONE plane -- near, far, or a side of the scissor rectangle `strict` pixels further out -- by more
+// than the rounding those two products can accumulate (E x the sum of the magnitudes of their terms; the products' own bound is ~5e-7 of
+// it).  The planes are half-spaces of clip space (x - x_l w < 0 ...), so no corner needs w > 0: whatever part of a triangle is drawn has
+// w > 0 (setup_triangle, the clipper's near plane) and lies in the same half-space, i.e. projects outside the scissor.  A lane takes corner
+// lane & 7; every wave of the workgroup reaches the same answer from the same numbers.  NaN or infinite bounds (renderer.cpp stores
+// them for clusters it cannot bound) compare false everywhere: never culled.
+// strict = 2 for k_vertex's vertex blocks, whose boxes contain the boxes of every cluster that uses one of their vertices: a block is
+// skipped only if each of those clusters is skipped by k_setup's test with strict = 1 (twice the margins on a larger box).
+__device__ __forceinline__ bool box_outside(const float *__restrict__ bb, const float *__restrict__ trs, const GeomParams &gp, float strict) {
+    const uint32_t k = threadIdx.x & 7u;
+    const float lo0 = bb[0], lo1 = bb[1], lo2 = bb[2], hi0 = bb[3], hi1 = bb[4], hi2 = bb[5];
+    float world[4], clip[4], aw[4], ac[4];
+    mat_vec(trs, (k & 1u) ? hi0 : lo0, (k & 2u) ? hi1 : lo1, (k & 4u) ? hi2 : lo2, 1.0f, world);
+    mat_vec(gp.clip_from_world, world[0], world[1], world[2], world[3], clip);
+    const float ax = fmaxf(fabsf(lo0), fabsf(hi0)), ay = fmaxf(fabsf(lo1), fabsf(hi1)), az = fmaxf(fabsf(lo2), fabsf(hi2));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) aw[i] = ((fabsf(trs[i]) * ax + fabsf(trs[4 + i]) * ay) + fabsf(trs[8 + i]) * az) + fabsf(trs[12 + i]);
+    const float *c = gp.clip_from_world;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ac[i] = ((fabsf(c[i]) * aw[0] + fabsf(c[4 + i]) * aw[1]) + fabsf(c[8 + i]) * aw[2]) + fabsf(c[12 + i]) * aw[3];
+    const float E = 4.0e-6f * strict, ex = E * ac[0], ey = E * ac[1], ez = E * ac[2], ew = E * ac[3];
+    const float hx = 0.5f * gp.vp_w, hy = 0.5f * gp.vp_h;   // setup_triangle: X = (x / w + 1) hx, Y = (1 - y / w) hy
+    const float xl = ((float)gp.sc_x0 - strict) / hx - 1.0f, xr = ((float)gp.sc_x1 + strict) / hx - 1.0f;
+    const float yt = 1.0f - ((float)gp.sc_y0 - strict) / hy, yb = 1.0f - ((float)gp.sc_y1 + strict) / hy;
+    const bool in_near = !(clip[2] < -ez), in_far = !(clip[2] - clip[3] > ez + ew);
+    const bool in_left = !(clip[0] - xl * clip[3] < -(ex + fabsf(xl) * ew)), in_right = !(clip[0] - xr * clip[3] > ex + fabsf(xr) * ew);
+    const bool in_top = !(clip[1] - yt * clip[3] > ey + fabsf(yt) * ew), in_bottom = !(clip[1] - yb * clip[3] < -(ey + fabsf(yb) * ew));
+    return !__ballot(in_near) || !__ballot(in_far) || !__ballot(in_left) || !__ballot(in_right) || !__ballot(in_top) || !__ballot(in_bottom);
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward.hlsl:50-66 vs_main for every vertex of every object in one launch
 // ---------------------------------------------------------------------------------------------
@@ -213,11 +246,15 @@ __global__ __launch_bounds__(256) void k_vertex(const ObjectRec *__restrict__ ob
                                                 const uint32_t *__restrict__ block_first, const GeomParams gp,
                                                 XVert *__restrict__ xv, int clip_only, uint32_t *__restrict__ counters,
                                                 unsigned long long *__restrict__ clear, unsigned long long clear_value, size_t clear_count,
-                                                uint32_t *__restrict__ zero, size_t zero_count) {
-    if (blockIdx.x == 0 && threadIdx.x < N_GEO_COUNTERS) counters[threadIdx.x] = 0;   // k_setup's slot counters and overflow flag (no memset launch)
+                                                uint32_t *__restrict__ zero, size_t zero_count, const float *__restrict__ bounds) {
+    // k_setup's slot counters and overflow flag (no memset launch); [6] counts this kernel's own skipped blocks when asked to (raster_flags bit 1: zeroed by the host then)
+    if (blockIdx.x == 0 && threadIdx.x < N_GEO_COUNTERS && !((gp.raster_flags & 2) && threadIdx.x == 6)) counters[threadIdx.x] = 0;
     const ObjectRec &ob = objs[block_obj[blockIdx.x]];
     uint32_t vi = block_first[blockIdx.x] + threadIdx.x;
-    const bool live = vi < ob.n_vertices;
+    // vertices only triangles of culled clusters use are not transformed: nothing will read them (box_outside)
+    const bool outside = bounds && box_outside(bounds + 6u * blockIdx.x, ob.trs, gp, 2.0f);   // (by every lane: the corners are spread over them)
+    const bool live = vi < ob.n_vertices && !outside;
+    if (outside && (gp.raster_flags & 2) && threadIdx.x == 0) atomicAdd(&counters[6], 1u);
     float src[14];
     if (live) {
         const float *p = ob.vertices + (size_t)vi * 14;
@@ -277,10 +314,19 @@ struct SetupTables {
 };
 
 // clip-space vertices of source triangle ti of object ob; false: no such triangle / an index out of range
-__device__ __forceinline__ bool load_triangle(const ObjectRec &ob, uint32_t ti, const XVert *__restrict__ xv, CV &a, CV &b, CV &c) {
+__device__ __forceinline__ bool load_indices(const ObjectRec &ob, uint32_t ti, uint32_t &i0, uint32_t &i1, uint32_t &i2) {
+    i0 = i1 = i2 = 0u;
     if (ti >= ob.n_triangles) return false;
-    const uint32_t i0 = ob.indices[3 * ti], i1 = ob.indices[3 * ti + 1], i2 = ob.indices[3 * ti + 2];
-    if (!(i0 < ob.n_vertices && i1 < ob.n_vertices && i2 < ob.n_vertices)) return false;
+    i0 = ob.indices[3 * ti]; i1 = ob.indices[3 * ti + 1]; i2 = ob.indices[3 * ti + 2];
+    return i0 < ob.n_vertices && i1 < ob.n_vertices && i2 < ob.n_vertices;
+}
+__device__ __forceinline__ bool load_triangle(const ObjectRec &ob, uint32_t ti, const XVert *__restrict__ xv, CV &a, CV &b, CV &c, const float *__restrict__ cull_bounds = nullptr,
+                                              const GeomParams *gp = nullptr, bool *culled = nullptr) {
+    uint32_t i0, i1, i2;
+    const bool ok = load_indices(ob, ti, i0, i1, i2);
+    // (k_setup: the cluster's test sits between the index loads and the vertex loads that wait for them, so a cluster that stays pays no round trip for it)
+    if (cull_bounds && box_outside(cull_bounds, ob.trs, *gp, 1.0f)) { *culled = true; return false; }
+    if (!ok) return false;
     const auto fetch = [&](uint32_t i, CV &v, float b0, float b1, float b2) {
         const float4 p = *reinterpret_cast<const float4 *>(xv[ob.first_xvert + i].clip);
         v.x = p.x; v.y = p.y; v.z = p.z; v.w = p.w; v.b0 = b0; v.b1 = b1; v.b2 = b2;
@@ -410,7 +456,7 @@ __device__ __forceinline__ unsigned long long take_slots(uint32_t nr, uint32_t n
 // for k_setup_clipped.  (With the clipper inside, its polygons in scratch memory, this kernel took 43 us at 4K.)
 __global__ __launch_bounds__(SETUP_THREADS) void k_setup(const ObjectRec *__restrict__ objs, const uint32_t *__restrict__ block_obj,
                                                          const uint32_t *__restrict__ block_first, const GeomParams gp,
-                                                         const XVert *__restrict__ xv, SetupTables T, uint2 *__restrict__ clip_list) {
+                                                         const XVert *__restrict__ xv, SetupTables T, uint2 *__restrict__ clip_list, const float *__restrict__ bounds) {
     constexpr uint32_t WAVES = SETUP_THREADS / 64;
     __shared__ uint32_t s_count[WAVES][2], s_base[2];
     const uint32_t oi = block_obj[blockIdx.x];
@@ -418,7 +464,12 @@ __global__ __launch_bounds__(SETUP_THREADS) void k_setup(const ObjectRec *__rest
     const uint32_t ti = block_first[blockIdx.x] + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     CV a, b, c;
-    const bool valid = load_triangle(ob, ti, xv, a, b, c);
+    bool culled = false;
+    const bool valid = load_triangle(ob, ti, xv, a, b, c, bounds ? bounds + 6u * blockIdx.x : nullptr, &gp, &culled);
+    if (culled) {         // the whole workgroup: no record, no item, no entry of the clip list could have come from it
+        if ((gp.raster_flags & 2) && threadIdx.x == 0) atomicAdd(&T.counters[5], 1u);
+        return;
+    }
     // the clipper's own first decision (clip_polygon): the first plane that does not hold all three vertices either holds none
     // -- nothing to draw -- or cuts the triangle; no such plane: the triangle goes through untouched
     bool inside = valid, straddles = false;
@@ -1081,18 +1132,18 @@ inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
 hipError_t launch_vertex(const ObjectRec *objs, const uint32_t *block_obj, const uint32_t *block_first, uint32_t n_blocks,
                          const GeomParams &gp, XVert *xv, int clip_only, uint32_t *counters, unsigned long long *clear, unsigned long long clear_value,
-                         size_t clear_count, uint32_t *zero, size_t zero_count, hipStream_t s) {
+                         size_t clear_count, uint32_t *zero, size_t zero_count, const float *block_bounds, hipStream_t s) {
     if (n_blocks == 0) return clear_count ? launch_fill_u64(clear, clear_value, clear_count, s) : hipSuccess;
-    k_vertex<<<n_blocks, 256, 0, s>>>(objs, block_obj, block_first, gp, xv, clip_only, counters, clear, clear_value, clear_count, zero, zero_count);
+    k_vertex<<<n_blocks, 256, 0, s>>>(objs, block_obj, block_first, gp, xv, clip_only, counters, clear, clear_value, clear_count, zero, zero_count, block_bounds);
     return hipGetLastError();
 }
 
 hipError_t launch_setup(const ObjectRec *objs, const uint32_t *block_obj, const uint32_t *block_first, uint32_t n_blocks,
                         const GeomParams &gp, const XVert *xv, SetupRec *recs, RasterRec *rrecs, uint32_t *rec_of, uint2 *items, uint32_t item_cap,
-                        uint32_t rec_cap, uint32_t *counters, uint2 *clip_list, hipStream_t s) {
+                        uint32_t rec_cap, uint32_t *counters, uint2 *clip_list, const float *block_bounds, hipStream_t s) {
     if (n_blocks == 0) return hipSuccess;
     const SetupTables T = {recs, rrecs, rec_of, items, item_cap, rec_cap, counters};
-    k_setup<<<n_blocks, SETUP_THREADS, 0, s>>>(objs, block_obj, block_first, gp, xv, T, clip_list);
+    k_setup<<<n_blocks, SETUP_THREADS, 0, s>>>(objs, block_obj, block_first, gp, xv, T, clip_list, block_bounds);
     // the clip list's length stays on the device: a fixed small grid strides over it (empty in most frames of most scenes)
     k_setup_clipped<<<std::min<uint32_t>(n_blocks * (SETUP_THREADS / CLIP_LANES), 256u), 64, 0, s>>>(objs, gp, xv, T, clip_list);
     return hipGetLastError();

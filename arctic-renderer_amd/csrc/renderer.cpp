@@ -13,6 +13,8 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -132,6 +134,7 @@ struct PassTables {
     // device views into the arena (valid after upload)
     const ObjectRec *objs = nullptr;
     const uint32_t *vblock_obj = nullptr, *vblock_first = nullptr, *tblock_obj = nullptr, *tblock_first = nullptr;
+    const float *vblock_bounds = nullptr, *tblock_bounds = nullptr;   // 6 floats per block (cluster_bounds)
 };
 
 struct Mesh {
@@ -139,7 +142,44 @@ struct Mesh {
     uint32_t *d_indices = nullptr;
     uint32_t n_vertices = 0, n_indices = 0;
     uint64_t material = 0;
+    std::vector<float> tbounds, vbounds;   // cluster_bounds: 6 floats per block of SETUP_THREADS triangles / of 256 vertices
 };
+
+// Object-space boxes for geometry.hip's box_outside, made once per mesh on the host.  tbounds[c] = {min xyz, max xyz} of the positions
+// the triangles [c * SETUP_THREADS, (c + 1) * SETUP_THREADS) use -- one workgroup of k_setup --, vbounds[b] = the union of the boxes
+// of every TRIANGLE that uses one of the vertices [256 b, 256 b + 256) -- one workgroup of k_vertex: a vertex may be skipped only when
+// all its triangles are.  Triangles with an index out of range draw nothing (load_indices) and bound nothing; a block that holds a
+// position that is not finite, or no triangle at all, gets an infinite box (never culled).
+void cluster_bounds(const ArcticVertex *v, uint32_t n_vertices, const uint32_t *ind, uint32_t n_indices, std::vector<float> &tb, std::vector<float> &vb) {
+    const uint32_t n_tri = n_indices / 3, n_tb = (n_tri + SETUP_THREADS - 1) / SETUP_THREADS, n_vb = (n_vertices + 255) / 256;
+    const float inf = std::numeric_limits<float>::infinity();
+    tb.assign((size_t)n_tb * 6, 0.0f); vb.assign((size_t)n_vb * 6, 0.0f);
+    for (uint32_t b = 0; b < n_tb; ++b) for (int k = 0; k < 3; ++k) { tb[6 * b + k] = inf; tb[6 * b + 3 + k] = -inf; }
+    for (uint32_t b = 0; b < n_vb; ++b) for (int k = 0; k < 3; ++k) { vb[6 * b + k] = inf; vb[6 * b + 3 + k] = -inf; }
+    std::vector<char> bad_t(n_tb, 0), bad_v(n_vb, 0);
+    for (uint32_t t = 0; t < n_tri; ++t) {
+        const uint32_t i[3] = {ind[3 * t], ind[3 * t + 1], ind[3 * t + 2]};
+        if (!(i[0] < n_vertices && i[1] < n_vertices && i[2] < n_vertices)) continue;
+        float lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf};
+        bool finite = true;
+        for (int j = 0; j < 3; ++j) for (int k = 0; k < 3; ++k) {
+            const float p = v[i[j]].position[k];
+            finite = finite && std::isfinite(p);
+            lo[k] = std::min(lo[k], p); hi[k] = std::max(hi[k], p);
+        }
+        const auto grow = [&](std::vector<float> &box, std::vector<char> &bad, uint32_t b) {
+            if (!finite) bad[b] = 1;
+            for (int k = 0; k < 3; ++k) { box[6 * b + k] = std::min(box[6 * b + k], lo[k]); box[6 * b + 3 + k] = std::max(box[6 * b + 3 + k], hi[k]); }
+        };
+        grow(tb, bad_t, t / SETUP_THREADS);
+        for (int j = 0; j < 3; ++j) if (j == 0 || (i[j] / 256 != i[0] / 256 && (j == 1 || i[j] / 256 != i[1] / 256))) grow(vb, bad_v, i[j] / 256);
+    }
+    const auto finish = [&](std::vector<float> &box, const std::vector<char> &bad, uint32_t n) {
+        for (uint32_t b = 0; b < n; ++b)
+            if (bad[b] || !(box[6 * b] <= box[6 * b + 3])) for (int k = 0; k < 3; ++k) { box[6 * b + k] = -inf; box[6 * b + 3 + k] = inf; }
+    };
+    finish(tb, bad_t, n_tb); finish(vb, bad_v, n_vb);
+}
 
 }  // namespace
 
@@ -183,6 +223,7 @@ struct ArcticRenderer {
         DevBuf d_bin_count, d_bin_slots;   // block ownership (common.h: BinTables): a counter and BIN_SLOTS record indices per 16x16 block of the target
         uint32_t item_cap = 0;      // entries of d_items (work-item table of the rasteriser)
         uint32_t bins_x = 0, bins_y = 0;   // blocks of the latest owned pass (arctic_read_bin_counts)
+        uint32_t n_tblocks = 0, n_vblocks = 0; bool cull_counted = false;   // the latest pass's workgroups (arctic_read_cull_counts)
     } geo[4];   // indexed like tables
     DevBuf d_geo_counters, d_stage;
     hipStream_t shadow_stream = nullptr;            // arctic_render_frame draws the shadow map here while the main stream runs the visibility prepass
@@ -227,6 +268,7 @@ struct ArcticRenderer {
                                      // out by cost instead of by XCD row costs the pass 83 MB of fabric reads per launch (L2 hits 2.33 M -> 1.73 M: neighbouring strips no longer meet in one L2)
     uint32_t order_tail = 60;        // ARCTIC_OPT_ORDER_TAIL: the last part of the order (per mille) that holds cheap strips only
     DevBuf d_tile_trace;             // ARCTIC_OPT_TILE_TRACE: 4 x u64 per tile of the latest shading pass
+    int cluster_cull = 3;            // ARCTIC_OPT_CLUSTER_CULL: bit 0 k_setup skips clusters, bit 1 k_vertex skips vertex blocks, that cannot touch the pass's pixels
     int raster_owner = -1;           // ARCTIC_OPT_RASTER_OWNER: bit 0 forward pass, bit 1 shadow pass: the blocks of the target are written once by owner waves
                                      // (k_bin + k_raster_owned) instead of per-pixel atomics; -1: the library's choice
     uint32_t raster_blocks[2] = {2048, 2048};  // persistent grid of k_raster: [0] forward pass, [1] shadow pass
@@ -329,6 +371,7 @@ int upload_pass_tables(ArcticRenderer *r, PassTables &T, DevBuf &d_xverts, hipSt
                        uint32_t &n_xverts, uint32_t &n_src_tris, uint32_t &n_vblocks, uint32_t &n_tblocks) {
     std::vector<ObjectRec> objs;
     std::vector<uint32_t> vb_obj, vb_first, tb_obj, tb_first;
+    std::vector<float> vb_box, tb_box;
     uint64_t xv = 0, tri = 0;
     for (uint64_t i = 0; i < sc->n_objects; ++i) {
         const ArcticObject &o = sc->objects[i];
@@ -347,6 +390,8 @@ int upload_pass_tables(ArcticRenderer *r, PassTables &T, DevBuf &d_xverts, hipSt
         uint32_t oi = (uint32_t)objs.size();
         for (uint32_t b = 0; b < rec.n_vertices; b += 256) { vb_obj.push_back(oi); vb_first.push_back(b); }
         for (uint32_t b = 0; b < rec.n_triangles; b += SETUP_THREADS) { tb_obj.push_back(oi); tb_first.push_back(b); }
+        vb_box.insert(vb_box.end(), m.vbounds.begin(), m.vbounds.end());
+        tb_box.insert(tb_box.end(), m.tbounds.begin(), m.tbounds.end());
         xv += rec.n_vertices;
         tri += rec.n_triangles;
         objs.push_back(rec);
@@ -358,13 +403,17 @@ int upload_pass_tables(ArcticRenderer *r, PassTables &T, DevBuf &d_xverts, hipSt
     auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
     const size_t o_objs = 0, o_vo = align16(o_objs + objs.size() * sizeof(ObjectRec)),
                  o_vf = align16(o_vo + vb_obj.size() * 4), o_to = align16(o_vf + vb_first.size() * 4),
-                 o_tf = align16(o_to + tb_obj.size() * 4), total = align16(o_tf + tb_first.size() * 4) + 16;
+                 o_tf = align16(o_to + tb_obj.size() * 4), o_vb = align16(o_tf + tb_first.size() * 4), o_tb = align16(o_vb + vb_box.size() * 4),
+                 total = align16(o_tb + tb_box.size() * 4) + 16;
+    if (vb_box.size() != vb_obj.size() * 6 || tb_box.size() != tb_obj.size() * 6) return r->fail(ARCTIC_E_INVALID, "internal: cluster bounds out of step with the block tables");
     T.gp = gp;
     std::vector<char> stage(total, 0);
     char *h = stage.data();
     if (!objs.empty()) std::memcpy(h + o_objs, objs.data(), objs.size() * sizeof(ObjectRec));
     if (!vb_obj.empty()) { std::memcpy(h + o_vo, vb_obj.data(), vb_obj.size() * 4); std::memcpy(h + o_vf, vb_first.data(), vb_first.size() * 4); }
     if (!tb_obj.empty()) { std::memcpy(h + o_to, tb_obj.data(), tb_obj.size() * 4); std::memcpy(h + o_tf, tb_first.data(), tb_first.size() * 4); }
+    if (!vb_box.empty()) std::memcpy(h + o_vb, vb_box.data(), vb_box.size() * 4);
+    if (!tb_box.empty()) std::memcpy(h + o_tb, tb_box.data(), tb_box.size() * 4);
     if (!(T.d.p && stage == T.last)) {
         if (T.pending) { HIPCHECK(r, hipEventSynchronize(T.copied)); T.pending = false; }
         if (total > T.h_cap) {
@@ -386,6 +435,7 @@ int upload_pass_tables(ArcticRenderer *r, PassTables &T, DevBuf &d_xverts, hipSt
     T.objs = reinterpret_cast<const ObjectRec *>(d + o_objs);
     T.vblock_obj = reinterpret_cast<const uint32_t *>(d + o_vo); T.vblock_first = reinterpret_cast<const uint32_t *>(d + o_vf);
     T.tblock_obj = reinterpret_cast<const uint32_t *>(d + o_to); T.tblock_first = reinterpret_cast<const uint32_t *>(d + o_tf);
+    T.vblock_bounds = reinterpret_cast<const float *>(d + o_vb); T.tblock_bounds = reinterpret_cast<const float *>(d + o_tb);
     if (n_objs) {
         HIPCHECK(r, d_xverts.ensure((size_t)n_xverts * sizeof(XVert)));
     }
@@ -423,7 +473,7 @@ int run_geometry(ArcticRenderer *r, const ArcticScene *sc, bool shadow_pass, hip
         gp.tiles_x = (int32_t)r->tiles_x; gp.tile_y0 = (int32_t)r->tile_y0; gp.pitch = 0;
         gp.band_tiles = (int32_t)(r->band_rows / TILE); gp.shard_index = (int32_t)r->shard_index; gp.shard_count = (int32_t)r->shard_count;
     }
-    gp.raster_flags = (r->debug & 32) ? 1 : 0;
+    gp.raster_flags = ((r->debug & 32) ? 1 : 0) | ((r->debug & 1024) ? 2 : 0);
     gp.tiles_y = shadow_pass ? (int32_t)((r->shadow_size + 7) / 8) : (int32_t)r->tiles_y;
     // block ownership (ARCTIC_OPT_RASTER_OWNER; default -1 = the choice below): the blocks are written once by their owners, so nothing is cleared
     // the library's choice: the forward pass of a handle that owns 4 Mpx or more -- three launches instead of one cost ~12 us of fixed
@@ -456,8 +506,11 @@ int run_geometry(ArcticRenderer *r, const ArcticScene *sc, bool shadow_pass, hip
         return ARCTIC_OK;
     }
     const ObjectRec *objs = T.objs;
+    G.n_tblocks = n_tblocks; G.n_vblocks = n_vblocks; G.cull_counted = (r->debug & 1024) != 0;
+    if (G.cull_counted) HIPCHECK(r, hipMemsetAsync(r->d_geo_counters.as<uint32_t>() + N_GEO_COUNTERS * set + 6, 0, 4, stream));   // (k_vertex counts into it from its first workgroup on)
     HIPCHECK(r, launch_vertex(objs, T.vblock_obj, T.vblock_first, n_vblocks, d_gp, G.d_xverts.as<XVert>(), shadow_pass ? 1 : 0,
-                              r->d_geo_counters.as<uint32_t>() + N_GEO_COUNTERS * set, clear, clear_value, owned ? 0 : clear_count, B.count, owned ? B.n_blocks : 0, stream));
+                              r->d_geo_counters.as<uint32_t>() + N_GEO_COUNTERS * set, clear, clear_value, owned ? 0 : clear_count, B.count, owned ? B.n_blocks : 0,
+                              (r->cluster_cull & 2) ? T.vblock_bounds : nullptr, stream));
     // Record slots: a triangle clipped against 6 planes yields at most 7 triangles, so 7 * n_src slots can never overflow.
     // Records and work items are allocated on the device from two counters (k_setup): no count pass, no scan, and neither
     // count has to come back to the host -- the frame stays asynchronous.
@@ -482,7 +535,7 @@ int run_geometry(ArcticRenderer *r, const ArcticScene *sc, bool shadow_pass, hip
     uint32_t *counters = r->d_geo_counters.as<uint32_t>() + N_GEO_COUNTERS * set;   // zeroed by k_vertex
     HIPCHECK(r, launch_setup(objs, T.tblock_obj, T.tblock_first, n_tblocks, d_gp, G.d_xverts.as<XVert>(), G.d_recs.as<SetupRec>(),
                              G.d_rrecs.as<RasterRec>(), G.d_rec_of.as<uint32_t>(), G.d_items.as<uint2>(), G.item_cap, n_slots, counters,
-                             G.d_clip_list.as<uint2>(), stream));
+                             G.d_clip_list.as<uint2>(), (r->cluster_cull & 1) ? T.tblock_bounds : nullptr, stream));
     // counts for arctic_stats() and the overflow flag: k_raster stores them into pinned, mapped memory (no copy launches between
     // the kernels); looked at only when the stream has been synchronised
     uint32_t *dh = r->dh_counts + (shadow_pass ? 2 : 0), *dh_overflow = r->dh_counts + 4 + (shadow_pass ? 1 : 0);
@@ -757,24 +810,29 @@ ArcticRenderer *arctic_create(const ArcticCreateInfo *info, char *err, uint64_t 
         return (ArcticRenderer *)nullptr;
     };
     hipError_t e;
+    // The events below order streams of THIS device among each other (prepass / shadow pass / shading of frames in flight); nothing waits for them on the
+    // host or on another device.  Without the system-scope fence HIP otherwise puts around every record and wait -- a cache write-back and invalidate between
+    // two shading kernels -- a 4K frame takes 0.256 instead of 0.261 ms, one rank of 8's 0.065 instead of 0.069 (round 5, tools/experiments/cull_ab.py's loop).
+    // (ev_main and the gather's events, which RCCL's transfers to other devices follow, keep the default.)
+    const unsigned in_device_event = hipEventDisableTiming | hipEventDisableSystemFence;
     if ((e = hipSetDevice(r->device)) != hipSuccess) return bail("hipSetDevice", e);
     if ((e = hipStreamCreateWithFlags(&r->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     r->stream = r->own_stream;
     if ((e = hipStreamCreateWithFlags(&r->shadow_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
-    if ((e = hipEventCreateWithFlags(&r->ev_fork, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
-    if ((e = hipEventCreateWithFlags(&r->ev_shadow, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
-    if ((e = hipEventCreateWithFlags(&r->ev_shadow_scratch, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreateWithFlags(&r->ev_fork, in_device_event)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreateWithFlags(&r->ev_shadow, in_device_event)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreateWithFlags(&r->ev_shadow_scratch, in_device_event)) != hipSuccess) return bail("hipEventCreate", e);
     // The HIP runtime deals its hardware queues (4 by default, GPU_MAX_HW_QUEUES) to streams in the order they are created, and two
     // streams on one queue do not overlap: the handle's own stream, the shadow stream and the first prepass stream are created here, in
     // that order (with a caller's stream that makes four); the second prepass stream, which only three frames in flight use, is the
     // handle's own stream when the caller brought one (it is idle then), else created when first needed (second_prepass_stream)
     if ((e = hipStreamCreateWithFlags(&r->prepass_stream[0], hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     for (int k = 0; k < 2; ++k)
-        if ((e = hipEventCreateWithFlags(&r->ev_prepass[k], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+        if ((e = hipEventCreateWithFlags(&r->ev_prepass[k], in_device_event)) != hipSuccess) return bail("hipEventCreate", e);
     for (hipEvent_t &ev : r->ev_released)
-        if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+        if ((e = hipEventCreateWithFlags(&ev, in_device_event)) != hipSuccess) return bail("hipEventCreate", e);
     for (hipEvent_t &ev : r->ev_shadow_released)
-        if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+        if ((e = hipEventCreateWithFlags(&ev, in_device_event)) != hipSuccess) return bail("hipEventCreate", e);
     {
         hipDeviceProp_t prop;
         if ((e = hipGetDeviceProperties(&prop, r->device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
@@ -959,6 +1017,7 @@ int arctic_create_mesh(ArcticRenderer *r, const ArcticVertex *vertices, uint64_t
     HIPCHECK(r, hipMalloc((void **)&m.d_vertices, n_vertices * sizeof(ArcticVertex)));
     if (hipMalloc((void **)&m.d_indices, n_indices * 4) != hipSuccess) { (void)hipFree(m.d_vertices); return r->fail(ARCTIC_E_DEVICE, "create_mesh: hipMalloc indices"); }
     m.n_vertices = (uint32_t)n_vertices; m.n_indices = (uint32_t)n_indices; m.material = material_idx;
+    cluster_bounds(vertices, m.n_vertices, indices, m.n_indices, m.tbounds, m.vbounds);
     r->meshes.push_back(m);
     HIPCHECK(r, hipMemcpy(m.d_vertices, vertices, n_vertices * sizeof(ArcticVertex), hipMemcpyHostToDevice));
     HIPCHECK(r, hipMemcpy(m.d_indices, indices, n_indices * 4, hipMemcpyHostToDevice));
@@ -1302,6 +1361,19 @@ int arctic_read_bin_counts(ArcticRenderer *r, int shadow_pass, uint32_t *out, ui
     return ARCTIC_OK;
 }
 
+int arctic_read_cull_counts(ArcticRenderer *r, int shadow_pass, uint32_t *out) {
+    if (!r || !out) return ARCTIC_E_INVALID;
+    const int set = shadow_pass ? 1 : r->fwd();
+    const ArcticRenderer::GeoSet &G = r->geo[set];
+    if (!G.cull_counted) return r->fail(ARCTIC_E_STATE, "read_cull_counts: the latest %s pass did not count (ARCTIC_OPT_DEBUG bit 10)", shadow_pass ? "shadow" : "forward");
+    int rc = arctic_flush(r);
+    if (rc) return rc;
+    uint32_t c[N_GEO_COUNTERS];
+    HIPCHECK(r, hipMemcpy(c, r->d_geo_counters.as<uint32_t>() + N_GEO_COUNTERS * set, sizeof c, hipMemcpyDeviceToHost));
+    out[0] = G.n_tblocks; out[1] = c[5]; out[2] = G.n_vblocks; out[3] = c[6];
+    return ARCTIC_OK;
+}
+
 int arctic_read_tile_trace(ArcticRenderer *r, uint64_t *out, uint64_t capacity_tiles, uint32_t *tiles_x, uint32_t *tiles_y) {
     if (!r) return ARCTIC_E_INVALID;
     if (tiles_x) *tiles_x = r->tiles_x;
@@ -1388,6 +1460,9 @@ int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value) {
         if (value < 0 || value > 1000) return r->fail(ARCTIC_E_INVALID, "set_option: order tail is per mille, 0..1000");
         r->order_tail = (uint32_t)value;
         break;
+    case ARCTIC_OPT_CLUSTER_CULL:
+        if (value < 0 || value > 3 || value == 2) return r->fail(ARCTIC_E_INVALID, "ARCTIC_OPT_CLUSTER_CULL: 0, 1 or 3 (vertex blocks are skipped only where their clusters are)");
+        r->cluster_cull = (int)value; r->shadow_key.clear(); break;
     case ARCTIC_OPT_RASTER_OWNER: r->raster_owner = value < 0 ? -1 : (int)(value & 3); r->shadow_key.clear(); break;
     case ARCTIC_OPT_SHADOW_CACHE: r->shadow_cache = value != 0; r->shadow_key.clear(); break;
     case ARCTIC_OPT_SHADOW_SHARDED: r->shadow_sharded = value != 0; r->shadow_key.clear(); break;

@@ -261,6 +261,13 @@ class Renderer:
         self._check(self.L.arctic_read_bin_counts(self.h, int(shadow_pass), _ptr(out), bx.value * by.value, C.byref(bx), C.byref(by)))
         return out
 
+    def cull_counts(self, shadow_pass=False):
+        """(clusters, clusters skipped, vertex blocks, vertex blocks skipped) of the latest prepass that ran under debug bit 10
+        (arctic_read_cull_counts)."""
+        out = np.zeros(4, np.uint32)
+        self._check(self.L.arctic_read_cull_counts(self.h, int(shadow_pass), _ptr(out)))
+        return out
+
     def set_option(self, name, value):
         self._check(self.L.arctic_set_option(self.h, binding.OPTIONS[name], int(value)))
 

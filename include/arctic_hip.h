@@ -272,7 +272,8 @@ int arctic_stats(ArcticRenderer *r, uint64_t *out, uint32_t n);
                                           pointers (the path of tables of 4 GiB and more) instead of 32-bit offsets (same image); bit 7 arctic_render_frame draws the
                                           shadow map on the main stream before the visibility prepass instead of beside it on a second stream (same image);
                                           bit 8 every tile through the general tile code, none through the fast tile (same image; A/B and tests);
-                                          bit 9 the bins of the block owners count every work item offered, full or not (arctic_read_bin_counts as a histogram; same image) */
+                                          bit 9 the bins of the block owners count every work item offered, full or not (arctic_read_bin_counts as a histogram; same image);
+                                          bit 10 the prepasses count the workgroups ARCTIC_OPT_CLUSTER_CULL skipped (arctic_read_cull_counts; same image) */
 #define ARCTIC_OPT_HDR16             6 /* 1 = round ps_main's colour through binary16 before post_process, like the reference's
                                         R16G16B16A16_FLOAT colour target (forward_pass.cpp:149, renderer.cpp:128-144); default 0 = fp32 */
 #define ARCTIC_OPT_SHADOW_CACHE      9 /* 1 (default) = arctic_render_frame redraws the shadow map only when the sun, the objects or the mesh list changed
@@ -324,6 +325,12 @@ int arctic_stats(ArcticRenderer *r, uint64_t *out, uint32_t n);
                                           4 x 4 texels (one 128-byte line each) for images of 2048 texels a side and more, row-major below; 0 = row-major; 1 = tiles.
                                           The reference creates one mip level (rhi.cpp:550), so large textures are minified at mip 0 and every pixel's footprint is its
                                           own cache lines: 2 in a row-major image, 1.56 on average in tiles.  A layout only: same texels, same image */
+#define ARCTIC_OPT_CLUSTER_CULL      23 /* the prepasses skip whole workgroups of triangles / vertices whose object-space box (made per mesh by arctic_create_mesh) lies
+                                          beyond a side of the pass's scissor rectangle, the near or the far plane -- the shard's rows for a row-range shard, the
+                                          rank's slice of a sharded shadow map: 3 (default) = k_setup skips clusters of 256 triangles and k_vertex blocks of 256
+                                          vertices all of whose triangles are skipped, 1 = k_setup only, 0 = off.  Conservative (geometry.hip: box_outside): same
+                                          visibility plane, shadow map and counts, bit for bit.  No counterpart in the reference, which leaves culling to the
+                                          hardware's clipper (forward_pass.cpp:212-224 draws every object) */
 #define ARCTIC_OPT_MARKERS          13 /* 1 = roctx ranges around each pass, named like the reference's Tracy zones (process-wide; libroctx64 is loaded on demand) */
 int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value);
 
@@ -348,6 +355,11 @@ int arctic_read_tile_order(ArcticRenderer *r, uint32_t *order, uint8_t *tile_cla
    waves, choice of the bin size); no counterpart in the reference, whose rasteriser is the GPU's fixed function
    (forward_pass.cpp:212-224). */
 int arctic_read_bin_counts(ArcticRenderer *r, int shadow_pass, uint32_t *out, uint64_t capacity_blocks, uint32_t *blocks_x, uint32_t *blocks_y);
+
+/* What ARCTIC_OPT_CLUSTER_CULL skipped in the latest forward (shadow_pass = 0) or shadow (1) prepass that ran under ARCTIC_OPT_DEBUG bit 10:
+   out[0] = clusters of 256 triangles in the scene, out[1] = of them skipped by k_setup, out[2] = blocks of 256 vertices, out[3] = of them skipped by
+   k_vertex.  Synchronises.  A measuring aid; no counterpart in the reference (forward_pass.cpp:212-224 draws every object). */
+int arctic_read_cull_counts(ArcticRenderer *r, int shadow_pass, uint32_t *out);
 
 /* The owner grid of a forward prepass as plain numbers -- pure host functions, no device, no handle (the library's kernels use the
    same definitions).  A handle created with these sizes (row range [row_begin, row_end), or -- band_rows > 0 -- the interleaved
