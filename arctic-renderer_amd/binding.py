@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ARCTIC_HIP_LIBRARY") or os.path.join(HERE, "csrc", "libarctic_hip.so")   # the override is for A/B timing of two builds (tools/experiments)
 HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "arctic_hip.h")
 
-OPTIONS = {"keep_float_output": 1, "count_light_evals": 2, "culling": 3, "debug": 4, "hdr16": 6, "shadow_cache": 9, "visbuffer": 10, "item_table_floor": 11, "light_path": 12, "markers": 13, "shadow_sharded": 14, "frames_in_flight": 15, "tiles_per_wave": 16, "tile_trace": 17, "raster_owner": 18, "tile_order": 19, "order_tail": 20, "sampler": 21, "texture_tiling": 22, "cluster_cull": 23}
+OPTIONS = {"keep_float_output": 1, "count_light_evals": 2, "culling": 3, "debug": 4, "hdr16": 6, "shadow_cache": 9, "visbuffer": 10, "item_table_floor": 11, "light_path": 12, "markers": 13, "shadow_sharded": 14, "frames_in_flight": 15, "tiles_per_wave": 16, "tile_trace": 17, "raster_owner": 18, "tile_order": 19, "order_tail": 20, "sampler": 21, "texture_tiling": 22, "cluster_cull": 23, "small_triangles": 24}
 ERRORS = {-1: "ARCTIC_E_INVALID", -2: "ARCTIC_E_DEVICE", -3: "ARCTIC_E_NO_DEVICE", -4: "ARCTIC_E_STATE", -5: "ARCTIC_E_CAPACITY"}
 
 _vp, _u32, _u64, _i32, _i64 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32, C.c_int64

@@ -317,7 +317,8 @@ hipError_t launch_setup(const ObjectRec *objs, const uint32_t *block_obj, const 
                         const GeomParams &gp, const XVert *xv, SetupRec *recs, RasterRec *rrecs, uint32_t *rec_of /*8 per source triangle*/,
                         uint2 *items, uint32_t item_cap, uint32_t rec_cap, uint32_t *counters /*records, items, overflow, clip-list length: zeroed by launch_vertex*/,
                         uint2 *clip_list /*one entry per source triangle*/,
-                        const float *block_bounds /*6 floats per block of SETUP_THREADS triangles: object-space box of their positions, or null*/, hipStream_t s);
+                        const float *block_bounds /*6 floats per block of SETUP_THREADS triangles: object-space box of their positions, or null*/,
+                        uint32_t *small_depth_bits /*shadow pass: the map, when k_setup is to draw the triangles with a small bounding box itself; else null*/, hipStream_t s);
 uint32_t raster_grid_blocks(bool depth_only, uint32_t cu_count);
 // after_owned: the blocks were written by k_raster_owned; only what k_bin left in the item table (counters[4] != 0) is drawn
 hipError_t launch_raster_vis(const SetupRec *recs, const RasterRec *rrecs, const uint2 *items, uint32_t item_cap, const uint32_t *counters, uint32_t grid_blocks,

@@ -311,6 +311,7 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v, uint32_t lane
 struct SetupTables {
     SetupRec *recs; RasterRec *rrecs; uint32_t *rec_of; uint2 *items; uint32_t item_cap, rec_cap;
     uint32_t *counters;   // [0] records, [1] work items (one 64-bit word), [2] overflow flag, [3] entries of the clip list
+    uint32_t *depth_bits; // k_setup<true> (the shadow pass): the map, for the triangles k_setup draws itself (draw_small)
 };
 
 // clip-space vertices of source triangle ti of object ob; false: no such triangle / an index out of range
@@ -451,14 +452,112 @@ __device__ __forceinline__ unsigned long long take_slots(uint32_t nr, uint32_t n
     return base;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Small triangles of the shadow pass, drawn by k_setup itself (round 5).  The sun's orthographic frustum holds the whole scene, so most of
+// what it sees is small: 63 % of config 3's 113 k shadow records have a bounding box of at most 64 pixels (median 54) -- and each paid
+// a record (256 B written, 128 B read per item through the scalar cache), 1.8 work items, a place in a wave's sort and 256 pixel
+// evaluations per item in binary64 for its ~25 covered pixels.  Here such a triangle never becomes a record: the lanes of the wave that
+// set the triangles up share out the PIXELS of their bounding boxes (a lane per pixel, box after box, 64 at a time), the planes as 32-bit
+// integers relative to the box's first pixel (exact: SmallRec), and a covered pixel goes to the map with one atomicMin -- lanes of one
+// instruction that fall into one 64-byte row segment are one request for the memory side, whichever triangle they belong to, and the
+// boxes of consecutive triangles of a mesh are neighbours.  Same coverage rule, same depth expression on the same exact numerators as
+// item_pixels / raster_item_i64, and atomicMin does not care who sends the depth: the map is the same bit for bit.
+// ---------------------------------------------------------------------------------------------
+#ifndef SMALL_PX
+#define SMALL_PX 64     // bounding-box pixels up to which a shadow-pass triangle is drawn by k_setup (0: none)
+#endif
+struct SmallRec {       // 64 B in LDS, one per small triangle of the wave, in lane order
+    int32_t E[3];       // edge functions (edges.h: edge_eval + bias) at the box's first pixel: covered <=> all three >= 0
+    int32_t Ax[3], By[3];   // their steps per pixel in x and y; |.| < 2^23 (24-bit multiplies), so that no value over the box leaves int32
+    float z0, dz1, dz2, inv_area;
+    uint32_t origin;    // px0 | py0 << 16
+    uint32_t span;      // first pixel slot of the triangle in the wave's list | box width << 16 | (bias of edge 0 != 0) << 28 | (bias of edge 2 != 0) << 29
+    uint32_t M;         // floor(65536 / width) + 1: slot j of the box is pixel (j - w (j M >> 16), j M >> 16) -- exact while w * j < 65536
+};
+static_assert(sizeof(SmallRec) == 64, "SmallRec layout");
+constexpr uint32_t SMALL_WORDS = (SMALL_PX * 64u + 31u) / 32u + 2u;   // start bits of a wave's pixel list (+ the 64-bit read at its end)
+
+// is the triangle small, and if so its SmallRec (span without the slot, which the caller knows after the wave's prefix sum)
+__device__ __forceinline__ bool small_record(const SetupRec &t, SmallRec &s, uint32_t &n) {
+    const uint32_t w = (uint32_t)(t.px1 - t.px0 + 1), h = (uint32_t)(t.py1 - t.py0 + 1);
+    n = w * h;
+    if (w > 64u || h > (uint32_t)SMALL_PX || n > (uint32_t)SMALL_PX) return false;
+    Edges e;
+    make_edges(t, e);
+    bool fits = true;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int64_t E = edge_eval(e, i, t.px0, t.py0) + e.bias[i], ax = -e.dy[i] * 256, by = e.dx[i] * 256;
+        const int64_t reach = (E < 0 ? -E : E) + (ax < 0 ? -ax : ax) * (int64_t)(w - 1) + (by < 0 ? -by : by) * (int64_t)(h - 1);
+        fits = fits && ax > -(1 << 23) && ax < (1 << 23) && by > -(1 << 23) && by < (1 << 23) && reach < 0x7FFFFFF0ll;
+        s.E[i] = (int32_t)E; s.Ax[i] = (int32_t)ax; s.By[i] = (int32_t)by;
+    }
+    s.z0 = t.z[0]; s.dz1 = t.z[1] - t.z[0]; s.dz2 = t.z[2] - t.z[0];
+    s.inv_area = 1.0f / (float)t.area2;
+    s.origin = (uint32_t)t.px0 | ((uint32_t)t.py0 << 16);
+    s.span = (w << 16) | (e.bias[0] != 0 ? 1u << 28 : 0u) | (e.bias[2] != 0 ? 1u << 29 : 0u);
+    s.M = 65536u / w + 1u;
+    return fits && t.px0 >= 0 && t.py0 >= 0 && t.px1 < 65536 && t.py1 < 65536;
+}
+
+// every lane of the wave calls this; `small` lanes bring a triangle.  recs / starts: this wave's LDS.  Returns the wave's pixel slots.
+// (Two parts, so that the sixteen registers of a SmallRec do not live through planning and placing the other triangles.)
+__device__ __forceinline__ uint32_t stage_small(bool small, SmallRec &s, uint32_t n, SmallRec *recs, uint32_t *starts) {
+    const uint32_t lane = threadIdx.x & 63;
+    const unsigned long long sm = __ballot(small);
+    if (sm == 0ull) return 0u;   // uniform per wave
+    const uint32_t incl = wave_inclusive_sum(small ? n : 0u, lane);
+    for (uint32_t k = lane; k < SMALL_WORDS; k += 64) starts[k] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (LDS operations of one wave execute in order; this keeps the compiler from exchanging them)
+    if (small) {
+        const uint32_t first = incl - n;
+        s.span |= first;
+        recs[__popcll(sm & ((1ull << lane) - 1ull))] = s;
+        atomicOr(&starts[first >> 5], 1u << (first & 31u));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    return __shfl(incl, 63);
+}
+__device__ __forceinline__ void draw_small(uint32_t total, uint32_t *__restrict__ depth_bits, uint32_t pitch, const SmallRec *recs, const uint32_t *starts) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t le_lo = lane >= 32 ? 0xFFFFFFFFu : (2u << lane) - 1u, le_hi = lane >= 32 ? (lane == 63 ? 0xFFFFFFFFu : (2u << (lane - 32)) - 1u) : 0u;   // lanes <= this one
+    uint32_t base = 0;        // triangles that begin before this step's pixels
+    for (uint32_t first = 0; first < total; first += 64) {
+        const uint32_t w0 = starts[first >> 5], w1 = starts[(first >> 5) + 1];   // the step's 64 start bits (first is a multiple of 64)
+        const uint32_t idx = base + (uint32_t)__popc(w0 & le_lo) + (uint32_t)__popc(w1 & le_hi) - 1u;
+        base += (uint32_t)__popc(w0) + (uint32_t)__popc(w1);
+        const uint32_t p = first + lane;
+        if (p < total) {
+            const SmallRec r = recs[idx];
+            const uint32_t j = p - (r.span & 0xFFFFu), w = (r.span >> 16) & 0xFFFu;
+            const uint32_t dy = __umul24(j, r.M) >> 16, dx = j - __umul24(dy, w);
+            const int32_t e0 = r.E[0] + __mul24(r.Ax[0], (int32_t)dx) + __mul24(r.By[0], (int32_t)dy);
+            const int32_t e1 = r.E[1] + __mul24(r.Ax[1], (int32_t)dx) + __mul24(r.By[1], (int32_t)dy);
+            const int32_t e2 = r.E[2] + __mul24(r.Ax[2], (int32_t)dx) + __mul24(r.By[2], (int32_t)dy);
+            // the depth's numerators are the edge functions without the fill-rule bias (bias = -1 where bit set)
+            const float l1 = (float)(e2 + (int32_t)((r.span >> 29) & 1u)) * r.inv_area, l2 = (float)(e0 + (int32_t)((r.span >> 28) & 1u)) * r.inv_area;
+            float z = fmaf(l2, r.dz2, fmaf(l1, r.dz1, r.z0));
+            z = fminf(fmaxf(z, 0.0f), 1.0f);
+            const uint32_t zb = __float_as_uint(z);
+            if ((e0 | e1 | e2) >= 0 && zb < 0x3F800000u) {   // covered, and LESS against the 1.0 clear (a -0.0 never wins an unsigned min either way)
+                const uint32_t at = __umul24((r.origin >> 16) + dy, pitch) + (r.origin & 0xFFFFu) + dx;
+                __hip_atomic_fetch_min((uint32_t __attribute__((address_space(1))) *)((char __attribute__((address_space(1))) *)depth_bits + at * 4u), zb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
 // The common case, no private arrays and no LDS polygons: triangles inside all six planes are set up and emitted here (the
 // workgroup takes its slots with one atomic, split among the waves through LDS); triangles a plane cuts go to the clip list
 // for k_setup_clipped.  (With the clipper inside, its polygons in scratch memory, this kernel took 43 us at 4K.)
+template <bool SMALL>   // SMALL: the shadow pass -- triangles with a small bounding box are drawn here (draw_small) and take no record slot's bytes, no work item
 __global__ __launch_bounds__(SETUP_THREADS) void k_setup(const ObjectRec *__restrict__ objs, const uint32_t *__restrict__ block_obj,
                                                          const uint32_t *__restrict__ block_first, const GeomParams gp,
                                                          const XVert *__restrict__ xv, SetupTables T, uint2 *__restrict__ clip_list, const float *__restrict__ bounds) {
     constexpr uint32_t WAVES = SETUP_THREADS / 64;
     __shared__ uint32_t s_count[WAVES][2], s_base[2];
+    __shared__ SmallRec s_small[SMALL ? WAVES * 64 : 1];
+    __shared__ uint32_t s_starts[SMALL ? WAVES * SMALL_WORDS : 1];
     const uint32_t oi = block_obj[blockIdx.x];
     const ObjectRec &ob = objs[oi];
     const uint32_t ti = block_first[blockIdx.x] + threadIdx.x;
@@ -487,11 +586,17 @@ __global__ __launch_bounds__(SETUP_THREADS) void k_setup(const ObjectRec *__rest
     }
     SetupRec t;
     bool has = inside && setup_triangle(a, b, c, gp, t);
+    // (a small triangle counts as a record -- arctic_stats: triangles set up -- and takes a slot NUMBER, but nothing is written there and no item names it)
+    SmallRec sr;
+    uint32_t small_n = 0;
+    const bool small = SMALL && has && small_record(t, sr, small_n);
+    const uint32_t small_total = SMALL ? stage_small(small, sr, small_n, s_small + wave * 64, s_starts + wave * SMALL_WORDS) : 0u;
+    const unsigned long long m = __ballot(has);
+    has = has && !small;
     EmitPlan e;
     plan_triangle(has, t, gp, e);
     // an uncut source triangle: its vertices carry unit barycentrics (load_triangle), setup_triangle may have exchanged the last two
     if (has) e.q.flags |= RASTER_UNIT_BARY | (t.bary[1][2] == 1.0f ? RASTER_SWAPPED : 0u);
-    const unsigned long long m = __ballot(has);
     const uint32_t iincl = wave_inclusive_sum(e.nb, lane);
     if (lane == 63) { s_count[wave][0] = (uint32_t)__popcll(m); s_count[wave][1] = iincl; }
     __syncthreads();
@@ -505,6 +610,7 @@ __global__ __launch_bounds__(SETUP_THREADS) void k_setup(const ObjectRec *__rest
     uint32_t rbase = s_base[0], ibase = s_base[1];
     for (uint32_t w = 0; w < wave; ++w) { rbase += s_count[w][0]; ibase += s_count[w][1]; }
     place_triangle(has, t, e, rbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), ibase + iincl - e.nb, ob.first_triangle + ti, oi, 0u, gp, T, ob);
+    if (SMALL) draw_small(small_total, T.depth_bits, (uint32_t)gp.pitch, s_small + wave * 64, s_starts + wave * SMALL_WORDS);
 }
 
 // The triangles of the clip list, one wave per workgroup.  First a lane per triangle (CLIP_LANES of them): Sutherland-Hodgman in
@@ -1140,10 +1246,12 @@ hipError_t launch_vertex(const ObjectRec *objs, const uint32_t *block_obj, const
 
 hipError_t launch_setup(const ObjectRec *objs, const uint32_t *block_obj, const uint32_t *block_first, uint32_t n_blocks,
                         const GeomParams &gp, const XVert *xv, SetupRec *recs, RasterRec *rrecs, uint32_t *rec_of, uint2 *items, uint32_t item_cap,
-                        uint32_t rec_cap, uint32_t *counters, uint2 *clip_list, const float *block_bounds, hipStream_t s) {
+                        uint32_t rec_cap, uint32_t *counters, uint2 *clip_list, const float *block_bounds, uint32_t *small_depth_bits, hipStream_t s) {
     if (n_blocks == 0) return hipSuccess;
-    const SetupTables T = {recs, rrecs, rec_of, items, item_cap, rec_cap, counters};
-    k_setup<<<n_blocks, SETUP_THREADS, 0, s>>>(objs, block_obj, block_first, gp, xv, T, clip_list, block_bounds);
+    const SetupTables T = {recs, rrecs, rec_of, items, item_cap, rec_cap, counters, small_depth_bits};
+    // small_depth_bits: the shadow pass's map when its small triangles are to be drawn by k_setup (never with the integer path forced: that switch is an A/B of the item rasterisers)
+    if (small_depth_bits && SMALL_PX > 0 && !(gp.raster_flags & 1)) k_setup<true><<<n_blocks, SETUP_THREADS, 0, s>>>(objs, block_obj, block_first, gp, xv, T, clip_list, block_bounds);
+    else k_setup<false><<<n_blocks, SETUP_THREADS, 0, s>>>(objs, block_obj, block_first, gp, xv, T, clip_list, block_bounds);
     // the clip list's length stays on the device: a fixed small grid strides over it (empty in most frames of most scenes)
     k_setup_clipped<<<std::min<uint32_t>(n_blocks * (SETUP_THREADS / CLIP_LANES), 256u), 64, 0, s>>>(objs, gp, xv, T, clip_list);
     return hipGetLastError();

@@ -269,6 +269,7 @@ struct ArcticRenderer {
     uint32_t order_tail = 60;        // ARCTIC_OPT_ORDER_TAIL: the last part of the order (per mille) that holds cheap strips only
     DevBuf d_tile_trace;             // ARCTIC_OPT_TILE_TRACE: 4 x u64 per tile of the latest shading pass
     int cluster_cull = 3;            // ARCTIC_OPT_CLUSTER_CULL: bit 0 k_setup skips clusters, bit 1 k_vertex skips vertex blocks, that cannot touch the pass's pixels
+    int small_triangles = 1;         // ARCTIC_OPT_SMALL_TRIANGLES: 1 = the shadow pass's k_setup draws triangles with a small bounding box itself (geometry.hip: draw_small)
     int raster_owner = -1;           // ARCTIC_OPT_RASTER_OWNER: bit 0 forward pass, bit 1 shadow pass: the blocks of the target are written once by owner waves
                                      // (k_bin + k_raster_owned) instead of per-pixel atomics; -1: the library's choice
     uint32_t raster_blocks[2] = {2048, 2048};  // persistent grid of k_raster: [0] forward pass, [1] shadow pass
@@ -535,7 +536,9 @@ int run_geometry(ArcticRenderer *r, const ArcticScene *sc, bool shadow_pass, hip
     uint32_t *counters = r->d_geo_counters.as<uint32_t>() + N_GEO_COUNTERS * set;   // zeroed by k_vertex
     HIPCHECK(r, launch_setup(objs, T.tblock_obj, T.tblock_first, n_tblocks, d_gp, G.d_xverts.as<XVert>(), G.d_recs.as<SetupRec>(),
                              G.d_rrecs.as<RasterRec>(), G.d_rec_of.as<uint32_t>(), G.d_items.as<uint2>(), G.item_cap, n_slots, counters,
-                             G.d_clip_list.as<uint2>(), (r->cluster_cull & 1) ? T.tblock_bounds : nullptr, stream));
+                             G.d_clip_list.as<uint2>(), (r->cluster_cull & 1) ? T.tblock_bounds : nullptr,
+                             // (block owners STORE their blocks -- that store is the clear --, so nothing may be drawn before them)
+                             shadow_pass && !owned && r->small_triangles ? r->d_shadow().as<uint32_t>() : nullptr, stream));
     // counts for arctic_stats() and the overflow flag: k_raster stores them into pinned, mapped memory (no copy launches between
     // the kernels); looked at only when the stream has been synchronised
     uint32_t *dh = r->dh_counts + (shadow_pass ? 2 : 0), *dh_overflow = r->dh_counts + 4 + (shadow_pass ? 1 : 0);
@@ -1460,6 +1463,9 @@ int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value) {
         if (value < 0 || value > 1000) return r->fail(ARCTIC_E_INVALID, "set_option: order tail is per mille, 0..1000");
         r->order_tail = (uint32_t)value;
         break;
+    case ARCTIC_OPT_SMALL_TRIANGLES:
+        if (value < 0 || value > 1) return r->fail(ARCTIC_E_INVALID, "ARCTIC_OPT_SMALL_TRIANGLES: 0 or 1");
+        r->small_triangles = (int)value; r->shadow_key.clear(); break;
     case ARCTIC_OPT_CLUSTER_CULL:
         if (value < 0 || value > 3 || value == 2) return r->fail(ARCTIC_E_INVALID, "ARCTIC_OPT_CLUSTER_CULL: 0, 1 or 3 (vertex blocks are skipped only where their clusters are)");
         r->cluster_cull = (int)value; r->shadow_key.clear(); break;

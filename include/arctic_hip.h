@@ -331,6 +331,12 @@ int arctic_stats(ArcticRenderer *r, uint64_t *out, uint32_t n);
                                           vertices all of whose triangles are skipped, 1 = k_setup only, 0 = off.  Conservative (geometry.hip: box_outside): same
                                           visibility plane, shadow map and counts, bit for bit.  No counterpart in the reference, which leaves culling to the
                                           hardware's clipper (forward_pass.cpp:212-224 draws every object) */
+#define ARCTIC_OPT_SMALL_TRIANGLES   24 /* 1 (default) = the shadow pass draws triangles whose bounding box holds at most 64 pixels in its set-up kernel: the lanes
+                                          that set a wave's triangles up share out the pixels of their boxes, the edge functions as 32-bit integers relative to the
+                                          box, one atomicMin per covered pixel -- such a triangle (two thirds of what an orthographic sun sees of a tessellated
+                                          scene) never becomes a record or a 16x16 work item.  0 = every triangle through the work-item rasteriser.  Same map, bit
+                                          for bit (the hardware rasteriser of shadow_map_pass.cpp:96-97,157-167 / depth.hlsl:7-10 does not care either).
+                                          Not used where the shadow pass runs with block owners (ARCTIC_OPT_RASTER_OWNER bit 1) */
 #define ARCTIC_OPT_MARKERS          13 /* 1 = roctx ranges around each pass, named like the reference's Tracy zones (process-wide; libroctx64 is loaded on demand) */
 int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value);
 
