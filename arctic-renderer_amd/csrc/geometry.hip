@@ -35,6 +35,16 @@ namespace arctic {
 
 namespace {
 
+// Wave priority of the prepass kernels (s_setprio; 0 = the hardware's default).  A frame in flight runs its prepass beside the previous frame's shading
+// kernel, whose seven waves per SIMD take the issue slots oldest first: a prepass kernel is a short dependent chain per workgroup, and every instruction
+// of it waits its turn.  With a priority above the shading waves' the chain runs at its own length; the shading kernel gets the slots the chain leaves.
+// Measured (profiles/r5_p_prepass_priority_ab.txt, libraries alternating on one box): whole 4K frames within noise (0.2645-0.2665 / 0.3465-0.3499 ->
+// 0.2654-0.2658 / 0.3442-0.3474 ms), one rank of 8 as a row range 0.070 -> 0.066 ms, with the shadow map redrawn 0.164 -> 0.156; 3 measures like 1.
+#ifndef ARCTIC_PREPASS_PRIO
+#define ARCTIC_PREPASS_PRIO 1
+#endif
+__device__ __forceinline__ void prepass_priority() { if (ARCTIC_PREPASS_PRIO) __builtin_amdgcn_s_setprio(ARCTIC_PREPASS_PRIO); }
+
 constexpr float GUARD = 64.0f;  // guard band |x|,|y| <= GUARD*w keeps 24.8 coordinates inside int32
 constexpr int MAX_POLY = 10;
 
@@ -247,6 +257,7 @@ __global__ __launch_bounds__(256) void k_vertex(const ObjectRec *__restrict__ ob
                                                 XVert *__restrict__ xv, int clip_only, uint32_t *__restrict__ counters,
                                                 unsigned long long *__restrict__ clear, unsigned long long clear_value, size_t clear_count,
                                                 uint32_t *__restrict__ zero, size_t zero_count, const float *__restrict__ bounds) {
+    prepass_priority();
     // k_setup's slot counters and overflow flag (no memset launch); [6] counts this kernel's own skipped blocks when asked to (raster_flags bit 1: zeroed by the host then)
     if (blockIdx.x == 0 && threadIdx.x < N_GEO_COUNTERS && !((gp.raster_flags & 2) && threadIdx.x == 6)) counters[threadIdx.x] = 0;
     const ObjectRec &ob = objs[block_obj[blockIdx.x]];
@@ -554,6 +565,7 @@ template <bool SMALL>   // SMALL: the shadow pass -- triangles with a small boun
 __global__ __launch_bounds__(SETUP_THREADS) void k_setup(const ObjectRec *__restrict__ objs, const uint32_t *__restrict__ block_obj,
                                                          const uint32_t *__restrict__ block_first, const GeomParams gp,
                                                          const XVert *__restrict__ xv, SetupTables T, uint2 *__restrict__ clip_list, const float *__restrict__ bounds) {
+    prepass_priority();
     constexpr uint32_t WAVES = SETUP_THREADS / 64;
     __shared__ uint32_t s_count[WAVES][2], s_base[2];
     __shared__ SmallRec s_small[SMALL ? WAVES * 64 : 1];
@@ -618,6 +630,7 @@ __global__ __launch_bounds__(SETUP_THREADS) void k_setup(const ObjectRec *__rest
 // set-up, planning, one slot atomic and the writes happen once per round instead of once (twice: count, then write) per fan index.
 __global__ __launch_bounds__(64) void k_setup_clipped(const ObjectRec *__restrict__ objs, const GeomParams gp, const XVert *__restrict__ xv,
                                                       SetupTables T, const uint2 *__restrict__ clip_list) {
+    prepass_priority();
     __shared__ PolyStore P;
     __shared__ int s_n[CLIP_LANES], s_buf[CLIP_LANES];
     __shared__ uint32_t s_obj[CLIP_LANES], s_src[CLIP_LANES];
@@ -861,6 +874,7 @@ __global__ __launch_bounds__(256) void k_raster(const SetupRec *__restrict__ rec
                                                 const uint32_t *__restrict__ counters, const GeomParams gp,
                                                 unsigned long long *__restrict__ vis, uint32_t *__restrict__ depth_bits,
                                                 uint32_t *__restrict__ host_counts, uint32_t *__restrict__ host_overflow, uint32_t after_owned) {
+    prepass_priority();
     typedef typename KeyOf<DEPTH_ONLY>::type Key;
     constexpr Key NONE = (Key)~(Key)0;
     // records, work items and the overflow flag for the host (pinned, mapped memory: no copy launches); read after a synchronise
@@ -956,6 +970,7 @@ __global__ __launch_bounds__(256) void k_raster(const SetupRec *__restrict__ rec
 // block evaluates its bin with the block's 256 keys in registers and stores them once: that store is also the clear.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_bin(const uint2 *__restrict__ items, uint2 *__restrict__ left, uint32_t item_cap, uint32_t *__restrict__ counters, const BinTables B) {
+    prepass_priority();
     if (counters[2]) return;
     const uint32_t n_items = min(counters[1], item_cap);
     const uint32_t lane = threadIdx.x & 63;
@@ -990,6 +1005,7 @@ __global__ __launch_bounds__(256) void k_bin(const uint2 *__restrict__ items, ui
 template <bool DEPTH_ONLY>
 __global__ __launch_bounds__(256) void k_raster_owned(const RasterRec *__restrict__ rrecs, const BinTables B, const GeomParams gp,
                                                       unsigned long long *__restrict__ vis, uint32_t *__restrict__ depth_bits) {
+    prepass_priority();
     typedef typename KeyOf<DEPTH_ONLY>::type Key;
     constexpr Key NONE = (Key)~(Key)0;
     const uint32_t lane = threadIdx.x & 63;
