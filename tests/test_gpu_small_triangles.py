@@ -6,7 +6,8 @@ The reference hands every triangle to the hardware rasteriser (src/renderer/shad
 per texel whatever the path, so the map must be the same bit for bit, and the count of triangles set up (arctic_stats) with it.  Compared: the
 option off / on, and both against the oracle; scenes whose sun sees mostly small triangles (configs 2, 3), random triangle soups from sub-texel
 slivers to triangles larger than the map (whose scissored boxes can be small while their edge functions are not: the 32-bit bounds must refuse
-them), maps of ragged sizes, and a scissored (sharded) map.
+them), maps of ragged sizes, block owners in the shadow pass, whole frames under a moving sun.  (A scissored map -- a rank's slice of a sharded shadow map --
+runs with the path on in tests/test_gpu_exchange_loopback.py: every rank's map against the single-device map.)
 """
 import numpy as np
 import pytest
