@@ -101,6 +101,9 @@ constexpr uint32_t RASTER_EXACT_F64 = 1u;
 // barycentrics ARE the record's perspective-corrected ones -- (b0, b1, b2), or (b0, b2, b1) when set-up exchanged vertices 1 and 2
 // to orient the triangle (RASTER_SWAPPED) -- and b * 1 + b' * 0 + b'' * 0 is b bit for bit (the b are never negative zeros)
 constexpr uint32_t RASTER_UNIT_BARY = 2u, RASTER_SWAPPED = 4u;
+// every edge function of the record stays below 2^31 in magnitude over every 16x16 block its bounding box touches (k_setup: plan_triangle): the shadow
+// raster evaluates such a record's pixels in 32-bit integers from the binary64 value at its first pixel (item_pixels)
+constexpr uint32_t RASTER_I32 = 8u;
 // a work item = {record, block}: block = bx | by << 12 | ITEM_SCISSOR (the 16x16 block is cut by the scissor / the target's edge);
 // record ITEM_SKIP: an entry of a large record whose block no edge function reaches (its slot was taken before that was known)
 constexpr uint32_t SETUP_THREADS = 256;   // triangles per workgroup of k_setup (one slot atomic per workgroup).  512 is 1 us faster alone, but a 512-thread

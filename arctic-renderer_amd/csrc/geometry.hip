@@ -43,6 +43,11 @@ namespace {
 #ifndef ARCTIC_PREPASS_PRIO
 #define ARCTIC_PREPASS_PRIO 1
 #endif
+#ifndef ARCTIC_RASTER_I32
+#define ARCTIC_RASTER_I32 0   // 1: shadow-pass records whose edge functions fit 32 bits over their blocks are evaluated in integers (item_pixels).  Same map, 14 of 36 binary64-rate
+                              // instructions per item -- and SLOWER like every trim of this kernel before it (k_raster<true> 50.7 -> 53.0 us, 71.6 -> 78.3 without the small path:
+                              // profiles/r5_t_raster_int32_ab.txt): off
+#endif
 __device__ __forceinline__ void prepass_priority() { if (ARCTIC_PREPASS_PRIO) __builtin_amdgcn_s_setprio(ARCTIC_PREPASS_PRIO); }
 
 constexpr float GUARD = 64.0f;  // guard band |x|,|y| <= GUARD*w keeps 24.8 coordinates inside int32
@@ -376,6 +381,20 @@ __device__ __forceinline__ void plan_triangle(bool &has, const SetupRec &t, cons
     e.nbx = (uint32_t)((t.px1 >> 4) - e.bx0 + 1);
     e.nbb = tiles_of(t);
     e.nb = e.nbb;
+#if ARCTIC_RASTER_I32
+    if (gp.pitch != 0 && (e.q.flags & RASTER_EXACT_F64)) {   // (the shadow pass: gp.pitch is its map's)
+        // a plane is largest in magnitude at a corner of the block-aligned bounding box
+        const double xa = (double)(e.bx0 * 16), xb = (double)((t.px1 >> 4) * 16 + 15), ya = (double)(e.by0 * 16), yb = (double)((t.py1 >> 4) * 16 + 15);
+        double m = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double ca = __builtin_fma(e.q.B[i], ya, e.q.C[i]), cb = __builtin_fma(e.q.B[i], yb, e.q.C[i]);
+            m = fmax(m, fmax(fmax(fabs(__builtin_fma(e.q.A[i], xa, ca)), fabs(__builtin_fma(e.q.A[i], xb, ca))), fmax(fabs(__builtin_fma(e.q.A[i], xa, cb)), fabs(__builtin_fma(e.q.A[i], xb, cb)))));
+            m = fmax(m, fmax(fabs(e.q.A[i]), fabs(e.q.B[i])) * 64.0);
+        }
+        if (m < 2147480000.0) e.q.flags |= RASTER_I32;
+    }
+#endif
     if (e.nbb <= LANE_BLOCKS && (e.q.flags & RASTER_EXACT_F64)) {
         // block_reachable for every block of the bounding box, incrementally: per edge the value at the first block's best corner,
         // then + 16 A per block to the right, + 16 B per block down (exact: integers below 2^53); reachable <=> no negative value
@@ -710,6 +729,29 @@ __device__ __forceinline__ void item_pixels(const RasterRec &t, uint32_t code, u
     const bool cut = (code & ITEM_SCISSOR) != 0;   // the block is cut by the scissor: test every pixel against it
     const int32_t x0 = ox + (int32_t)(DEPTH_ONLY ? lane & 15u : lane & 7u), y0 = oy + (int32_t)(DEPTH_ONLY ? lane >> 4 : lane >> 3);
     const double xd = (double)x0, yd = (double)y0;
+#if ARCTIC_RASTER_I32
+    if (DEPTH_ONLY && !RAW && (t.flags & RASTER_I32)) {   // wave-uniform (the record sits in scalar registers)
+        // the three planes at the lane's first pixel in binary64 (exact integers below 2^31: plan_triangle), everything after that in 32-bit integers:
+        // the pixels (x0, y0 + 4k) are 4 B[i] apart; (float) of the same integer, the same depth expression: the same bits as below
+        int32_t v[3], sb[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { v[i] = (int32_t)__builtin_fma(t.A[i], xd, __builtin_fma(t.B[i], yd, t.C[i])); sb[i] = (int32_t)t.B[i]; }
+        const int32_t t0i = high_word(t.t0) != 0, t2i = high_word(t.t2) != 0;   // the thresholds are 0 or 1
+        int32_t out_x = 0;
+        if (cut) out_x = (x0 - fr.sc_x0) | (fr.sc_x1 - 1 - x0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k) { v[0] += sb[0] << 2; v[1] += sb[1] << 2; v[2] += sb[2] << 2; }
+            int32_t outside = (v[0] - t0i) | v[1] | (v[2] - t2i);
+            if (cut) { const int32_t py = y0 + 4 * k; outside |= out_x | (py - fr.sc_y0) | (fr.sc_y1 - 1 - py); }
+            const float l1 = (float)v[2] * t.inv_area, l2 = (float)v[0] * t.inv_area;
+            float z = fmaf(l2, t.dz2, fmaf(l1, t.dz1, t.z0));
+            z = fminf(fmaxf(z, 0.0f), 1.0f);
+            zb[k] = (outside >= 0 && z < 1.0f) ? __float_as_uint(z) : NO_DEPTH;
+        }
+        return;
+    }
+#endif
     double e[4][3];
     if (DEPTH_ONLY) {   // pixels (x0, y0 + 4k)
         const double yk[4] = {yd, yd + 4.0, yd + 8.0, yd + 12.0};

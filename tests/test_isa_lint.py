@@ -125,3 +125,14 @@ def test_ab_switches_still_compile(tmp_path, defines):
     out = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "--offload-device-only", "-ffp-contract=off", "-mllvm", "-disable-machine-licm",
                           *defines, "-c", src, "-o", str(tmp_path / "shade_variant.o")], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")
+def test_geometry_ab_switches_still_compile(tmp_path):
+    """the same for geometry.hip's switches: the shadow raster's 32-bit pixel evaluation (measured slower: profiles/r5_t_*), another bounding-box
+    limit of the set-up kernel's small-triangle path, the prepass kernels without a wave priority"""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = os.path.join(ROOT, "arctic-renderer_amd", "csrc", "geometry.hip")
+    out = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "--offload-device-only", "-ffp-contract=off", "-DARCTIC_RASTER_I32=1", "-DSMALL_PX=256",
+                          "-DARCTIC_PREPASS_PRIO=0", "-c", src, "-o", str(tmp_path / "geometry_variant.o")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
