@@ -331,7 +331,8 @@ hipError_t launch_raster_depth(const SetupRec *recs, const RasterRec *rrecs, con
 // block ownership: k_bin (work items -> bins) + k_raster_owned (one wave per block, the block written once); the atomic rasteriser
 // launched after them finds what they left (counters[4]) or nothing
 hipError_t launch_raster_owned(bool depth_only, const RasterRec *rrecs, const uint2 *items, uint2 *left /*what the bins did not take: counters[4] entries*/, uint32_t item_cap, uint32_t *counters, const BinTables &B,
-                               const GeomParams &gp, unsigned long long *vis, uint32_t *depth_bits, hipStream_t s);
+                               const GeomParams &gp, unsigned long long *vis, uint32_t *depth_bits,
+                               bool merge /*shadow pass: the map is cleared and holds k_setup's small triangles; owners merge into it and empty bins have none*/, hipStream_t s);
 hipError_t launch_resolve(const unsigned long long *vis, const SetupRec *recs, const RasterRec *rrecs, const uint32_t *rec_of, const ObjectRec *objs, const XVert *xv,
                           const GeomParams &gp, uint32_t n_tiles, GBuffer g, const TileHint &hint, hipStream_t s);
 // the shading pass's dispatch order (ShadeParams::tile_order) from the cost classes k_resolve left: lists = scratch of 2 N words, N = ceil(tiles_x / 4) *

@@ -1044,7 +1044,9 @@ __global__ __launch_bounds__(256) void k_bin(const uint2 *__restrict__ items, ui
     }
 }
 
-template <bool DEPTH_ONLY>
+// MERGE (the shadow pass beside k_setup's small-triangle path, round 5): the target was cleared and the small triangles are in it already -- an owner starts from
+// what its block holds instead of from nothing, and a block whose bin is empty (two thirds of a sun's map) has no owner at all
+template <bool DEPTH_ONLY, bool MERGE = false>
 __global__ __launch_bounds__(256) void k_raster_owned(const RasterRec *__restrict__ rrecs, const BinTables B, const GeomParams gp,
                                                       unsigned long long *__restrict__ vis, uint32_t *__restrict__ depth_bits) {
     prepass_priority();
@@ -1078,9 +1080,16 @@ __global__ __launch_bounds__(256) void k_raster_owned(const RasterRec *__restric
     // load does not wait for the counter
     const uint32_t my = lane < BIN_SLOTS ? B.slots[b * BIN_SLOTS + lane] : 0u;
     const uint32_t n = min(B.count[b], BIN_SLOTS);   // wave-uniform (scalar load)
+    if (MERGE && n == 0) return;
     // keys with depth bits of 0x3F800000 (a covered pixel at depth 1.0: fails LESS against the clear) or 0xFFFFFFFF (not covered)
     // lose against every drawn pixel in the merge and are turned into "nothing drawn" once, at the end
     Key acc[4] = {NONE, NONE, NONE, NONE};
+    if (MERGE) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (mine[k]) acc[k] = DEPTH_ONLY ? (Key) * (const uint32_t __attribute__((address_space(1))) *)((gbytes)depth_bits + at[k] * 4u)
+                                             : (Key) * (const unsigned long long __attribute__((address_space(1))) *)((gbytes)vis + at[k] * 8u);
+    }
     const auto merge = [&](const RasterRec &q) {
         uint32_t zb[4];
         item_pixels<DEPTH_ONLY, true>(q, code, lane, fr, zb);
@@ -1332,12 +1341,13 @@ hipError_t launch_raster_vis(const SetupRec *recs, const RasterRec *rrecs, const
 }
 
 hipError_t launch_raster_owned(bool depth_only, const RasterRec *rrecs, const uint2 *items, uint2 *left, uint32_t item_cap, uint32_t *counters, const BinTables &B,
-                               const GeomParams &gp, unsigned long long *vis, uint32_t *depth_bits, hipStream_t s) {
+                               const GeomParams &gp, unsigned long long *vis, uint32_t *depth_bits, bool merge, hipStream_t s) {
     // the item count stays on the device: a fixed grid strides over the table
     k_bin<<<std::min<uint32_t>(div_up(item_cap, 256u), 1024u), 256, 0, s>>>(items, left, item_cap, counters, B);
     const uint32_t n = B.grid_x * B.grid_y;
     if (n) {
-        if (depth_only) k_raster_owned<true><<<div_up(n, 4), 256, 0, s>>>(rrecs, B, gp, vis, depth_bits);
+        if (depth_only && merge) k_raster_owned<true, true><<<div_up(n, 4), 256, 0, s>>>(rrecs, B, gp, vis, depth_bits);
+        else if (depth_only) k_raster_owned<true><<<div_up(n, 4), 256, 0, s>>>(rrecs, B, gp, vis, depth_bits);
         else k_raster_owned<false><<<div_up(n, 4), 256, 0, s>>>(rrecs, B, gp, vis, depth_bits);
     }
     return hipGetLastError();

@@ -483,6 +483,8 @@ int run_geometry(ArcticRenderer *r, const ArcticScene *sc, bool shadow_pass, hip
     // meshes: 14 % of the items beyond their bins) 0.106 / 0.093, config 1 (512^2) 0.064 / 0.038;
     // never the shadow pass (instruction bound, two thirds of its blocks empty: 0.124 -> 0.163 ms)
     const bool owned = r->raster_owner < 0 ? (!shadow_pass && (uint64_t)r->rows() * r->width >= 4000000ull) : (r->raster_owner & (shadow_pass ? 2 : 1)) != 0;
+    // owners beside the small-triangle path: the map is cleared as without owners, k_setup draws the small triangles into it, the owners MERGE their bins into it
+    const bool merge = owned && shadow_pass && r->small_triangles && !(r->debug & 32);
     BinTables B{};
     if (owned) {
         const uint32_t tw = shadow_pass ? r->shadow_size : r->width, th = shadow_pass ? r->shadow_size : r->height;
@@ -510,7 +512,7 @@ int run_geometry(ArcticRenderer *r, const ArcticScene *sc, bool shadow_pass, hip
     G.n_tblocks = n_tblocks; G.n_vblocks = n_vblocks; G.cull_counted = (r->debug & 1024) != 0;
     if (G.cull_counted) HIPCHECK(r, hipMemsetAsync(r->d_geo_counters.as<uint32_t>() + N_GEO_COUNTERS * set + 6, 0, 4, stream));   // (k_vertex counts into it from its first workgroup on)
     HIPCHECK(r, launch_vertex(objs, T.vblock_obj, T.vblock_first, n_vblocks, d_gp, G.d_xverts.as<XVert>(), shadow_pass ? 1 : 0,
-                              r->d_geo_counters.as<uint32_t>() + N_GEO_COUNTERS * set, clear, clear_value, owned ? 0 : clear_count, B.count, owned ? B.n_blocks : 0,
+                              r->d_geo_counters.as<uint32_t>() + N_GEO_COUNTERS * set, clear, clear_value, (owned && !merge) ? 0 : clear_count, B.count, owned ? B.n_blocks : 0,
                               (r->cluster_cull & 2) ? T.vblock_bounds : nullptr, stream));
     // Record slots: a triangle clipped against 6 planes yields at most 7 triangles, so 7 * n_src slots can never overflow.
     // Records and work items are allocated on the device from two counters (k_setup): no count pass, no scan, and neither
@@ -537,8 +539,8 @@ int run_geometry(ArcticRenderer *r, const ArcticScene *sc, bool shadow_pass, hip
     HIPCHECK(r, launch_setup(objs, T.tblock_obj, T.tblock_first, n_tblocks, d_gp, G.d_xverts.as<XVert>(), G.d_recs.as<SetupRec>(),
                              G.d_rrecs.as<RasterRec>(), G.d_rec_of.as<uint32_t>(), G.d_items.as<uint2>(), G.item_cap, n_slots, counters,
                              G.d_clip_list.as<uint2>(), (r->cluster_cull & 1) ? T.tblock_bounds : nullptr,
-                             // (block owners STORE their blocks -- that store is the clear --, so nothing may be drawn before them)
-                             shadow_pass && !owned && r->small_triangles ? r->d_shadow().as<uint32_t>() : nullptr, stream));
+                             // (block owners STORE their blocks -- that store is the clear --, so nothing may be drawn before them unless they merge)
+                             shadow_pass && (!owned || merge) && r->small_triangles ? r->d_shadow().as<uint32_t>() : nullptr, stream));
     // counts for arctic_stats() and the overflow flag: k_raster stores them into pinned, mapped memory (no copy launches between
     // the kernels); looked at only when the stream has been synchronised
     uint32_t *dh = r->dh_counts + (shadow_pass ? 2 : 0), *dh_overflow = r->dh_counts + 4 + (shadow_pass ? 1 : 0);
@@ -546,7 +548,7 @@ int run_geometry(ArcticRenderer *r, const ArcticScene *sc, bool shadow_pass, hip
     const uint2 *draw = G.d_items.as<uint2>();
     if (owned) {
         HIPCHECK(r, launch_raster_owned(shadow_pass, G.d_rrecs.as<RasterRec>(), G.d_items.as<uint2>(), G.d_left.as<uint2>(), G.item_cap, counters, B, d_gp,
-                                        shadow_pass ? nullptr : r->d_vis().as<unsigned long long>(), shadow_pass ? r->d_shadow().as<uint32_t>() : nullptr, stream));
+                                        shadow_pass ? nullptr : r->d_vis().as<unsigned long long>(), shadow_pass ? r->d_shadow().as<uint32_t>() : nullptr, merge, stream));
         // what the bins left goes through the atomic rasteriser: when the previous pass left next to nothing (pinned h_counts, a frame
         // late: it only sizes the grid) a launch of 64 workgroups, else the whole persistent grid -- the kernel shortens its chunks
         // so that every resident wave gets one (a grid cut to the item count measured slower: config 1, half of whose items are left)

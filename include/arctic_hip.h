@@ -336,7 +336,8 @@ int arctic_stats(ArcticRenderer *r, uint64_t *out, uint32_t n);
                                           box, one atomicMin per covered pixel -- such a triangle (two thirds of what an orthographic sun sees of a tessellated
                                           scene) never becomes a record or a 16x16 work item.  0 = every triangle through the work-item rasteriser.  Same map, bit
                                           for bit (the hardware rasteriser of shadow_map_pass.cpp:96-97,157-167 / depth.hlsl:7-10 does not care either).
-                                          Not used where the shadow pass runs with block owners (ARCTIC_OPT_RASTER_OWNER bit 1) */
+                                          Where the shadow pass runs with block owners (ARCTIC_OPT_RASTER_OWNER bit 1) the owners merge their bins into the map
+                                          this path has drawn into, and blocks with an empty bin have no owner (measured: no faster than the atomic rasteriser) */
 #define ARCTIC_OPT_MARKERS          13 /* 1 = roctx ranges around each pass, named like the reference's Tracy zones (process-wide; libroctx64 is loaded on demand) */
 int arctic_set_option(ArcticRenderer *r, uint32_t option, int64_t value);
 

@@ -15,9 +15,10 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def shadow(hip, sc, small, desc=None, debug=0):
+def shadow(hip, sc, small, desc=None, debug=0, owner=-1):
     r = sc.upload(hip.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights))
     r.set_option("small_triangles", small)
+    r.set_option("raster_owner", owner)
     if debug:
         r.set_option("debug", debug)
     r.pass_shadow_map(desc or sc.desc)
@@ -74,6 +75,9 @@ def test_triangle_soup(pkg, hip, oracle, S, n, lo, hi, spread):
     (mi, si) = shadow(hip, sc, 1, debug=32)    # the integer path forced: the small path stands back (the switch is an A/B of the item rasterisers)
     np.testing.assert_array_equal(m0, mi)
     assert si[3] >= s0[3]                      # every triangle became work items again (the integer path has no reachability masks: a few more than off)
+    (mo, so) = shadow(hip, sc, 1, owner=2)     # block owners in the shadow pass MERGE into the map the set-up kernel has drawn the small triangles into; bins that overflow
+    np.testing.assert_array_equal(m0, mo)      # (dense soups) leave their items to the atomic rasteriser behind them
+    assert so[2] == s0[2] and so[3] == s1[3]
     if S <= 1000:
         o = sc.upload(oracle.Oracle(sc.width, sc.height, sc.shadow_size, sc.max_lights))
         o.pass_shadow_map(sc.desc)
@@ -82,16 +86,16 @@ def test_triangle_soup(pkg, hip, oracle, S, n, lo, hi, spread):
         o.close()
 
 
-def test_block_owners_in_the_shadow_pass_keep_their_map(pkg, hip):
-    """owners STORE their blocks (the store is the clear): the small path must not draw in front of them"""
-    sc = pkg.scenes.config3(scale=0.25)
-    ref, _ = shadow(hip, sc, 0)
-    r = sc.upload(hip.Renderer(sc.width, sc.height, sc.shadow_size, sc.max_lights))
-    r.set_option("raster_owner", 3)
-    r.set_option("small_triangles", 1)
-    r.pass_shadow_map(sc.desc); r.pass_shadow_map(sc.desc)
-    np.testing.assert_array_equal(r.read_shadow_map().view(np.uint32), ref)
-    r.close()
+@pytest.mark.parametrize("cfg,scale", [(2, 0.5), (3, 0.25), (3, 0.5)])
+def test_block_owners_in_the_shadow_pass_keep_their_map(pkg, hip, cfg, scale):
+    """owners alone STORE their blocks (the store is the clear); beside the small path the map is cleared, the set-up kernel draws the small triangles and the
+    owners of non-empty bins merge into it: the same map either way, and with the integer rasteriser forced (classic owners, no small path)"""
+    sc = pkg.scenes.CONFIGS[cfg](scale=scale)
+    ref, s0 = shadow(hip, sc, 0)
+    for small, debug in ((1, 0), (0, 0), (1, 32)):
+        m, st = shadow(hip, sc, small, owner=3, debug=debug)
+        np.testing.assert_array_equal(m, ref)
+        assert st[2] == s0[2]
 
 
 def test_whole_frames_with_a_moving_sun(pkg, hip):
