@@ -48,6 +48,9 @@ namespace {
                               // instructions per item -- and SLOWER like every trim of this kernel before it (k_raster<true> 50.7 -> 53.0 us, 71.6 -> 78.3 without the small path:
                               // profiles/r5_t_raster_int32_ab.txt): off
 #endif
+#ifndef ARCTIC_RASTER_WGW
+#define ARCTIC_RASTER_WGW 4   // waves per workgroup of k_bin / k_raster_owned (their waves are independent of each other): an A/B switch beside ARCTIC_VIS_WG_WAVES (shade.hip)
+#endif
 __device__ __forceinline__ void prepass_priority() { if (ARCTIC_PREPASS_PRIO) __builtin_amdgcn_s_setprio(ARCTIC_PREPASS_PRIO); }
 
 constexpr float GUARD = 64.0f;  // guard band |x|,|y| <= GUARD*w keeps 24.8 coordinates inside int32
@@ -1011,12 +1014,12 @@ __global__ __launch_bounds__(256) void k_raster(const SetupRec *__restrict__ rec
 // returning atomic per ITEM on the block's counter -- 160 k per 4K frame instead of 1.47 M per-pixel requests), then one wave per
 // block evaluates its bin with the block's 256 keys in registers and stores them once: that store is also the clear.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_bin(const uint2 *__restrict__ items, uint2 *__restrict__ left, uint32_t item_cap, uint32_t *__restrict__ counters, const BinTables B) {
+__global__ __launch_bounds__(64 * ARCTIC_RASTER_WGW) void k_bin(const uint2 *__restrict__ items, uint2 *__restrict__ left, uint32_t item_cap, uint32_t *__restrict__ counters, const BinTables B) {
     prepass_priority();
     if (counters[2]) return;
     const uint32_t n_items = min(counters[1], item_cap);
     const uint32_t lane = threadIdx.x & 63;
-    for (uint32_t first = blockIdx.x * 256 + (threadIdx.x & ~63u); first < n_items; first += gridDim.x * 256) {   // uniform per wave
+    for (uint32_t first = blockIdx.x * (64u * ARCTIC_RASTER_WGW) + (threadIdx.x & ~63u); first < n_items; first += gridDim.x * (64u * ARCTIC_RASTER_WGW)) {   // uniform per wave
         const uint32_t i = first + lane;
         bool keep = false;     // not binned: the atomic rasteriser draws it
         uint2 en = make_uint2(ITEM_SKIP, 0u);
@@ -1047,13 +1050,13 @@ __global__ __launch_bounds__(256) void k_bin(const uint2 *__restrict__ items, ui
 // MERGE (the shadow pass beside k_setup's small-triangle path, round 5): the target was cleared and the small triangles are in it already -- an owner starts from
 // what its block holds instead of from nothing, and a block whose bin is empty (two thirds of a sun's map) has no owner at all
 template <bool DEPTH_ONLY, bool MERGE = false>
-__global__ __launch_bounds__(256) void k_raster_owned(const RasterRec *__restrict__ rrecs, const BinTables B, const GeomParams gp,
+__global__ __launch_bounds__(64 * ARCTIC_RASTER_WGW) void k_raster_owned(const RasterRec *__restrict__ rrecs, const BinTables B, const GeomParams gp,
                                                       unsigned long long *__restrict__ vis, uint32_t *__restrict__ depth_bits) {
     prepass_priority();
     typedef typename KeyOf<DEPTH_ONLY>::type Key;
     constexpr Key NONE = (Key)~(Key)0;
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t w = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t w = blockIdx.x * ARCTIC_RASTER_WGW + (ARCTIC_RASTER_WGW == 1 ? 0u : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
     if (w >= B.grid_x * B.grid_y) return;
     const uint32_t bx = w % B.grid_x, gy = w / B.grid_x;
     const uint32_t by = owner_block_row(gy, B.by0, B.local_rows, gp.band_tiles, gp.shard_count, gp.shard_index, gp.tile_y0);   // block row of the target
@@ -1343,12 +1346,12 @@ hipError_t launch_raster_vis(const SetupRec *recs, const RasterRec *rrecs, const
 hipError_t launch_raster_owned(bool depth_only, const RasterRec *rrecs, const uint2 *items, uint2 *left, uint32_t item_cap, uint32_t *counters, const BinTables &B,
                                const GeomParams &gp, unsigned long long *vis, uint32_t *depth_bits, bool merge, hipStream_t s) {
     // the item count stays on the device: a fixed grid strides over the table
-    k_bin<<<std::min<uint32_t>(div_up(item_cap, 256u), 1024u), 256, 0, s>>>(items, left, item_cap, counters, B);
+    k_bin<<<std::min<uint32_t>(div_up(item_cap, 64u * ARCTIC_RASTER_WGW), 4096u / ARCTIC_RASTER_WGW), 64 * ARCTIC_RASTER_WGW, 0, s>>>(items, left, item_cap, counters, B);
     const uint32_t n = B.grid_x * B.grid_y;
     if (n) {
-        if (depth_only && merge) k_raster_owned<true, true><<<div_up(n, 4), 256, 0, s>>>(rrecs, B, gp, vis, depth_bits);
-        else if (depth_only) k_raster_owned<true><<<div_up(n, 4), 256, 0, s>>>(rrecs, B, gp, vis, depth_bits);
-        else k_raster_owned<false><<<div_up(n, 4), 256, 0, s>>>(rrecs, B, gp, vis, depth_bits);
+        if (depth_only && merge) k_raster_owned<true, true><<<div_up(n, ARCTIC_RASTER_WGW), 64 * ARCTIC_RASTER_WGW, 0, s>>>(rrecs, B, gp, vis, depth_bits);
+        else if (depth_only) k_raster_owned<true><<<div_up(n, ARCTIC_RASTER_WGW), 64 * ARCTIC_RASTER_WGW, 0, s>>>(rrecs, B, gp, vis, depth_bits);
+        else k_raster_owned<false><<<div_up(n, ARCTIC_RASTER_WGW), 64 * ARCTIC_RASTER_WGW, 0, s>>>(rrecs, B, gp, vis, depth_bits);
     }
     return hipGetLastError();
 }

@@ -39,7 +39,10 @@
                                 // 5.1 instead of 4.5 waves resident per SIMD.  Round 4 measured them faster with few lights and 1.8 % slower at 64 (with its dispatch order on);
                                 // on round 5's build, order off: 64 / 16 / 0 lights 0.1874 / 0.1273 / 0.0951 -> 0.1857 / 0.1224 / 0.0936 ms (profiles/r5_l_ab_one_wave_workgroups.txt).
                                 // k_material_vis keeps 4 (VIS_WG_WAVES): whole frames are 9 % slower with one.
-constexpr int VIS_WG_WAVES = 4;   // (2 and 1 measured: whole frames 0.2765 -> 0.2955 / 0.2964 ms, profiles/r5_l_ab_one_wave_workgroups.txt)
+#ifndef ARCTIC_VIS_WG_WAVES
+#define ARCTIC_VIS_WG_WAVES 4
+#endif
+constexpr int VIS_WG_WAVES = ARCTIC_VIS_WG_WAVES;   // (2 and 1 measured: whole frames 0.2765 -> 0.2955 / 0.2964 ms, profiles/r5_l_ab_one_wave_workgroups.txt)
 #ifndef ARCTIC_LUT_SHARED
 #define ARCTIC_LUT_SHARED 0     // A/B switch: 1 = each wave of a workgroup loads a quarter of the sRGB table (256 B instead of 1 KiB per wave) and a barrier stands behind the stores
 #endif
@@ -1531,7 +1534,11 @@ __global__ __launch_bounds__(256) void k_post_process(const float4 *__restrict__
 
 template <int LOOP, bool STATS, bool LDS_SHADOW>
 hipError_t launch_variant(const ShadeParams &sp, const ShadeLaunch &L, dim3 grid) {
-    if (L.from_vis) { k_material_vis<LOOP, STATS, LDS_SHADOW><<<grid, 64 * VIS_WG_WAVES, 0, L.stream>>>(sp); return hipGetLastError(); }
+    if (L.from_vis) {
+        if (VIS_WG_WAVES == 1) grid.x = (grid.x + 7) / 8 * 32;   // (block_id, as below)
+        k_material_vis<LOOP, STATS, LDS_SHADOW><<<grid, 64 * VIS_WG_WAVES, 0, L.stream>>>(sp);
+        return hipGetLastError();
+    }
     if (ARCTIC_WG_WAVES == 1) grid.x = (grid.x + 7) / 8 * 32;   // (block_id: four one-wave blocks per strip, a strip's blocks on one XCD)
     k_material<LOOP, STATS, LDS_SHADOW><<<grid, 64 * ARCTIC_WG_WAVES, 0, L.stream>>>(sp);
     return hipGetLastError();

@@ -115,7 +115,7 @@ def test_shading_kernels_keep_their_register_budgets(shade_isa):
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")
 @pytest.mark.parametrize("defines", [("-DARCTIC_WG_WAVES=4", "-DARCTIC_EDGE_IN_FAST=0"),
-                                     ("-DARCTIC_LUT_SHARED=1", "-DARCTIC_PCF_CANDIDATES=1", "-DARCTIC_PCF_ROW_CANDIDATES=1")],
+                                     ("-DARCTIC_LUT_SHARED=1", "-DARCTIC_PCF_CANDIDATES=1", "-DARCTIC_PCF_ROW_CANDIDATES=1", "-DARCTIC_VIS_WG_WAVES=1")],
                          ids=["four-wave-workgroups+edge-tiles-to-general-tile", "shared-lut+pcf-candidates"])
 def test_ab_switches_still_compile(tmp_path, defines):
     """the A/B compile switches of shade.hip (measured variants kept behind a default: DESIGN 4.2c, profiles/r4_c_*, r5_a_*, r5_b_*) build for gfx950 with
@@ -134,5 +134,5 @@ def test_geometry_ab_switches_still_compile(tmp_path):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     src = os.path.join(ROOT, "arctic-renderer_amd", "csrc", "geometry.hip")
     out = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "--offload-device-only", "-ffp-contract=off", "-DARCTIC_RASTER_I32=1", "-DSMALL_PX=256",
-                          "-DARCTIC_PREPASS_PRIO=0", "-c", src, "-o", str(tmp_path / "geometry_variant.o")], capture_output=True, text=True, timeout=900)
+                          "-DARCTIC_PREPASS_PRIO=0", "-DARCTIC_RASTER_WGW=1", "-c", src, "-o", str(tmp_path / "geometry_variant.o")], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
