@@ -3,7 +3,8 @@ Bars as in tests/test_gpu_parity.py: shadow map / G-buffer bit-exact, float LDR 
 where the reference formula itself is ill-conditioned in fp32 (tests/test_oracle_noise_floor.py: grazing views with
 n.wo ~ 1e-6, low-roughness highlights): a pixel whose LITERAL fp32 evaluation (oracle precision 32) is itself more than
 5e-5 away from the float64 value, or whose float64 value moves by more than 2.5e-5 when tangent frame and world position
-move by one fp32 ulp of their vectors' magnitudes, is reported and must stay within 4x the larger of those two distances instead.
+move by one fp32 ulp of their vectors' magnitudes, is reported; since the end of round 5 it must hold the 1e-4 like every other pixel unless ARCTIC_FUZZ_ALLOW_ILL=1
+(then: within 4x the larger of those two distances instead).
 usage: python tools/fuzz_parity.py [n_cases] [seed] [only] [size_factor] [jitter]   (size_factor 8: frames of 2-3 Mpx, where the
 rasteriser merges chunks of 32 work items per wave; the default small frames give every wave a single item.  jitter 1: odd frame
 and shadow-map sizes -- ragged tiles, scissored windows, a bounds table whose last blocks are cut --, object transforms, materials with unequal image sizes, and the culling / light-loop options of the HIP side)"""
@@ -94,7 +95,10 @@ for case in range(n_cases):
     n_ill, worst_ill = int(ill.sum()), float(e_hip[ill].max()) if ill.any() else 0.0
     mism = float((orgba != hrgba).mean())
     cov = float((og[1] != 0xFFFFFFFF).mean())
-    ok = sm_ok and gb_ok and err <= 1e-4 and ill_ok and np.abs(orgba.astype(int) - hrgba.astype(int)).max() <= 1 and np.array_equal(img, hrgba)
+    # STRICT by default: EVERY pixel within 1e-4 of the float64 oracle, as in the pytest suite; the conditioning census above is reported, and only
+    # ARCTIC_FUZZ_ALLOW_ILL=1 lets pixels it marks ill-conditioned pass at 4x the literal fp32 evaluation's own distance (scenes with grazing views under a normal map)
+    strict = os.environ.get("ARCTIC_FUZZ_ALLOW_ILL") != "1"
+    ok = sm_ok and gb_ok and err <= 1e-4 and (float(e_hip.max()) <= 1e-4 if strict else ill_ok) and np.abs(orgba.astype(int) - hrgba.astype(int)).max() <= 1 and np.array_equal(img, hrgba)
     shard_note = ""
     if ok and case % 3 == 0:   # a random interleaved shard of the same frame must reproduce its rows byte for byte
         from importlib import import_module
