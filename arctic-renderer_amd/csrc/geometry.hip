@@ -12,7 +12,9 @@
 //   vertex  : 1 thread / vertex -> XVert[] (coalesced 96 B records); the launch also clears the pass's target and the counters
 //   setup   : 1 thread / triangle inside all clip planes: set up, take record and work-item slots from one device counter (one
 //             64-bit atomicAdd per workgroup) -> SetupRec[] + RasterRec[] in arbitrary order + explicit work items
-//             (record, 16x16 block), only blocks an edge function can reach; triangles a plane cuts -> clip list
+//             (record, 16x16 block), only blocks an edge function can reach; triangles a plane cuts -> clip list.
+//             Shadow pass (k_setup<true>, round 5): a triangle whose bounding box holds at most SMALL_PX pixels -- two thirds of what an
+//             orthographic sun sees -- is drawn HERE, a lane per box pixel with 32-bit edge functions, and never becomes a record or a work item
 //   clipped : the clip list, a lane per triangle: Sutherland-Hodgman in LDS, then the same set-up per fan triangle
 //   bin + owned raster (forward pass): every 16x16 block of the target has a bin of 32 record indices and ONE owner wave that merges
 //             the bin in registers and stores the block once -- no clear, no early read, no per-pixel atomic (k_bin, k_raster_owned)
@@ -509,6 +511,7 @@ struct SmallRec {       // 64 B in LDS, one per small triangle of the wave, in l
 };
 static_assert(sizeof(SmallRec) == 64, "SmallRec layout");
 constexpr uint32_t SMALL_WORDS = (SMALL_PX * 64u + 31u) / 32u + 2u;   // start bits of a wave's pixel list (+ the 64-bit read at its end)
+static_assert(SMALL_PX <= 1023, "SmallRec::span holds a slot of the wave's list (64 SMALL_PX of them) in 16 bits, and slot -> box coordinates is exact while 64 * slot < 65536");
 
 // is the triangle small, and if so its SmallRec (span without the slot, which the caller knows after the wave's prefix sum)
 __device__ __forceinline__ bool small_record(const SetupRec &t, SmallRec &s, uint32_t &n) {
